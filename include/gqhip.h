@@ -1,0 +1,156 @@
+/*
+ * gqhip.h -- C ABI of libgqhip.so, the MI355X (gfx950) implementation of the
+ * reference's Gaussian-quantiser inference hot path.
+ *
+ * Plain pointers and sizes only: every pointer is a DEVICE pointer (hipMalloc /
+ * torch CUDA tensor .data_ptr()) unless its name ends in _host; `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  All entry points
+ * are asynchronous on `stream`, never synchronise, never allocate, and return
+ * a gqhip_status (0 = success) instead of throwing.  They are re-entrant and
+ * hold no global state except the optional profiling recorder.
+ *
+ * Reference interface each entry point replaces (paths under /root/reference):
+ *
+ *   gq_scores_f32    gq_cuda_extension/gq_cuda/csrc/cuda/gq_cuda.cu:77-118
+ *                    (host launcher `gq_cuda`, schema csrc/gq_cuda.cpp:29-31,
+ *                    python gq_cuda/ops.py:7-8) -- fills out[b, n].
+ *   gq_argmax_f32    pit/quantization/gaussian.py:124-150 -- the whole
+ *                    "score matrix -> argmax -> index_select" block (K1+K2+K3 /
+ *                    K4 of SURVEY.md 2.3), fused; indices are those of the
+ *                    reference's torch CPU backend (gaussian.py:134-150).
+ *   gq_quantize_z_f32 pit/quantization/gaussian.py:61-81,120-160 (GQ1) and
+ *                    :273-331 (GQ2.quant_vq) -- also folds the chunk/clamp/exp
+ *                    and the group permutes into the kernels.
+ *   gq_dequant_f32   pit/quantization/gaussian.py:162-178, :347-362.
+ *   vq_argmin_f32    pit/quantization/vq.py:58-73.
+ *   lfq_pack_f32     pit/quantization/lfq.py:147-158.
+ *   lfq_unpack_f32   pit/quantization/lfq.py:210-228.
+ *   gq_index_histogram eval.py:127,137-141,152-154 (stubbed-out histogram).
+ */
+#ifndef GQHIP_H_
+#define GQHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GQHIP_ABI_VERSION 1
+
+typedef enum gqhip_status {
+  GQHIP_OK = 0,
+  GQHIP_ERR_INVALID_ARG = 1,   /* NULL pointer, negative size, unsupported dim */
+  GQHIP_ERR_WORKSPACE = 2,     /* workspace too small / NULL                  */
+  GQHIP_ERR_LAUNCH = 3,        /* hipGetLastError() != hipSuccess after launch */
+  GQHIP_ERR_NO_DEVICE = 4
+} gqhip_status;
+
+int gqhip_abi_version(void);
+const char *gqhip_status_string(int status);
+/* last hipError_t observed by a failing call on this thread (0 if none). */
+int gqhip_last_hip_error(void);
+
+/* ---- workspace ------------------------------------------------------------
+ * Bytes of scratch gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32 need for
+ * `rows` rows against `n` codes of width `dim`.  The caller allocates once
+ * (device memory, 256-B aligned) and reuses it; contents are don't-care. */
+int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim);
+
+/* max |cb[j,i]| over the codebook -> *absmax_out (device float).  Callers cache
+ * the value per codebook and pass it to the fused entry points (cb_absmax);
+ * passing cb_absmax <= 0 makes them recompute it (one extra tiny kernel). */
+int gqhip_codebook_absmax(const float *cb, int64_t n, int64_t dim,
+                          float *absmax_out, void *stream);
+
+/* ---- compat op: the reference's native boundary ---------------------------
+ * out[r, j] = sum_i -((cb[j,i]-mu[r,i])/sd[r,i])^2 + cb[j,i]^2 * beta
+ * mu, sd [rows, dim]; cb [n, dim]; out [rows, n]; all fp32 contiguous. */
+int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
+                  int64_t dim, int64_t rows, int64_t n, double beta,
+                  void *stream);
+
+/* ---- fused score + argmax + gather ----------------------------------------
+ * idx[r]  = argmax_j of the reference torch-backend score (first max wins,
+ *           NaN counts as max), bit-identical to the CPU reference given the
+ *           same (mu, sd, logsd).
+ * zhat[r] = cb[idx[r]]  (optional, may be NULL).
+ * logsd_or_null: log(sd) as the caller computed it; NULL -> the kernel uses
+ *           float(log(double(sd))) (correctly rounded).
+ * cb_absmax: cached max|cb| (see gqhip_codebook_absmax) or <= 0.
+ * dim: any 1..64 (4, 8, 16, 32 run on the MFMA filter; others exhaustive). */
+int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null,
+                  const float *cb, int64_t *idx, float *zhat_or_null,
+                  int64_t dim, int64_t rows, int64_t n, double beta,
+                  float cb_absmax, void *workspace, int64_t workspace_bytes,
+                  void *stream);
+
+/* ---- module-level fused quantiser -----------------------------------------
+ * z is the encoder output holding [mu | logvar] along its channel axis.
+ * layout: GQHIP_LAYOUT_BCHW  z [B, 2c, L] (L = h*w)   -> idx [B, K, L], zhat [B, c, L]
+ *         GQHIP_LAYOUT_BLC   z [B, L, 2c]             -> idx [B, L, K], zhat [B, L, c]
+ * grouping: GQHIP_GROUP_STRIDED    (GaussianQuantRegularizer : column g of
+ *                                   sub-codebook k <- channel g*K + k)
+ *           GQHIP_GROUP_CONTIGUOUS (GaussianQuantRegularizer2: channel k*dim + g)
+ * K = c / dim.  logvar is clamped to [lv_min, lv_max]; sd = exp(0.5*logvar) and
+ * log(sd) are evaluated in fp64 and rounded once (numerics).
+ * mu_out/sd_out (optional, [rows, dim], row = (b*L + l)*K + k) receive the
+ * permuted operands so callers/tests can replay them through the oracle. */
+#define GQHIP_LAYOUT_BCHW 0
+#define GQHIP_LAYOUT_BLC 1
+#define GQHIP_GROUP_STRIDED 0
+#define GQHIP_GROUP_CONTIGUOUS 1
+int gq_quantize_z_f32(const float *z, const float *cb, int64_t *idx,
+                      float *zhat_or_null, float *mu_out_or_null,
+                      float *sd_out_or_null, int64_t B, int64_t L, int64_t c,
+                      int64_t dim, int64_t n, int layout, int grouping,
+                      double lv_min, double lv_max, double beta,
+                      float cb_absmax, void *workspace,
+                      int64_t workspace_bytes, void *stream);
+
+/* zhat from indices (same layouts as above). */
+int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B,
+                   int64_t L, int64_t K, int64_t dim, int64_t n, int layout,
+                   int grouping, void *stream);
+
+/* ---- VQ: argmin_j |z_r - e_j|^2 (fp64 arbiter, first min wins) ------------- */
+int vq_argmin_f32(const float *z, const float *emb, int64_t *idx,
+                  float *zq_or_null, int64_t dim, int64_t rows, int64_t n,
+                  float emb_absmax, void *workspace, int64_t workspace_bytes,
+                  void *stream);
+
+/* ---- LFQ: sign quantisation + big-endian bit pack -------------------------- */
+int lfq_pack_f32(const float *x, int64_t *idx, float *q_or_null, int64_t rows,
+                 int64_t nbits, void *stream);
+int lfq_unpack_f32(const int64_t *idx, float *q, int64_t rows, int64_t nbits,
+                   void *stream);
+
+/* ---- index wire format / usage histogram ----------------------------------- */
+int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n,
+                       int32_t *hist, void *stream);
+int gq_indices_to_u16(const int64_t *idx, uint16_t *out, int64_t count,
+                      void *stream);
+int gq_indices_from_u16(const uint16_t *in, int64_t *idx, int64_t count,
+                        void *stream);
+
+/* ---- profiling recorder ------------------------------------------------------
+ * When enabled, every launch of the MFMA filter kernel is bracketed with
+ * hipEvents on its own stream.  gqhip_profile_collect synchronises those
+ * events and returns the number of launches and their total/avg milliseconds;
+ * it resets the recorder.  Disabled by default (zero overhead). */
+int gqhip_profile_enable(int on);
+int gqhip_profile_collect(int *launches_host, double *total_ms_host);
+
+/* Diagnostics of the last fused call on `workspace` (device-side counters,
+ * copied out synchronously): rows sent to the exhaustive fallback and total
+ * half-tiles re-ranked.  For tests / DESIGN.md statistics only. */
+/* on != 0: the re-rank kernel also counts re-ranked half-tiles (adds one
+ * contended atomic per row -- keep off when timing). */
+int gqhip_debug_enable(int on);
+int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
+                         int64_t *reranked_halftiles_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GQHIP_H_ */

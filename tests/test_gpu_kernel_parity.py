@@ -1,0 +1,121 @@
+"""-m gpu: the HIP fused path (through the C ABI) against the CPU oracle at the
+kernel boundary (mu, sd, log sd) -> indices.  Bit-exact (integer indices).
+Mirrors what a test of the reference's gq_cuda op + argmax would assert
+(gq_cuda_extension/test/test_extension.py has no assertions)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(rows, dim, seed, realistic=True):
+    g = torch.Generator().manual_seed(seed)
+    if realistic:
+        mu = 0.9 * torch.randn(rows, dim, generator=g)
+        sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(rows, dim, generator=g)))
+    else:
+        sd = 0.5 * torch.exp(0.2 * torch.randn(rows, dim, generator=g))
+        mu = torch.randn(rows, dim, generator=g) * torch.sqrt(torch.clamp(1 - sd * sd, min=0.0))
+    return mu, sd
+
+
+def _run(mu, sd, cb, beta=1.0, logsd="cpu"):
+    from pit_hip import _lib
+
+    ws = _lib.Workspace()
+    dev = torch.device("cuda:0")
+    lsd_np = O.torch_log(sd.numpy()) if logsd == "cpu" else None
+    idx, zhat = _lib.gq_argmax(mu.to(dev), sd.to(dev), torch.from_numpy(cb).to(dev), beta,
+                               logsd=None if lsd_np is None else torch.from_numpy(lsd_np).to(dev), ws=ws)
+    torch.cuda.synchronize()
+    fb, _ = _lib.debug_counters(ws)
+    return idx.cpu().numpy(), zhat.cpu().numpy(), lsd_np, fb
+
+
+@pytest.mark.parametrize("dim,n,rows", [(16, 1024, 1000), (16, 65536, 1024), (8, 4096, 777), (4, 65536, 640),
+                                        (32, 2048, 300), (16, 1000, 129), (16, 31, 5), (4, 33, 1)])
+def test_indices_bit_exact(dim, n, rows):
+    cb = O.codebook(n, dim, 42)
+    mu, sd = _inputs(rows, dim, seed=dim * 1000 + rows)
+    idx, zhat, lsd, fb = _run(mu, sd, cb)
+    ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb, 1.0, logstd=lsd)
+    assert np.array_equal(idx, ref_idx)
+    assert np.array_equal(zhat, ref_zhat)
+    assert fb <= max(2, rows // 50), f"too many exhaustive fallbacks: {fb}"
+
+
+def test_batch16_shape_and_beta():
+    # BASELINE config 2 shape: 16 images x 1024 rows, dim 16, 2^16 codes (oracle on a 2048-row sample)
+    dim, n, rows = 16, 65536, 16384
+    cb = O.codebook(n, dim, 42)
+    mu, sd = _inputs(rows, dim, seed=0)
+    for beta in (1.0, 0.5):
+        idx, zhat, lsd, fb = _run(mu, sd, cb, beta=beta)
+        sel = np.arange(0, rows, 8)
+        ref_idx, _ = O.argmax_rows(mu.numpy()[sel], sd.numpy()[sel], cb, beta, logstd=lsd[sel])
+        assert np.array_equal(idx[sel], ref_idx)
+        assert np.array_equal(zhat, cb[idx])  # dequant round trip at full size
+        assert fb < 200
+
+
+def test_kernel_side_log_matches_fp64_log():
+    dim, n, rows = 16, 4096, 512
+    cb = O.codebook(n, dim, 42)
+    mu, sd = _inputs(rows, dim, seed=5)
+    idx, _, _, _ = _run(mu, sd, cb, logsd=None)
+    lsd = np.log(sd.numpy().astype(np.float64)).astype(np.float32)
+    ref_idx, _ = O.argmax_rows(mu.numpy(), sd.numpy(), cb, 1.0, logstd=lsd)
+    assert np.array_equal(idx, ref_idx)
+
+
+def test_edge_rows_nan_inf_extreme_sigma_and_ties():
+    dim, n = 16, 2048
+    cb = O.codebook(n, dim, 42).copy()
+    cb[100] = cb[7]          # exact duplicate: first index must win
+    cb[1500] = cb[7]
+    mu, sd = _inputs(64, dim, seed=9)
+    mu[0, 3] = float("nan")                  # NaN row -> every score NaN -> index 0
+    sd[1, :] = float(np.exp(0.5 * -30.0))    # logvar clamp floor
+    sd[2, :] = float(np.exp(0.5 * 20.0))     # logvar clamp ceiling
+    sd[3, 0] = 0.0                           # sigma == 0
+    sd[4, 2] = float("inf")
+    mu[5, :] = torch.from_numpy(cb[7])       # row sitting exactly on the duplicated code
+    sd[5, :] = 0.05
+    mu[6, :] = 1e4                           # far outside the codebook
+    sd[7, :] = -0.5                          # negative sigma: log -> NaN
+    idx, zhat, lsd, fb = _run(mu, sd, cb)
+    ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb, 1.0, logstd=lsd)
+    assert np.array_equal(idx, ref_idx)
+    assert idx[5] == 7
+    assert np.array_equal(zhat, ref_zhat)
+
+
+def test_generic_dims_use_exhaustive_path():
+    for dim, n, rows in [(1, 512, 40), (2, 300, 33), (3, 257, 17), (12, 1024, 50)]:
+        cb = O.codebook(n, dim, 42)
+        mu, sd = _inputs(rows, dim, seed=dim)
+        idx, zhat, lsd, _ = _run(mu, sd, cb)
+        ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb, 1.0, logstd=lsd)
+        assert np.array_equal(idx, ref_idx)
+        assert np.array_equal(zhat, ref_zhat)
+
+
+def test_compat_scores_op_matches_cuda_formula():
+    from pit_hip import _lib
+
+    dev = torch.device("cuda:0")
+    for dim, n, rows in [(16, 1024, 37), (8, 515, 16), (5, 100, 3)]:
+        cb = O.codebook(n, dim, 42)
+        mu, sd = _inputs(rows, dim, seed=77)
+        out = torch.zeros(rows, n, device=dev)
+        _lib.gq_scores(mu.to(dev), sd.to(dev), torch.from_numpy(cb).to(dev), out, 1.0)
+        got = out.cpu().numpy()
+        ref = O.cuda_formula_scores(mu.numpy(), sd.numpy(), cb, 1.0)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-4)  # fp32, fma-contraction freedom
+        # same arg-max as the torch-backend reference wherever the top-2 gap is not a rounding tie
+        ridx, _, best, second = O.argmax_rows(mu.numpy(), sd.numpy(), cb, 1.0, with_gap=True)
+        clear = (best - second) > 1e-3
+        assert np.array_equal(got.argmax(1)[clear], ridx[clear])

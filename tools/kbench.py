@@ -1,0 +1,54 @@
+"""Quantiser-only microbenchmark (SURVEY.md 8d synthetic recipe): times the fused
+HIP path at a given shape and prints achieved fp32 FLOP/s of the MFMA filter."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "vq-vae-from-gaussian-vae_amd"))
+from pit_hip import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=16384)
+    ap.add_argument("--dim", type=int, default=16)
+    ap.add_argument("--n", type=int, default=65536)
+    ap.add_argument("--iters", type=int, default=50)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    mu = (0.9 * torch.randn(a.rows, a.dim, generator=g)).to(dev)
+    sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(a.rows, a.dim, generator=g))).to(dev)
+    cb = torch.randn(a.n, a.dim, generator=g).clamp(-4.6, 4.6).to(dev)
+    absmax = _lib.codebook_absmax(cb)
+    ws = _lib.Workspace()
+    for _ in range(5):
+        _lib.gq_argmax(mu, sd, cb, 1.0, absmax=absmax, ws=ws)
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        _lib.gq_argmax(mu, sd, cb, 1.0, absmax=absmax, ws=ws)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / a.iters
+    launches, ms = _lib.profile_collect()
+    _lib.profile_enable(False)
+    flops = 4.0 * a.dim * a.n * a.rows
+    kms = ms / max(launches, 1)
+    _lib.debug_enable(True)
+    _lib.gq_argmax(mu, sd, cb, 1.0, absmax=absmax, ws=ws)
+    torch.cuda.synchronize()
+    fb, rr = _lib.debug_counters(ws)
+    _lib.debug_enable(False)
+    print(f"rows={a.rows} dim={a.dim} n={a.n}: filter kernel {kms*1e3:.1f} us avg over {launches} launches "
+          f"-> {flops/kms/1e9:.1f} TFLOP/s ({flops/kms/1e9/157.3*100:.1f}% of 157.3); "
+          f"whole call wall {wall*1e6:.1f} us; fallback rows {fb}, re-ranked half-tiles/row {rr/a.rows:.3f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+// gq_aux.h -- the small HBM-bound kernels around the filter: codebook abs-max,
+// workspace header init, operand prep from the encoder output, dequant gather,
+// the reference-compatible score-matrix op, LFQ bit pack/unpack, index
+// histogram and the u16 wire format.
+#pragma once
+#include "gq_common.h"
+#include "gq_rerank.h"
+
+namespace gqhip {
+
+__global__ void ws_init_kernel(WsHeader *hdr, float absmax) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    hdr->fb_count = 0;
+    hdr->reranked = 0ull;
+    hdr->absmax = absmax;
+  }
+}
+
+// max |cb| -> *out via integer atomicMax on the (non-negative) float bits; a
+// NaN/inf element maps to +inf so the fused paths fall back to exhaustive.
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ cb, long count,
+                                                      float *out) {
+  float m = 0.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+    const float v = fabsf(cb[i]);
+    m = (v != v) ? __builtin_inff() : __builtin_fmaxf(m, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int *>(out), __float_as_int(m));
+}
+
+// ---- operand prep: z [mu | logvar] -> mu, sd, lsd rows ---------------------
+// pit/quantization/gaussian.py:62-81,122-123 (GQ1) / :273-287 (GQ2), with
+// sd = float(exp(0.5*logvar)) and lsd = float(log(sd)) evaluated in fp64.
+struct PrepParams {
+  const float *z;
+  float *mu, *sd, *lsd;   // [rows, dim]
+  long rows;
+  int dim, K, L, c;       // c = channels of mu (z has 2c)
+  int layout, grouping;
+  float lv_min, lv_max;
+};
+
+__global__ __launch_bounds__(256) void prep_kernel(const PrepParams p) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.rows * p.dim) return;
+  // BCHW reads are coalesced along l when consecutive threads walk l; rows are
+  // (pos*K + k) so we index threads as (b, ch, l) for BCHW and (pos, ch) for BLC.
+  long row, b, l, pos;
+  int g, k, ch;
+  if (p.layout == 0) {
+    l = t % p.L;
+    ch = (int)((t / p.L) % p.c);
+    b = t / ((long)p.L * p.c);
+    pos = b * p.L + l;
+  } else {
+    ch = (int)(t % p.c);
+    pos = t / p.c;
+    b = pos / p.L;
+    l = pos % p.L;
+  }
+  if (p.grouping == 0) { g = ch / p.K; k = ch % p.K; } else { k = ch / p.dim; g = ch % p.dim; }
+  row = pos * p.K + k;
+  float m, lv;
+  if (p.layout == 0) {
+    m = p.z[(b * 2 * p.c + ch) * p.L + l];
+    lv = p.z[(b * 2 * p.c + p.c + ch) * p.L + l];
+  } else {
+    m = p.z[pos * 2 * p.c + ch];
+    lv = p.z[pos * 2 * p.c + p.c + ch];
+  }
+  // torch.clamp propagates NaN; min/max with explicit compares keeps that.
+  lv = lv < p.lv_min ? p.lv_min : lv;
+  lv = lv > p.lv_max ? p.lv_max : lv;
+  const float half = 0.5f * lv;
+  const float s = (float)exp((double)half);
+  const float ls = (float)log((double)s);
+  const long o = row * p.dim + g;
+  p.mu[o] = m;
+  p.sd[o] = s;
+  p.lsd[o] = ls;
+}
+
+// ---- dequant: zhat <- cb[idx] in the module layout -------------------------
+struct DequantParams {
+  const int64_t *idx;
+  const float *cb;
+  float *zhat;
+  long rows;
+  int dim, n;
+  OutMap omap;
+};
+
+__global__ __launch_bounds__(256) void dequant_kernel(const DequantParams p) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.rows * p.dim) return;
+  long row;
+  int g;
+  if (p.omap.mode == 1) {
+    // walk the output [B, c, L] linearly so stores coalesce
+    const long l = t % p.omap.L;
+    const int ch = (int)((t / p.omap.L) % p.omap.c);
+    const long b = t / ((long)p.omap.L * p.omap.c);
+    int k;
+    if (p.omap.grouping == 0) { g = ch / p.omap.K; k = ch % p.omap.K; } else { k = ch / p.dim; g = ch % p.dim; }
+    row = (b * p.omap.L + l) * p.omap.K + k;
+  } else {
+    row = t / p.dim;
+    g = (int)(t % p.dim);
+  }
+  long j = p.idx[out_idx_offset(p.omap, row)];
+  j = j < 0 ? 0 : (j >= p.n ? p.n - 1 : j);
+  p.zhat[out_zhat_offset(p.omap, row, g, p.dim)] = p.cb[j * p.dim + g];
+}
+
+// ---- compat op: the reference's score matrix --------------------------------
+// gq_cuda.cu:12-40.  One thread per code column, ROWS rows per block; the code
+// row lives in registers, mu / sd are wave-uniform (scalar loads), stores are
+// 1 KiB coalesced runs along n.  The running sum is a float; `iv*iv` is
+// contracted into the subtraction (nvcc's default -fmad), and the beta term is
+// accumulated through double exactly as the CUDA source spells it.
+template <int DIM, int ROWS>
+__global__ __launch_bounds__(256) void gq_scores_kernel(const float *__restrict__ mu,
+                                                        const float *__restrict__ sd,
+                                                        const float *__restrict__ cb,
+                                                        float *__restrict__ out, int rows, int n,
+                                                        double beta) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int jc = j < n ? j : n - 1;
+  float nv[DIM];
+  double nb[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    nv[i] = cb[(long)jc * DIM + i];
+    nb[i] = (double)(nv[i] * nv[i]) * beta;
+  }
+  const int r0 = blockIdx.y * ROWS;
+  for (int r = r0; r < r0 + ROWS && r < rows; ++r) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const float iv = __fdiv_rn(nv[i] - mu[(long)r * DIM + i], sd[(long)r * DIM + i]);
+      acc = __builtin_fmaf(-iv, iv, acc);
+      acc = (float)((double)acc + nb[i]);
+    }
+    if (j < n) out[(long)r * n + j] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gq_scores_generic_kernel(const float *__restrict__ mu,
+                                                                const float *__restrict__ sd,
+                                                                const float *__restrict__ cb,
+                                                                float *__restrict__ out, int dim,
+                                                                int rows, int n, double beta) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (j >= n || r >= rows) return;
+  float acc = 0.0f;
+  for (int i = 0; i < dim; ++i) {
+    const float co = cb[(long)j * dim + i];
+    const float iv = __fdiv_rn(co - mu[(long)r * dim + i], sd[(long)r * dim + i]);
+    acc = __builtin_fmaf(-iv, iv, acc);
+    acc = (float)((double)acc + (double)(co * co) * beta);
+  }
+  out[(long)r * n + j] = acc;
+}
+
+// ---- LFQ (lfq.py:147-158, 210-228) ------------------------------------------
+__global__ __launch_bounds__(256) void lfq_pack_kernel(const float *__restrict__ x,
+                                                       int64_t *__restrict__ idx,
+                                                       float *__restrict__ q, long rows, int nbits) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  int64_t v = 0;
+  for (int i = 0; i < nbits; ++i) {
+    const bool bit = x[r * nbits + i] > 0.0f;
+    v = v * 2 + (bit ? 1 : 0);
+    if (q) q[r * nbits + i] = bit ? 1.0f : -1.0f;
+  }
+  idx[r] = v;
+}
+
+__global__ __launch_bounds__(256) void lfq_unpack_kernel(const int64_t *__restrict__ idx,
+                                                         float *__restrict__ q, long rows, int nbits) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * nbits) return;
+  const long r = t / nbits;
+  const int i = (int)(t % nbits);
+  const int64_t v = idx[r];
+  q[t] = ((v >> (nbits - 1 - i)) & 1) ? 1.0f : -1.0f;
+}
+
+// ---- index histogram + u16 wire format (eval.py:127,137-141,152-154) --------
+__global__ __launch_bounds__(256) void hist_kernel(const int64_t *__restrict__ idx, long count, int n,
+                                                   int *__restrict__ hist) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+    const int64_t v = idx[i];
+    if (v >= 0 && v < n) atomicAdd(&hist[v], 1);
+  }
+}
+__global__ __launch_bounds__(256) void to_u16_kernel(const int64_t *__restrict__ idx,
+                                                     uint16_t *__restrict__ out, long count) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) out[i] = (uint16_t)idx[i];
+}
+__global__ __launch_bounds__(256) void from_u16_kernel(const uint16_t *__restrict__ in,
+                                                       int64_t *__restrict__ idx, long count) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) idx[i] = (int64_t)in[i];
+}
+
+}  // namespace gqhip

@@ -1,0 +1,140 @@
+// gq_common.h -- shared device helpers for libgqhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gqhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kTileCodes = 32;     // codes per MFMA 32x32 tile
+constexpr int kMaxSplit = 64;      // code splits (one lane per split in the re-rank)
+constexpr int kMaxDim = 64;
+
+// float32(log(sqrt(2*pi))): torch casts the python scalar to the tensor dtype.
+__device__ __host__ constexpr float half_log_2pi() { return 0.91893853320467274178f; }
+
+// One candidate record per (row, code split), produced by the filter kernel.
+//   m1 >= m2 >= m3 : the three largest half-tile maxima of the filter score
+//   id1, id2       : half-tile ids (tile*2 + half) of m1 and m2
+struct __attribute__((aligned(32))) Rec {
+  float m1, m2, m3;
+  int id1, id2;
+  int pad[3];
+};
+
+// Workspace header (first 256 bytes of the caller's workspace).
+struct WsHeader {
+  int fb_count;                       // rows routed to the exhaustive kernel
+  int pad0;
+  unsigned long long reranked;        // half-tiles evaluated exactly
+  float absmax;                       // max |cb| (device-computed when needed)
+  int pad1[59];
+};
+static_assert(sizeof(WsHeader) == 256, "header is 256 bytes");
+
+// Insert (t, id) into a descending top-3 (ids kept for the top 2 only).
+__device__ __forceinline__ void top3_insert(float t, int id, float &m1, float &m2,
+                                            float &m3, int &i1, int &i2) {
+  const bool g1 = t > m1;
+  const bool g2 = t > m2;
+  m3 = __builtin_amdgcn_fmed3f(m2, m3, t);
+  m2 = __builtin_amdgcn_fmed3f(m1, m2, t);
+  m1 = __builtin_fmaxf(m1, t);
+  // three plain selects (g1 implies g2) -> v_cndmask, no control flow
+  i2 = g2 ? id : i2;
+  i2 = g1 ? i1 : i2;
+  i1 = g1 ? id : i1;
+}
+__device__ __forceinline__ void top3_insert_value(float t, float m2, float &m3) {
+  m3 = __builtin_amdgcn_fmed3f(m2, m3, t);
+}
+
+// torch.argmax order on (score, index): NaN is the maximum and the first NaN
+// wins; otherwise the larger score, then the smaller index.
+__device__ __forceinline__ bool ref_better(float sa, int ia, float sb, int ib) {
+  const bool na = sa != sa, nb = sb != sb;
+  if (na || nb) return na && (!nb || ia < ib);
+  return sa > sb || (sa == sb && ia < ib);
+}
+
+// ---- the reference's fp32 arithmetic, op by op (no contraction) -----------
+// pit/quantization/gaussian.py:51-52  Normal(0,1).log_prob(n)
+__device__ __forceinline__ float ref_nlp(float n) {
+#pragma clang fp contract(off)
+  float d = n - 0.0f;
+  float q = d * d;
+  float t = (-q) / 2.0f;
+  t = t - 0.0f;
+  return t - half_log_2pi();
+}
+
+// pit/quantization/gaussian.py:142-146 one element of log_ratios
+__device__ __forceinline__ float ref_term(float n, float mu, float var2, float lsd,
+                                          float beta) {
+#pragma clang fp contract(off)
+  float d = n - mu;
+  float q = d * d;
+  float t = __fdiv_rn(-q, var2);
+  t = t - lsd;
+  t = t - half_log_2pi();
+  float u = ref_nlp(n) * beta;
+  return t - u;
+}
+
+// torch.sum(dim=2) order (8 strided accumulators, left-to-right combine) --
+// see oracle/gq_oracle.c:gq_row_score.  All operands are in global memory:
+// code row `n`, row operands mu / sd / lsd (lsd may be NULL -> fp64 log).
+__device__ __forceinline__ float ref_lsd(const float *lsd, const float *sd, int i) {
+  return lsd ? lsd[i] : (float)log((double)sd[i]);
+}
+
+__device__ inline float ref_score(const float *__restrict__ n, const float *__restrict__ mu,
+                                  const float *__restrict__ sd, const float *__restrict__ lsd,
+                                  int dim, float beta) {
+#pragma clang fp contract(off)
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < dim) {
+      float s = sd[k];
+      float var2 = 2.0f * (s * s);
+      acc[k] = ref_term(n[k], mu[k], var2, ref_lsd(lsd, sd, k), beta);
+    } else {
+      acc[k] = 0.0f;
+    }
+  }
+  for (int i0 = 8; i0 < dim; i0 += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k;
+      if (i < dim) {
+        float s = sd[i];
+        float var2 = 2.0f * (s * s);
+        acc[k] = acc[k] + ref_term(n[i], mu[i], var2, ref_lsd(lsd, sd, i), beta);
+      }
+    }
+  }
+  float s = acc[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+    if (k < dim) s = s + acc[k];
+  return s;
+}
+
+// VQ arbiter: -(|z|^2 + |e|^2 - 2 z.e) in fp64 (argmax of the negated distance).
+__device__ inline double vq_neg_dist(const float *__restrict__ e, const float *__restrict__ z, int dim) {
+  double zz = 0.0, ee = 0.0, ze = 0.0;
+  for (int i = 0; i < dim; ++i) {
+    const double a = z[i], b = e[i];
+    zz += a * a;
+    ee += b * b;
+    ze += a * b;
+  }
+  return -(zz + ee - 2.0 * ze);
+}
+
+}  // namespace gqhip

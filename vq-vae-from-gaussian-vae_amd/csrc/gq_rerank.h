@@ -1,0 +1,243 @@
+// gq_rerank.h -- exact re-rank of the filter's candidates, and the exhaustive
+// fallback.  Both evaluate the reference's score in the reference's operation
+// order (gq_common.h:ref_score), so the winning index is the one
+// torch.argmax returns on the reference's CPU path
+// (pit/quantization/gaussian.py:142-150).
+//
+// Why a small candidate set is enough (DESIGN.md "exactness argument"): for
+// every code j,  |filter(r,j) + const(r) - ref_score(r,j)| <= E(r), where E is
+// the rigorous rounding bound computed below from (mu, sd, max|cb|, dim).  The
+// reference's arg-max j* therefore satisfies filter(r,j*) >= max_j filter(r,j)
+// - 2E, i.e. it lies in a half-tile whose maximum is within `margin` = 2.5 E of
+// the row maximum.  The filter keeps, per (row, split), the best two such
+// half-tiles by id and the third by value; if the third is also within the
+// margin (or the row has non-finite operands / bound) the row goes to the
+// exhaustive kernel instead.  Either way no approximation reaches the output.
+#pragma once
+#include "gq_common.h"
+#include "gq_filter.h"
+
+namespace gqhip {
+
+// Where results go: plain rows, or straight into the module's output layout
+// (folds the inverse permutes of gaussian.py:153-158 / :318-327).
+struct OutMap {
+  int mode;      // 0: idx[row], zhat[row*dim + g];  1: BCHW;  2: BLC
+  int K, L, c;   // sub-codebooks per position, positions per image, channels
+  int grouping;  // 0 strided (GQ1), 1 contiguous (GQ2)
+};
+
+__device__ __forceinline__ long out_idx_offset(const OutMap &m, long row) {
+  if (m.mode == 1) {
+    const long pos = row / m.K, k = row % m.K;
+    const long b = pos / m.L, l = pos % m.L;
+    return (b * m.K + k) * m.L + l;
+  }
+  return row;  // plain rows and BLC ([B, L, K]) coincide
+}
+__device__ __forceinline__ long out_zhat_offset(const OutMap &m, long row, int g, int dim) {
+  if (m.mode == 0) return row * dim + g;
+  const long pos = row / m.K, k = row % m.K;
+  const long ch = m.grouping == 0 ? (long)g * m.K + k : k * dim + g;
+  if (m.mode == 1) {
+    const long b = pos / m.L, l = pos % m.L;
+    return (b * m.c + ch) * m.L + l;
+  }
+  return pos * m.c + ch;
+}
+
+struct RerankParams {
+  const float *mu;    // [rows, dim] (VQ: z)
+  const float *sd;    // [rows, dim]
+  const float *lsd;   // [rows, dim] or NULL
+  const float *cb;    // [n, dim]
+  const Rec *rec;     // [nsplit, rows]
+  int64_t *idx;
+  float *zhat;        // may be NULL
+  WsHeader *hdr;
+  int *fb_list;       // [rows]
+  int rows, n, dim;
+  float beta;
+  int nsplit;
+  int all_rows;       // exhaustive kernel: process every row (no filter ran)
+  int stats;          // count re-ranked half-tiles (debug)
+  OutMap omap;
+};
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ double exact_score(const RerankParams &p, long row, int code) {
+  const float *n = p.cb + (long)code * p.dim;
+  if constexpr (MODE == kModeGQ) {
+    const float *lsd = p.lsd ? p.lsd + row * p.dim : nullptr;
+    return (double)ref_score(n, p.mu + row * p.dim, p.sd + row * p.dim, lsd, p.dim, p.beta);
+  } else {
+    return vq_neg_dist(n, p.mu + row * p.dim, p.dim);
+  }
+}
+
+// comparator on (double score, index) with torch.argmax semantics
+__device__ __forceinline__ bool better_d(double sa, int ia, double sb, int ib) {
+  const bool na = sa != sa, nb = sb != sb;
+  if (na || nb) return na && (!nb || ia < ib);
+  return sa > sb || (sa == sb && ia < ib);
+}
+
+__device__ __forceinline__ void write_result(const RerankParams &p, long row, int best, int lane) {
+  if (lane == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best;
+  if (p.zhat && lane < p.dim)
+    p.zhat[out_zhat_offset(p.omap, row, lane, p.dim)] = p.cb[(long)best * p.dim + lane];
+}
+
+// One wave per row.
+template <int MODE>
+__global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
+  __shared__ int cand[4][2 * kMaxSplit];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= p.rows) return;
+
+  // ---- rounding bound E(r) -> margin --------------------------------------
+  const double u = 5.9604644775390625e-08;  // 2^-24
+  const double N1 = (double)p.hdr->absmax, N2 = N1 * N1;
+  double T = 0.0, G = 0.0;
+  bool bad = !(N1 == N1) || N1 > 1e18;
+  if (lane < p.dim) {
+    const double m = fabs((double)p.mu[row * p.dim + lane]);
+    if constexpr (MODE == kModeGQ) {
+      const double s = (double)p.sd[row * p.dim + lane];
+      const double l = p.lsd ? (double)p.lsd[row * p.dim + lane] : log(s);
+      const double inv = 1.0 / (s * s);
+      const double b = fabs((double)p.beta);
+      T = (0.5 * b + 0.5 * inv) * N2 + m * inv * N1;
+      G = (N1 + m) * (N1 + m) * 0.5 * inv + fabs(l) + (double)half_log_2pi() +
+          b * (0.5 * N2 + (double)half_log_2pi());
+      bad = bad || !(s > 0.0) || !(T < 1e30) || !(G < 1e30);
+    } else {
+      T = N2 + 2.0 * m * N1;
+      G = 0.0;
+      bad = bad || !(T < 1e30);
+    }
+  }
+  T = wave_sum(T);
+  G = wave_sum(G);
+  const double Ef = (2.0 * p.dim + 4.0) * u * T;
+  const double Er = MODE == kModeGQ ? (p.dim + 16.0) * u * G : 1e-12 * T;
+  const double margin = 2.5 * (Ef + Er) + 1e-30;
+  bad = __any(bad) || !(margin < 1e30);
+
+  // ---- gather the per-split records ----------------------------------------
+  const float NEG_INF = -__builtin_inff();
+  Rec r;
+  r.m1 = r.m2 = r.m3 = NEG_INF;
+  r.id1 = r.id2 = 0;
+  if (lane < p.nsplit) r = p.rec[(long)lane * p.rows + row];
+  float fmax = r.m1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, o));
+  bad = bad || !(fmax == fmax) || !(fmax > NEG_INF) || !(fmax < __builtin_inff());
+
+  const double thr = (double)fmax - margin;
+  const bool c1 = (double)r.m1 >= thr, c2 = (double)r.m2 >= thr, c3 = (double)r.m3 >= thr;
+  const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
+  if (bad || b3 != 0ull) {
+    if (lane == 0) {
+      const int pos = atomicAdd(&p.hdr->fb_count, 1);
+      p.fb_list[pos] = (int)row;
+    }
+    return;
+  }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int n1 = __popcll(b1);
+  const int total = n1 + __popcll(b2);
+  if (c1) cand[wave][__popcll(b1 & lt)] = r.id1;
+  if (c2) cand[wave][n1 + __popcll(b2 & lt)] = r.id2;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- exact scores of every code in the flagged half-tiles ---------------
+  double best_s = 0.0;
+  int best_i = 0x7fffffff;
+  bool have = false;
+  for (int g = 0; g * 4 < total; ++g) {
+    const int e = g * 4 + (lane >> 4);
+    if (e < total) {
+      const int id = cand[wave][e];
+      const int rr = lane & 15;
+      const int code = (id >> 1) * kTileCodes + (rr & 3) + 8 * (rr >> 2) + 4 * (id & 1);
+      if (code < p.n) {
+        const double s = exact_score<MODE>(p, row, code);
+        if (!have || better_d(s, code, best_s, best_i)) {
+          best_s = s;
+          best_i = code;
+          have = true;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double os = __shfl_xor(best_s, o);
+    const int oi = __shfl_xor(best_i, o);
+    const bool oh = __shfl_xor((int)have, o) != 0;
+    if (oh && (!have || better_d(os, oi, best_s, best_i))) {
+      best_s = os;
+      best_i = oi;
+      have = true;
+    }
+  }
+  if (p.stats && lane == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)total);
+  write_result(p, row, best_i, lane);
+}
+
+// Exhaustive exact arg-max: one block per listed row (grid-stride over the
+// list).  Used for rows the filter could not decide and for shapes the MFMA
+// filter does not cover (dim not in {4,8,16,32}).
+template <int MODE>
+__global__ __launch_bounds__(256) void gq_exhaustive_kernel(const RerankParams p) {
+  __shared__ double sh_s[256];
+  __shared__ int sh_i[256];
+  const int tid = threadIdx.x;
+  const int count = p.all_rows ? p.rows : p.hdr->fb_count;
+  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    const long row = p.all_rows ? e : p.fb_list[e];
+    double best_s = 0.0;
+    int best_i = 0x7fffffff;
+    bool have = false;
+    for (int j = tid; j < p.n; j += 256) {
+      const double s = exact_score<MODE>(p, row, j);
+      if (!have || better_d(s, j, best_s, best_i)) {
+        best_s = s;
+        best_i = j;
+        have = true;
+      }
+    }
+    sh_s[tid] = best_s;
+    sh_i[tid] = have ? best_i : 0x7fffffff;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) {
+        const double os = sh_s[tid + o];
+        const int oi = sh_i[tid + o];
+        const bool mine = sh_i[tid] != 0x7fffffff;
+        if (oi != 0x7fffffff && (!mine || better_d(os, oi, sh_s[tid], sh_i[tid]))) {
+          sh_s[tid] = os;
+          sh_i[tid] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    const int best = sh_i[0];
+    __syncthreads();
+    write_result(p, row, best, tid);
+  }
+}
+
+}  // namespace gqhip

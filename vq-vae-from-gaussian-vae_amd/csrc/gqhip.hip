@@ -1,0 +1,401 @@
+// gqhip.hip -- C-ABI entry points of libgqhip.so (see include/gqhip.h).
+// gfx950 only; built by `make -C vq-vae-from-gaussian-vae_amd/csrc`.
+#include "gqhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "gq_aux.h"
+#include "gq_common.h"
+#include "gq_filter.h"
+#include "gq_rerank.h"
+
+using namespace gqhip;
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+inline int check_launch() {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return GQHIP_ERR_LAUNCH;
+  }
+  return GQHIP_OK;
+}
+
+// ---- launch plan: identical on the sizing and the launching side -----------
+struct Plan {
+  bool mfma;            // filter kernel applies (dim in {4,8,16,32}, n >= 32)
+  int rt;               // row tiles per wave
+  int rows_per_block;   // 128 * rt
+  int row_blocks;
+  int nsplit;           // code splits
+  int tiles_total;
+  int tiles_per_split;
+};
+
+Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
+  Plan pl{};
+  pl.mfma = (dim == 4 || dim == 8 || dim == 16 || dim == 32) && n >= 1 && rows >= 1;
+  pl.tiles_total = (int)((n + kTileCodes - 1) / kTileCodes);
+  pl.rt = rows >= 8192 ? 2 : 1;
+  pl.rows_per_block = 128 * pl.rt;
+  pl.row_blocks = (int)((rows + pl.rows_per_block - 1) / pl.rows_per_block);
+  // ~2 blocks per CU on 256 CUs; splits in multiples of 8 so that
+  // blockIdx % 8 (XCD) == split % 8.
+  int s = (512 + pl.row_blocks - 1) / (pl.row_blocks > 0 ? pl.row_blocks : 1);
+  s = ((s + 7) / 8) * 8;
+  if (s > kMaxSplit) s = kMaxSplit;
+  if (s > pl.tiles_total) s = pl.tiles_total;
+  if (s < 1) s = 1;
+  pl.tiles_per_split = (pl.tiles_total + s - 1) / s;
+  pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
+  return pl;
+}
+
+inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+struct WsLayout {
+  int64_t hdr, rec, fb, mu, sd, lsd, total;
+};
+
+WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
+  const Plan pl = make_plan(rows, n, dim);
+  WsLayout w{};
+  int64_t off = 0;
+  w.hdr = off; off += 256;
+  w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit : 0));
+  w.fb = off;  off += align256(4 * rows);
+  w.mu = off;  off += align256(4 * rows * dim);
+  w.sd = off;  off += align256(4 * rows * dim);
+  w.lsd = off; off += align256(4 * rows * dim);
+  w.total = off;
+  return w;
+}
+
+// ---- profiling recorder ------------------------------------------------------
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+int g_debug_stats = 0;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+
+struct ProfScope {
+  hipStream_t st;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  explicit ProfScope(hipStream_t s) : st(s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    on = g_prof_on;
+    if (on) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, st);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(b, st);
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      g_prof_events.emplace_back(a, b);
+    }
+  }
+};
+
+template <int MODE>
+int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t st) {
+  const dim3 grid((unsigned)(pl.row_blocks * pl.nsplit)), block(256);
+  ProfScope prof(st);
+#define GQ_LAUNCH(D, R, C) \
+  hipLaunchKernelGGL((gq_filter_kernel<D, R, C, MODE>), grid, block, 0, st, fp)
+  if (pl.rt == 2) {
+    switch (dim) {
+      case 4: GQ_LAUNCH(4, 2, 8); break;
+      case 8: GQ_LAUNCH(8, 2, 8); break;
+      case 16: GQ_LAUNCH(16, 2, 8); break;
+      case 32: GQ_LAUNCH(32, 2, 4); break;
+      default: return GQHIP_ERR_INVALID_ARG;
+    }
+  } else {
+    switch (dim) {
+      case 4: GQ_LAUNCH(4, 1, 8); break;
+      case 8: GQ_LAUNCH(8, 1, 8); break;
+      case 16: GQ_LAUNCH(16, 1, 8); break;
+      case 32: GQ_LAUNCH(32, 1, 4); break;
+      default: return GQHIP_ERR_INVALID_ARG;
+    }
+  }
+#undef GQ_LAUNCH
+  return check_launch();
+}
+
+// filter -> re-rank -> exhaustive, shared by GQ and VQ.
+template <int MODE>
+int run_argmax(const float *mu, const float *sd, const float *lsd, const float *cb, int64_t *idx,
+               float *zhat, int64_t dim, int64_t rows, int64_t n, double beta, float cb_absmax,
+               void *workspace, int64_t workspace_bytes, const OutMap &omap, hipStream_t st) {
+  if (!mu || !cb || !idx || (MODE == kModeGQ && !sd)) return GQHIP_ERR_INVALID_ARG;
+  if (dim < 1 || dim > kMaxDim || rows < 0 || n < 1 || n > 0x3fffffff || rows > 0x3fffffff)
+    return GQHIP_ERR_INVALID_ARG;
+  if (rows == 0) return GQHIP_OK;
+  const WsLayout w = ws_layout(rows, n, dim);
+  if (!workspace || workspace_bytes < w.total) return GQHIP_ERR_WORKSPACE;
+  char *ws = static_cast<char *>(workspace);
+  WsHeader *hdr = reinterpret_cast<WsHeader *>(ws + w.hdr);
+  const Plan pl = make_plan(rows, n, dim);
+
+  hipLaunchKernelGGL(ws_init_kernel, dim3(1), dim3(64), 0, st, hdr, cb_absmax > 0.f ? cb_absmax : 0.f);
+  if (!(cb_absmax > 0.f)) {
+    const long count = (long)n * dim;
+    const int blocks = (int)((count + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(256), 0,
+                       st, cb, count, &hdr->absmax);
+  }
+
+  RerankParams rp{};
+  rp.mu = mu; rp.sd = sd; rp.lsd = lsd; rp.cb = cb;
+  rp.rec = reinterpret_cast<const Rec *>(ws + w.rec);
+  rp.idx = idx; rp.zhat = zhat; rp.hdr = hdr;
+  rp.fb_list = reinterpret_cast<int *>(ws + w.fb);
+  rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
+  rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
+  rp.omap = omap;
+
+  if (pl.mfma) {
+    FilterParams fp{};
+    fp.mu = mu; fp.sd = sd; fp.cb = cb;
+    fp.rec = reinterpret_cast<Rec *>(ws + w.rec);
+    fp.rows = (int)rows; fp.n = (int)n; fp.beta = (float)beta;
+    fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
+    int rc = launch_filter<MODE>(pl, fp, (int)dim, st);
+    if (rc != GQHIP_OK) return rc;
+    hipLaunchKernelGGL((gq_rerank_kernel<MODE>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rp);
+    rc = check_launch();
+    if (rc != GQHIP_OK) return rc;
+  }
+  const int ex_blocks = (int)(rows < 2048 ? rows : 2048);
+  hipLaunchKernelGGL((gq_exhaustive_kernel<MODE>), dim3((unsigned)ex_blocks), dim3(256), 0, st, rp);
+  return check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int gqhip_abi_version(void) { return GQHIP_ABI_VERSION; }
+
+const char *gqhip_status_string(int s) {
+  switch (s) {
+    case GQHIP_OK: return "ok";
+    case GQHIP_ERR_INVALID_ARG: return "invalid argument";
+    case GQHIP_ERR_WORKSPACE: return "workspace missing or too small";
+    case GQHIP_ERR_LAUNCH: return "kernel launch failed";
+    case GQHIP_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown status";
+  }
+}
+
+int gqhip_last_hip_error(void) { return g_last_hip_error; }
+
+int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim) {
+  if (rows < 0 || n < 1 || dim < 1 || dim > kMaxDim) return -1;
+  return ws_layout(rows < 1 ? 1 : rows, n, dim).total;
+}
+
+int gqhip_codebook_absmax(const float *cb, int64_t n, int64_t dim, float *absmax_out, void *stream) {
+  if (!cb || !absmax_out || n < 1 || dim < 1) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(absmax_out, 0, sizeof(float), st) != hipSuccess) return check_launch();
+  const long count = (long)n * dim;
+  int blocks = (int)((count + 256 * 16 - 1) / (256 * 16));
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, cb, count, absmax_out);
+  return check_launch();
+}
+
+int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out, int64_t dim,
+                  int64_t rows, int64_t n, double beta, void *stream) {
+  if (!mu || !sd || !cb || !out || dim < 1 || rows < 0 || n < 1 || n > 0x7fffffff || rows > 0x7fffffff)
+    return GQHIP_ERR_INVALID_ARG;
+  if (rows == 0) return GQHIP_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned gx = (unsigned)((n + 255) / 256);
+  constexpr int ROWS = 16;
+  const unsigned gy = (unsigned)((rows + ROWS - 1) / ROWS);
+  if (gy > 65535u * 32u) return GQHIP_ERR_INVALID_ARG;
+#define GQ_SC(D)                                                                                   \
+  hipLaunchKernelGGL((gq_scores_kernel<D, ROWS>), dim3(gx, gy), dim3(256), 0, st, mu, sd, cb, out, \
+                     (int)rows, (int)n, beta)
+  switch (dim) {
+    case 4: GQ_SC(4); break;
+    case 8: GQ_SC(8); break;
+    case 16: GQ_SC(16); break;
+    case 32: GQ_SC(32); break;
+    default:
+      hipLaunchKernelGGL(gq_scores_generic_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, mu, sd, cb,
+                         out, (int)dim, (int)rows, (int)n, beta);
+  }
+#undef GQ_SC
+  return check_launch();
+}
+
+int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null, const float *cb,
+                  int64_t *idx, float *zhat_or_null, int64_t dim, int64_t rows, int64_t n, double beta,
+                  float cb_absmax, void *workspace, int64_t workspace_bytes, void *stream) {
+  OutMap om{};
+  om.mode = 0;
+  return run_argmax<kModeGQ>(mu, sd, logsd_or_null, cb, idx, zhat_or_null, dim, rows, n, beta, cb_absmax,
+                             workspace, workspace_bytes, om, static_cast<hipStream_t>(stream));
+}
+
+int gq_quantize_z_f32(const float *z, const float *cb, int64_t *idx, float *zhat_or_null,
+                      float *mu_out_or_null, float *sd_out_or_null, int64_t B, int64_t L, int64_t c,
+                      int64_t dim, int64_t n, int layout, int grouping, double lv_min, double lv_max,
+                      double beta, float cb_absmax, void *workspace, int64_t workspace_bytes,
+                      void *stream) {
+  if (!z || !cb || !idx || B < 0 || L < 1 || c < 1 || dim < 1 || dim > kMaxDim || c % dim != 0)
+    return GQHIP_ERR_INVALID_ARG;
+  if ((layout != GQHIP_LAYOUT_BCHW && layout != GQHIP_LAYOUT_BLC) ||
+      (grouping != GQHIP_GROUP_STRIDED && grouping != GQHIP_GROUP_CONTIGUOUS))
+    return GQHIP_ERR_INVALID_ARG;
+  const int64_t K = c / dim, rows = B * L * K;
+  if (rows == 0) return GQHIP_OK;
+  if (rows > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
+  const WsLayout w = ws_layout(rows, n, dim);
+  if (!workspace || workspace_bytes < w.total) return GQHIP_ERR_WORKSPACE;
+  char *ws = static_cast<char *>(workspace);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PrepParams pp{};
+  pp.z = z;
+  pp.mu = mu_out_or_null ? mu_out_or_null : reinterpret_cast<float *>(ws + w.mu);
+  pp.sd = sd_out_or_null ? sd_out_or_null : reinterpret_cast<float *>(ws + w.sd);
+  pp.lsd = reinterpret_cast<float *>(ws + w.lsd);
+  pp.rows = rows; pp.dim = (int)dim; pp.K = (int)K; pp.L = (int)L; pp.c = (int)c;
+  pp.layout = layout; pp.grouping = grouping;
+  pp.lv_min = (float)lv_min; pp.lv_max = (float)lv_max;
+  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, st, pp);
+  int rc = check_launch();
+  if (rc != GQHIP_OK) return rc;
+  OutMap om{};
+  om.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
+  om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = grouping;
+  return run_argmax<kModeGQ>(pp.mu, pp.sd, pp.lsd, cb, idx, zhat_or_null, dim, rows, n, beta, cb_absmax,
+                             workspace, workspace_bytes, om, st);
+}
+
+int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B, int64_t L, int64_t K,
+                   int64_t dim, int64_t n, int layout, int grouping, void *stream) {
+  if (!idx || !cb || !zhat || B < 0 || L < 1 || K < 1 || dim < 1 || n < 1) return GQHIP_ERR_INVALID_ARG;
+  const int64_t rows = B * L * K;
+  if (rows == 0) return GQHIP_OK;
+  DequantParams dp{};
+  dp.idx = idx; dp.cb = cb; dp.zhat = zhat; dp.rows = rows; dp.dim = (int)dim; dp.n = (int)n;
+  dp.omap.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
+  dp.omap.K = (int)K; dp.omap.L = (int)L; dp.omap.c = (int)(K * dim); dp.omap.grouping = grouping;
+  hipLaunchKernelGGL(dequant_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dp);
+  return check_launch();
+}
+
+int vq_argmin_f32(const float *z, const float *emb, int64_t *idx, float *zq_or_null, int64_t dim,
+                  int64_t rows, int64_t n, float emb_absmax, void *workspace, int64_t workspace_bytes,
+                  void *stream) {
+  OutMap om{};
+  om.mode = 0;
+  return run_argmax<kModeVQ>(z, nullptr, nullptr, emb, idx, zq_or_null, dim, rows, n, 0.0, emb_absmax,
+                             workspace, workspace_bytes, om, static_cast<hipStream_t>(stream));
+}
+
+int lfq_pack_f32(const float *x, int64_t *idx, float *q_or_null, int64_t rows, int64_t nbits,
+                 void *stream) {
+  if (!x || !idx || rows < 0 || nbits < 1 || nbits > 62) return GQHIP_ERR_INVALID_ARG;
+  if (rows == 0) return GQHIP_OK;
+  hipLaunchKernelGGL(lfq_pack_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, idx, q_or_null, (long)rows, (int)nbits);
+  return check_launch();
+}
+
+int lfq_unpack_f32(const int64_t *idx, float *q, int64_t rows, int64_t nbits, void *stream) {
+  if (!idx || !q || rows < 0 || nbits < 1 || nbits > 62) return GQHIP_ERR_INVALID_ARG;
+  if (rows == 0) return GQHIP_OK;
+  hipLaunchKernelGGL(lfq_unpack_kernel, dim3((unsigned)((rows * nbits + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), idx, q, (long)rows, (int)nbits);
+  return check_launch();
+}
+
+int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n, int32_t *hist, void *stream) {
+  if (!idx || !hist || count < 0 || n < 1) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(hist, 0, sizeof(int32_t) * n, st) != hipSuccess) return check_launch();
+  if (count == 0) return GQHIP_OK;
+  int blocks = (int)((count + 255) / 256);
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(256), 0, st, idx, (long)count, (int)n, hist);
+  return check_launch();
+}
+
+int gq_indices_to_u16(const int64_t *idx, uint16_t *out, int64_t count, void *stream) {
+  if (!idx || !out || count < 0) return GQHIP_ERR_INVALID_ARG;
+  if (count == 0) return GQHIP_OK;
+  hipLaunchKernelGGL(to_u16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), idx, out, (long)count);
+  return check_launch();
+}
+
+int gq_indices_from_u16(const uint16_t *in, int64_t *idx, int64_t count, void *stream) {
+  if (!in || !idx || count < 0) return GQHIP_ERR_INVALID_ARG;
+  if (count == 0) return GQHIP_OK;
+  hipLaunchKernelGGL(from_u16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, idx, (long)count);
+  return check_launch();
+}
+
+int gqhip_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return GQHIP_OK;
+}
+
+int gqhip_debug_enable(int on) {
+  g_debug_stats = on != 0;
+  return GQHIP_OK;
+}
+
+int gqhip_profile_collect(int *launches_host, double *total_ms_host) {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ev.swap(g_prof_events);
+  }
+  double total = 0.0;
+  int cnt = 0;
+  for (auto &pr : ev) {
+    float ms = 0.f;
+    if (hipEventSynchronize(pr.second) == hipSuccess &&
+        hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      total += ms;
+      ++cnt;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  if (launches_host) *launches_host = cnt;
+  if (total_ms_host) *total_ms_host = total;
+  return GQHIP_OK;
+}
+
+int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
+                         int64_t *reranked_halftiles_host) {
+  if (!workspace) return GQHIP_ERR_INVALID_ARG;
+  WsHeader h;
+  if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
+  if (fallback_rows_host) *fallback_rows_host = h.fb_count;
+  if (reranked_halftiles_host) *reranked_halftiles_host = (int64_t)h.reranked;
+  return GQHIP_OK;
+}
+
+}  // extern "C"

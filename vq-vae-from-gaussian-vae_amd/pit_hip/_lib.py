@@ -1,0 +1,299 @@
+"""ctypes binding of libgqhip.so (the C ABI declared in include/gqhip.h).
+
+torch is used only for device memory and the current HIP stream: every call
+hands raw ``data_ptr()`` values and ``torch.cuda.current_stream().cuda_stream``
+to the library.  There is NO CPU fallback here: if the library is missing or a
+tensor is not on a HIP device the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import torch
+
+_CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
+LIB_PATH = os.path.join(_CSRC, "libgqhip.so")
+
+GQHIP_LAYOUT = {"bchw": 0, "blc": 1}
+GQHIP_GROUP_STRIDED = 0
+GQHIP_GROUP_CONTIGUOUS = 1
+
+_lib: Optional[ctypes.CDLL] = None
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "gqhip_abi_version": (ctypes.c_int, []),
+    "gqhip_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "gqhip_last_hip_error": (ctypes.c_int, []),
+    "gqhip_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gqhip_codebook_absmax": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "gq_scores_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double, _vp]),
+    "gq_argmax_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double,
+                                     ctypes.c_float, _vp, _i64, _vp]),
+    "gq_quantize_z_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_float, _vp, _i64, _vp]),
+    "gq_dequant_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
+                                      ctypes.c_int, _vp]),
+    "vq_argmin_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _i64, _vp]),
+    "lfq_pack_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "lfq_unpack_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "gq_indices_from_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "gqhip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "gqhip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
+    "gqhip_debug_enable": (ctypes.c_int, [ctypes.c_int]),
+    "gqhip_debug_counters": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class GqHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libgqhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args + ["libgqhip.so"])
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load the library, failing loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GqHipError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C vq-vae-from-gaussian-vae_amd/csrc`). There is no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.gqhip_abi_version() != 1:
+            raise GqHipError("libgqhip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        L = lib()
+        raise GqHipError(f"{what}: {L.gqhip_status_string(rc).decode()} (hipError {L.gqhip_last_hip_error()})")
+
+
+def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GqHipError(f"{name} must be a tensor on a HIP device (got {getattr(t, 'device', type(t))}); "
+                         "the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise GqHipError(f"{name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Workspace:
+    """Caller-owned scratch, grown on demand and reused across calls."""
+
+    def __init__(self) -> None:
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, rows: int, n: int, dim: int, device) -> Tuple[int, int]:
+        need = lib().gqhip_workspace_bytes(rows, n, dim)
+        if need < 0:
+            raise GqHipError(f"unsupported shape rows={rows} n={n} dim={dim}")
+        if self.buf is None or self.buf.numel() < need or self.buf.device != device:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=device)
+        return self.buf.data_ptr(), self.buf.numel()
+
+
+def codebook_absmax(cb: torch.Tensor) -> float:
+    cb = _dev(cb, torch.float32, "codebook")
+    out = torch.zeros(1, dtype=torch.float32, device=cb.device)
+    with torch.cuda.device(cb.device):
+        _check(lib().gqhip_codebook_absmax(cb.data_ptr(), cb.shape[0], cb.shape[1], out.data_ptr(), _stream()),
+               "gqhip_codebook_absmax")
+    return float(out.item())
+
+
+def gq_scores(mu, sd, cb, out, beta: float = 1.0) -> None:
+    """Compat op (reference gq_cuda.ops.gq_cuda): fills out[rows, n] in place."""
+    mu, sd, cb = (_dev(t, torch.float32, n) for t, n in ((mu, "mu"), (sd, "std"), (cb, "codebook")))
+    if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()):
+        raise GqHipError("out must be a contiguous float32 HIP tensor")
+    rows, dim = mu.shape
+    n = cb.shape[0]
+    if sd.shape != mu.shape or cb.shape[1] != dim or tuple(out.shape) != (rows, n):
+        raise GqHipError("shape mismatch in gq_scores")
+    with torch.cuda.device(mu.device):
+        _check(lib().gq_scores_f32(mu.data_ptr(), sd.data_ptr(), cb.data_ptr(), out.data_ptr(), dim, rows, n,
+                                   float(beta), _stream()), "gq_scores_f32")
+
+
+def gq_argmax(mu, sd, cb, beta: float = 1.0, logsd=None, absmax: float = 0.0, ws: Optional[Workspace] = None,
+              want_zhat: bool = True):
+    """Fused score+argmax+gather on (mu, sd[, log sd]) rows -> (idx int64 [rows], zhat [rows, dim])."""
+    mu, sd, cb = (_dev(t, torch.float32, n) for t, n in ((mu, "mu"), (sd, "std"), (cb, "codebook")))
+    logsd = None if logsd is None else _dev(logsd, torch.float32, "logsd")
+    rows, dim = mu.shape
+    n = cb.shape[0]
+    if sd.shape != mu.shape or cb.shape[1] != dim:
+        raise GqHipError("shape mismatch in gq_argmax")
+    ws = ws or Workspace()
+    idx = torch.empty(rows, dtype=torch.int64, device=mu.device)
+    zhat = torch.empty(rows, dim, dtype=torch.float32, device=mu.device) if want_zhat else None
+    with torch.cuda.device(mu.device):
+        wptr, wbytes = ws.get(rows, n, dim, mu.device)
+        _check(lib().gq_argmax_f32(mu.data_ptr(), sd.data_ptr(), _ptr(logsd), cb.data_ptr(), idx.data_ptr(),
+                                   _ptr(zhat), dim, rows, n, float(beta), float(absmax), wptr, wbytes, _stream()),
+               "gq_argmax_f32")
+    return idx, zhat
+
+
+def gq_quantize_z(z, cb, dim: int, layout: str, grouping: int, lv_range=(-30.0, 20.0), beta: float = 1.0,
+                  absmax: float = 0.0, ws: Optional[Workspace] = None, return_operands: bool = False):
+    """Module-level fused quantiser on the encoder output z (see gqhip.h)."""
+    z, cb = _dev(z, torch.float32, "z"), _dev(cb, torch.float32, "codebook")
+    n = cb.shape[0]
+    if layout == "bchw":
+        B, c2, L = z.shape[0], z.shape[1], int(z[0, 0].numel())
+    else:
+        B, L, c2 = z.shape
+    c = c2 // 2
+    K = c // dim
+    rows = B * L * K
+    ws = ws or Workspace()
+    dev = z.device
+    if layout == "bchw":
+        idx = torch.empty((B, K) + tuple(z.shape[2:]), dtype=torch.int64, device=dev)
+        zhat = torch.empty((B, c) + tuple(z.shape[2:]), dtype=torch.float32, device=dev)
+    else:
+        idx = torch.empty((B, L, K), dtype=torch.int64, device=dev)
+        zhat = torch.empty((B, L, c), dtype=torch.float32, device=dev)
+    mu_o = sd_o = None
+    if return_operands:
+        mu_o = torch.empty(rows, dim, dtype=torch.float32, device=dev)
+        sd_o = torch.empty(rows, dim, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        wptr, wbytes = ws.get(max(rows, 1), n, dim, dev)
+        _check(lib().gq_quantize_z_f32(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), zhat.data_ptr(), _ptr(mu_o),
+                                       _ptr(sd_o), B, L, c, dim, n, GQHIP_LAYOUT[layout], grouping,
+                                       float(lv_range[0]), float(lv_range[1]), float(beta), float(absmax),
+                                       wptr, wbytes, _stream()), "gq_quantize_z_f32")
+    if return_operands:
+        return idx, zhat, mu_o, sd_o
+    return idx, zhat
+
+
+def gq_dequant(idx, cb, dim: int, layout: str, grouping: int):
+    idx, cb = _dev(idx, torch.int64, "indices"), _dev(cb, torch.float32, "codebook")
+    if layout == "bchw":
+        B, K, L = idx.shape[0], idx.shape[1], int(idx[0, 0].numel())
+        zhat = torch.empty((B, K * dim) + tuple(idx.shape[2:]), dtype=torch.float32, device=idx.device)
+    else:
+        B, L, K = idx.shape
+        zhat = torch.empty((B, L, K * dim), dtype=torch.float32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _check(lib().gq_dequant_f32(idx.data_ptr(), cb.data_ptr(), zhat.data_ptr(), B, L, K, dim, cb.shape[0],
+                                    GQHIP_LAYOUT[layout], grouping, _stream()), "gq_dequant_f32")
+    return zhat
+
+
+def vq_argmin(z, emb, absmax: float = 0.0, ws: Optional[Workspace] = None):
+    z, emb = _dev(z, torch.float32, "z"), _dev(emb, torch.float32, "embedding")
+    rows, dim = z.shape
+    n = emb.shape[0]
+    ws = ws or Workspace()
+    idx = torch.empty(rows, dtype=torch.int64, device=z.device)
+    zq = torch.empty(rows, dim, dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        wptr, wbytes = ws.get(max(rows, 1), n, dim, z.device)
+        _check(lib().vq_argmin_f32(z.data_ptr(), emb.data_ptr(), idx.data_ptr(), zq.data_ptr(), dim, rows, n,
+                                   float(absmax), wptr, wbytes, _stream()), "vq_argmin_f32")
+    return idx, zq
+
+
+def lfq_pack(x):
+    x = _dev(x, torch.float32, "x")
+    rows, nbits = x.shape
+    idx = torch.empty(rows, dtype=torch.int64, device=x.device)
+    q = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().lfq_pack_f32(x.data_ptr(), idx.data_ptr(), q.data_ptr(), rows, nbits, _stream()), "lfq_pack_f32")
+    return idx, q
+
+
+def lfq_unpack(idx, nbits: int):
+    idx = _dev(idx, torch.int64, "indices")
+    rows = idx.numel()
+    q = torch.empty(rows, nbits, dtype=torch.float32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _check(lib().lfq_unpack_f32(idx.data_ptr(), q.data_ptr(), rows, nbits, _stream()), "lfq_unpack_f32")
+    return q
+
+
+def index_histogram(idx, n: int):
+    idx = _dev(idx, torch.int64, "indices")
+    hist = torch.empty(n, dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _check(lib().gq_index_histogram(idx.data_ptr(), idx.numel(), n, hist.data_ptr(), _stream()),
+               "gq_index_histogram")
+    return hist
+
+
+def indices_to_u16(idx):
+    idx = _dev(idx, torch.int64, "indices")
+    out = torch.empty(idx.shape, dtype=torch.uint16, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _check(lib().gq_indices_to_u16(idx.data_ptr(), out.data_ptr(), idx.numel(), _stream()), "gq_indices_to_u16")
+    return out
+
+
+def indices_from_u16(u16):
+    if not (u16.is_cuda and u16.dtype == torch.uint16):
+        raise GqHipError("expected a uint16 HIP tensor")
+    u16 = u16.contiguous()
+    out = torch.empty(u16.shape, dtype=torch.int64, device=u16.device)
+    with torch.cuda.device(u16.device):
+        _check(lib().gq_indices_from_u16(u16.data_ptr(), out.data_ptr(), u16.numel(), _stream()),
+               "gq_indices_from_u16")
+    return out
+
+
+def profile_enable(on: bool) -> None:
+    lib().gqhip_profile_enable(1 if on else 0)
+
+
+def profile_collect() -> Tuple[int, float]:
+    n = ctypes.c_int(0)
+    ms = ctypes.c_double(0.0)
+    lib().gqhip_profile_collect(ctypes.byref(n), ctypes.byref(ms))
+    return n.value, ms.value
+
+
+def debug_enable(on: bool) -> None:
+    lib().gqhip_debug_enable(1 if on else 0)
+
+
+def debug_counters(ws: Workspace) -> Tuple[int, int]:
+    fb, rr = _i64(0), _i64(0)
+    _check(lib().gqhip_debug_counters(ws.buf.data_ptr(), ctypes.byref(fb), ctypes.byref(rr)), "gqhip_debug_counters")
+    return fb.value, rr.value
