@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of encode -> quantize -> decode (256x256, codebook 2^16).
+
+A "step" is one pass of the hot path over one batch of synthetic images already
+resident in HBM: SD3-UNet encoder (PyTorch-ROCm) -> GaussianQuantRegularizer
+(fused HIP kernels through libgqhip.so) -> decoder, followed -- exactly like the
+reference's eval.py loop -- by the per-batch PSNR and ONE packed all-gather of
+(indices, PSNR) across ranks.  Workload = BASELINE.json configs[1]:
+sd3unet_gq_0.25 (codebook 2^16, dim 16, 1 group), bs = 16 per GPU, fp32.
+
+Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N > 1
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+ --master-port P bench.py --gpus N ...` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "vq-vae-from-gaussian-vae_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+UNET = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=256, in_channels=3, out_ch=3, ch=128,
+            ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[32], dropout=0.0)
+N_CODES, DIM = 65536, 16
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
+
+
+def build_model(device):
+    from pit_hip.models.autoencoder import AutoencodingEngine
+
+    torch.manual_seed(1234)  # no checkpoint offline: seeded random init of the real architecture
+    vae = AutoencodingEngine(
+        encoder_config={"target": "pit.modules.unet.Encoder", "params": UNET},
+        decoder_config={"target": "pit.modules.unet.Decoder", "params": UNET},
+        regularizer_config={"target": "pit.quantization.gaussian.GaussianQuantRegularizer",
+                            "params": {"format": "bchw", "group": DIM, "n_samples": N_CODES, "backend": "hip"}},
+    )
+    return vae.eval().to(device)
+
+
+def cpu_baseline(bs_sample: int = 1):
+    """The CPU restatement (oracle + the same torch modules on CPU) on a bounded sample:
+    `bs_sample` 256x256 images through encoder -> oracle quantiser -> decoder, all host cores."""
+    import numpy as np
+
+    from oracle import gq_oracle as O
+    from pit_hip.modules.unet import Decoder, Encoder
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    enc, dec = Encoder(**UNET).eval(), Decoder(**UNET).eval()
+    g = torch.Generator().manual_seed(1000)
+    x = torch.rand(bs_sample, 3, 256, 256, generator=g) * 2 - 1
+    cb = O.codebook(N_CODES, DIM, 42)
+    O.lib()
+    with torch.no_grad():
+        enc(x[:1]); dec(torch.zeros(1, 16, 32, 32))  # warm the CPU kernels
+        t0 = time.perf_counter()
+        z = enc(x)
+        t1 = time.perf_counter()
+        zhat, ind = O.gq1_forward(z.numpy(), cb, DIM, threads=cores)
+        t2 = time.perf_counter()
+        dec(torch.from_numpy(zhat))
+        t3 = time.perf_counter()
+    total = t3 - t0
+    return {"value": round(bs_sample / total, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{bs_sample} image(s) 256x256: encoder {t1 - t0:.2f}s + oracle quantiser "
+                      f"({bs_sample * 1024} rows x 65536 codes, OpenMP) {t2 - t1:.2f}s + decoder {t3 - t2:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels-last", type=int, default=int(os.environ.get("GQ_CHANNELS_LAST", "0")))
+    args = ap.parse_args()
+
+    from pit_hip import _lib
+    from pit_hip.eval_dist import StepRecord, gather_step, init_from_env, psnr_zero_mean
+
+    env = init_from_env("nccl")
+    rank, world = env["rank"], env["world"]
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    device = torch.device("cuda", env["local_rank"])
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode (the reference sets trainer.benchmark: True)
+
+    vae = build_model(device)
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(device)
+    if args.channels_last:
+        vae = vae.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    tokens = (args.size // 8) ** 2
+    layout = StepRecord(args.batch, tokens, n_metrics=1)
+
+    @torch.no_grad()
+    def step():
+        zhat, info = vae.encode(x, return_reg_log=True)
+        rec = vae.decode(zhat)
+        record = layout.pack(info["indices"], psnr_zero_mean(x, rec)[:, None])
+        return gather_step(record, world)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = _lib.profile_collect()
+    _lib.profile_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        rows = args.batch * tokens
+        flops = 4.0 * DIM * N_CODES * rows  # 4*dim*N flops per row
+        avg_ms = kernel_ms / max(launches, 1)
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
+        line = {
+            "metric": "images/sec encode+quantize+decode, 256x256, codebook 2^16",
+            "value": round(args.batch * world * args.steps / elapsed, 3),
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "sd3unet_gq_0.25 encode->quantize->decode, bs=16/GPU, 256x256, "
+                                   "codebook 2^16 x dim 16, 1 group (BASELINE configs[1])",
+                       "global_batch": args.batch * world, "rows_per_step_per_gpu": rows,
+                       "weights": "seeded random init (seed 1234), no checkpoint offline",
+                       "parallelism": f"dp{world} image-sharded, one packed all_gather/step"},
+            "roofline": {"kernel": "gq_filter_kernel<16,2,8,GQ> (fp32 MFMA filter of the fused quantiser)",
+                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+                         "launches": launches, "avg_launch_us": round(avg_ms * 1e3, 2),
+                         "algorithmic_flops_per_launch": flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""CPU: host-side logic of the product package -- the C-ABI library loads and exports
+every symbol include/gqhip.h declares (no compute without a GPU), config factory,
+encoder/decoder parity with the seeded goldens, CPU plumbing of BASELINE config[0],
+and loud failure when tensors are not on a HIP device."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gq_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+META = json.load(open(os.path.join(G, "meta.json")))
+
+
+def _lib():
+    from pit_hip import _lib as L
+
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+    return L
+
+
+def test_cabi_exports_every_declared_symbol():
+    L = _lib()
+    header = open(os.path.join(ROOT, "include", "gqhip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b([a-z_0-9]+)\s*\(", header)) - {"defined"}
+    declared = {d for d in declared if d.startswith(("gq", "vq_", "lfq_"))}
+    assert len(declared) >= 19
+    dll = ctypes.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(dll, name), f"libgqhip.so does not export {name}"
+    assert declared == set(L.EXPORTED_SYMBOLS), "python binding and header disagree"
+    assert L.lib().gqhip_abi_version() == 1
+    assert L.lib().gqhip_status_string(2) == b"workspace missing or too small"
+
+
+def test_workspace_sizing_is_host_only_and_monotone():
+    L = _lib().lib()
+    a = L.gqhip_workspace_bytes(1024, 65536, 16)
+    b = L.gqhip_workspace_bytes(16384, 65536, 16)
+    assert 0 < a < b < (1 << 28)
+    assert L.gqhip_workspace_bytes(16, 65536, 65) == -1  # dim > 64 rejected
+    assert L.gqhip_workspace_bytes(16, 0, 16) == -1
+
+
+def test_invalid_arguments_return_status_not_crash():
+    L = _lib().lib()
+    assert L.gq_argmax_f32(None, None, None, None, None, None, 16, 4, 1024, 1.0, 0.0, None, 0, None) == 1
+    assert L.gq_scores_f32(None, None, None, None, 16, 4, 1024, 1.0, None) == 1
+    assert L.lfq_pack_f32(None, None, None, 4, 16, None) == 1
+
+
+def test_no_cpu_fallback():
+    L = _lib()
+    mu = torch.zeros(4, 16)
+    with pytest.raises(L.GqHipError, match="no CPU fallback"):
+        L.gq_argmax(mu, mu + 1, torch.zeros(64, 16))
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer
+
+    q = GaussianQuantRegularizer("bchw", 64, group=16).eval()
+    with pytest.raises(L.GqHipError):
+        q(torch.zeros(1, 32, 2, 2))
+
+
+def test_config_factory_remaps_pit_targets_and_resolves_interpolation():
+    from pit_hip.models.autoencoder import AutoencodingEngine
+    from pit_hip.util import instantiate_from_config, load_config
+
+    cfg = load_config(os.path.join(G, "tiny_config.yaml"))
+    assert cfg["model"]["params"]["decoder_config"]["params"]["ch_mult"] == [1, 2, 2]
+    m = instantiate_from_config(cfg["model"])
+    assert isinstance(m, AutoencodingEngine)
+    keys = list(m.state_dict())
+    assert keys[0] == "encoder.conv_in.weight" and any(k.startswith("decoder.up.0.block.0") for k in keys)
+    assert not any(k.startswith("regularization") for k in keys)  # GQ buffers are non-persistent
+    assert m.regularization.prior_samples.shape == (1024, 16)
+    with pytest.raises(KeyError):
+        instantiate_from_config({"params": {}})
+
+
+def test_regularizer_buffers_match_reference_hashes():
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer
+
+    q = GaussianQuantRegularizer("bchw", 65536, group=16, backend="cuda")
+    want = META["cases"]["G1"]["16"]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    assert sha(q.prior_samples.numpy()) == want["cb_sha"]
+    assert sha(q.normal_log_prob.numpy()) == want["nlp_sha"]
+    assert len(q.state_dict()) == 0 and q.group == 16 and q.n_samples == 65536
+    assert q._absmax == want["absmax"]
+
+
+def _sd_sha(sd):
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k].numpy()).tobytes())
+    return h.hexdigest()[:16]
+
+
+SMALL = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=32, in_channels=3, out_ch=3, ch=32,
+             ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[8], dropout=0.0)
+FULL = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=256, in_channels=3, out_ch=3, ch=128,
+            ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[32], dropout=0.0)
+
+
+def test_encoder_decoder_small_match_reference_outputs():
+    from pit_hip.modules.unet import Decoder, Encoder
+
+    torch.manual_seed(1234)
+    enc, dec = Encoder(**SMALL).eval(), Decoder(**SMALL).eval()
+    want = META["cases"]["G7"]["small"]
+    assert _sd_sha(enc.state_dict()) == want["enc_sd_sha"] and _sd_sha(dec.state_dict()) == want["dec_sd_sha"]
+    d = np.load(os.path.join(G, "g7_small.npz"))
+    with torch.no_grad():
+        ze = enc(torch.from_numpy(d["x"]))
+        xr = dec(torch.from_numpy(d["z_lat"]))
+    # fp32 tolerance: only the fused silu differs from the reference's x*sigmoid(x)
+    np.testing.assert_allclose(ze.numpy(), d["z_enc"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(xr.numpy(), d["x_rec"], atol=2e-5, rtol=1e-5)
+
+
+def test_cpu_plumbing_config0_single_image_encode_indices_decode():
+    """BASELINE.json configs[0]: one 256x256 image, CPU, no GPU: encoder (torch) ->
+    oracle quantiser -> decoder, against the reference's end-to-end golden."""
+    from pit_hip.modules.unet import Decoder, Encoder
+
+    torch.manual_seed(1234)
+    enc, dec = Encoder(**FULL).eval(), Decoder(**FULL).eval()
+    want = META["cases"]["G7"]["full"]
+    assert len(enc.state_dict()) == 116 and len(dec.state_dict()) == 158
+    assert _sd_sha(enc.state_dict()) == want["enc_sd_sha"] and _sd_sha(dec.state_dict()) == want["dec_sd_sha"]
+    d = np.load(os.path.join(G, "g7_full_e2e.npz"))
+    gx = torch.Generator().manual_seed(1000)
+    x = torch.rand(1, 3, 256, 256, generator=gx) * 2 - 1
+    with torch.no_grad():
+        ze = enc(x)
+    np.testing.assert_allclose(ze.numpy(), d["z_enc"], atol=5e-5, rtol=1e-4)
+    cb = O.codebook(65536, 16, 42)
+    zhat, ind = O.gq1_forward(d["z_enc"], cb, 16)  # the golden z_enc -> bit-exact indices
+    assert np.array_equal(ind, d["indices"])
+    with torch.no_grad():
+        xr = dec(torch.from_numpy(zhat))
+    assert float(np.abs(xr.numpy() - d["x_rec"].astype(np.float32)).max()) < 5e-3  # fp16-stored golden
+    st = d["x_rec_stats"]
+    assert abs(float(xr.mean()) - st[0]) < 1e-4 and abs(float(xr.std()) - st[1]) < 1e-4

@@ -1,0 +1,144 @@
+"""CPU: the oracle (oracle/gq_oracle.{c,py}) against the golden vectors captured from the
+reference by tests/golden/make_golden.py.  Integer/index results are compared bit-exactly."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gq_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+META = json.load(open(os.path.join(G, "meta.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.mark.parametrize("dim", [4, 8, 16])
+def test_g1_codebook_and_nlp_hashes(dim):
+    want = META["cases"]["G1"][str(dim)]
+    cb = O.codebook(65536, dim, 42)
+    assert sha(cb) == want["cb_sha"]
+    assert sha(O.nlp_table(cb)) == want["nlp_sha"]
+    assert float(np.abs(cb).max()) == want["absmax"]
+    assert np.array_equal(O.codebook(1024, dim, 42), cb[:1024])  # Sobol prefix
+
+
+@pytest.mark.parametrize("name,dim,n", [("g2_dim16_n1024", 16, 1024), ("g2_dim8_n1024", 8, 1024),
+                                        ("g2_dim4_n1024", 4, 1024), ("g2_dim16_n65536", 16, 65536)])
+def test_g2_kernel_boundary(name, dim, n):
+    d = load(name + ".npz")
+    cb = O.codebook(n, dim, 42)
+    idx, zhat, best, second = O.argmax_rows(d["mu"], d["std"], cb, 1.0, logstd=d["logstd"], with_gap=True)
+    assert np.array_equal(idx, d["indices"])
+    assert np.array_equal(zhat, cb[d["indices"]])
+    np.testing.assert_array_equal((best - second).astype(np.float32), d["gap"])
+    # the logstd the reference derived == torch-CPU log here (same torch build) -- informational pin
+    assert np.array_equal(O.torch_log(d["std"]), d["logstd"])
+
+
+def test_g2_score_matrix_argmax_consistency():
+    d = load("g2_dim16_n1024.npz")
+    cb = O.codebook(1024, 16, 42)
+    S = O.score_matrix(d["mu"][:64], d["std"][:64], cb, logstd=d["logstd"][:64])
+    assert np.array_equal(S.argmax(1), d["indices"][:64])
+
+
+@pytest.mark.parametrize("name", ["randn_seed0", "realistic_seed0"])
+def test_g3_module_boundary_known_answers(name):
+    d = load(f"g3_{name}.npz")
+    want = META["cases"]["G3"][name]
+    cb = O.codebook(65536, 16, 42)
+    zhat, ind = O.gq1_forward(d["z"], cb, 16)
+    assert ind.reshape(-1)[:8].tolist() == want["first8"]
+    assert np.array_equal(ind, d["indices"])
+    assert sha(ind) == want["indices_sha"] and sha(zhat) == want["zhat_sha"]
+    assert np.array_equal(O.gq1_dequant(ind, cb, 16), zhat)  # dequant round trip
+
+
+def test_g4_layouts():
+    cb4, cb8 = O.codebook(2048, 4, 42), O.codebook(2048, 8, 42)
+    for name, cb, group in (("g4_gq1_group4", cb4, 4), ("g4_gq1_group8", cb8, 8)):
+        d = load(name + ".npz")
+        zhat, ind = O.gq1_forward(d["z"], cb, group)
+        assert np.array_equal(ind, d["indices"]) and np.array_equal(zhat, d["zhat"])
+        assert np.array_equal(O.gq1_dequant(ind, cb, group), d["zhat"])
+    d = load("g4_gq1_blc_group4.npz")
+    zhat, ind = O.gq1_forward(d["z"], cb4, 4, fmt="blc")
+    assert np.array_equal(ind, d["indices"]) and np.array_equal(zhat, d["zhat"])
+    for dim_idx in (1, 2):
+        d = load(f"g4_gq2_dimidx{dim_idx}.npz")
+        zhat, ind = O.gq2_quant_vq(d["z"], cb4, 4, dim_idx)
+        assert np.array_equal(ind, d["indices"]) and np.array_equal(zhat, d["zhat"])
+        assert np.array_equal(O.gq2_dequant(ind, cb4, 4, dim_idx), d["zhat"])
+    a, b = load("g4_gq1_group4.npz")["indices"], load("g4_gq2_dimidx1.npz")["indices"]
+    assert a.shape == b.shape and not np.array_equal(a, b)  # strided vs contiguous grouping
+
+
+def test_g5_edges():
+    d = load("g5_edges.npz")
+    zhat, ind = O.gq1_forward(d["z"], d["cb"], 16)
+    assert np.array_equal(ind, d["indices"])
+    assert ind[0, 0, 0, 3] == 7  # duplicated codeword: first index wins
+    idx, _ = O.argmax_rows(d["mu"], d["std"], d["cb"], 1.0, logstd=d["logstd"])
+    assert np.array_equal(idx, d["indices"].transpose(0, 2, 3, 1).reshape(-1))
+
+
+def test_argmax_semantics_nan_and_ties():
+    # torch.argmax: first maximum wins; NaN counts as the maximum, first NaN wins
+    cb = O.codebook(64, 4, 42).copy()
+    cb[20] = cb[3]
+    mu = cb[[3, 5]].copy()
+    sd = np.full((2, 4), 0.1, np.float32)
+    idx, _ = O.argmax_rows(mu, sd, cb)
+    assert idx.tolist() == [3, 5]
+    mu[1, 0] = np.nan
+    idx, _ = O.argmax_rows(mu, sd, cb)
+    assert idx.tolist() == [3, 0]
+
+
+def test_g6_vq_lfq():
+    d = load("g6_vq_k1.npz")
+    zq, ind, gap = O.vq_forward(d["z"], d["emb"], 1, with_gap=True)
+    clear = gap > 1e-4
+    assert np.array_equal(ind[clear], d["indices"][clear])
+    d = load("g6_vq_k2.npz")
+    zq, ind, gap = O.vq_forward(d["z"], d["emb"], 2, with_gap=True)
+    clear = gap > 1e-4
+    assert np.array_equal(ind[clear], d["indices"][clear])
+    assert np.array_equal(O.vq_dequant(d["indices"].astype(np.int64), d["emb"], 2), d["zq"])
+    d = load("g6_lfq.npz")
+    q, ind = O.lfq_forward(d["x"])
+    assert np.array_equal(ind, d["indices"]) and np.array_equal(q, d["q"])
+    assert np.array_equal(O.lfq_dequant(ind), d["q"])
+    assert ind[0, 0, 0, 0] == 0  # x == 0 -> every bit 0
+
+
+def test_g8_sharding_index_logic():
+    for case in META["cases"]["G8"]:
+        n, w, bs = case["n"], case["world"], case["bs"]
+        per_rank = [O.eval_batches(n, w, r, bs) for r in range(w)]
+        assert per_rank == case["per_rank"]
+        flat = [[i for b in pr for i in b] for pr in per_rank]
+        order = O.reinterleave(flat)
+        steps = len(per_rank[0])
+        # restored order is the dataset order (the sampler wraps where it pads)
+        assert order == [j % n for j in range(steps * bs * w)]
+
+
+def test_cuda_formula_equals_twice_the_torch_score_up_to_row_constant():
+    d = load("g2_dim16_n1024.npz")
+    cb = O.codebook(1024, 16, 42)
+    mu, sd = d["mu"][:32], d["std"][:32]
+    a = O.cuda_formula_scores(mu, sd, cb, 1.0).astype(np.float64)
+    b = O.score_matrix(mu, sd, cb, logstd=d["logstd"][:32]).astype(np.float64)
+    diff = a - 2 * b
+    assert np.all(np.abs(diff - diff[:, :1]) < 2e-3)  # out = 2*s + const(r)
+    assert np.array_equal(a.argmax(1), b.argmax(1))

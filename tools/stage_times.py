@@ -1,0 +1,52 @@
+"""Per-stage device times (encoder / quantiser / decoder) for the bench workload."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "vq-vae-from-gaussian-vae_amd"))
+import bench  # noqa: E402
+
+
+def timed(fn, iters):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        out = fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--channels-last", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = True
+    vae = bench.build_model(dev)
+    x = (torch.rand(a.batch, 3, 256, 256) * 2 - 1).to(dev)
+    if a.channels_last:
+        vae = vae.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for _ in range(2):
+            z = vae.encoder(x)
+            zh, info = vae.regularization(z)
+            vae.decoder(zh)
+        te, z = timed(lambda: vae.encoder(x), a.iters)
+        tq, (zh, info) = timed(lambda: vae.regularization(z), a.iters * 4)
+        td, _ = timed(lambda: vae.decoder(zh), a.iters)
+    print(f"channels_last={a.channels_last} batch={a.batch}: encoder {te:.1f} ms, quantiser {tq:.3f} ms, "
+          f"decoder {td:.1f} ms -> {a.batch / (te + tq + td) * 1e3:.1f} img/s (stage sum)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+"""Image-sharded evaluation over RCCL / xGMI (one process per GPU).
+
+Re-expression of the reference's ``eval.py`` data path (eval.py:78-107 process
+group + DistributedSampler sharding, :144-205 per-batch encode -> decode ->
+metric -> all_gather, :207-257 rank-0 re-interleave).  What changes:
+
+* the reference issues six small ``all_gather``s per batch (PSNR, SSIM, MS-SSIM,
+  LPIPS, two Inception feature blocks; eval.py:166-201); every one is latency
+  bound on xGMI.  Here each rank packs everything it wants to publish for the
+  batch -- the code indices as uint16 (2^16-entry codebook) bit-cast into the
+  same buffer as the fp32 per-image metrics -- into ONE int32 record and the
+  step does ONE ``all_gather_into_tensor``.
+* records stay on the device; nothing is copied to the host until the end.
+* no data-path collective besides that gather: images are independent, the
+  4 MiB codebook and the weights are replicated (regenerated from the seed).
+
+Sharding semantics are exactly ``DistributedSampler(shuffle=False)`` (pads the
+index list by wrapping so every rank gets ceil(N/W) items) followed by a
+``drop_last=True`` loader, and the restore order is ``[j % W][j // W]``
+(eval.py:213-214).  Works with backend "nccl" (= RCCL on ROCm) and "gloo".
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+# ----------------------------------------------------------------------------- sharding
+def sampler_indices(n: int, world: int, rank: int) -> List[int]:
+    """DistributedSampler(shuffle=False, drop_last=False) index list of ``rank``."""
+    if n <= 0:
+        return []
+    total = -(-n // world) * world
+    idx = list(range(n))
+    pad = total - n
+    if pad > 0:
+        reps = -(-pad // n)
+        idx += (idx * reps)[:pad]
+    return idx[rank:total:world]
+
+
+def shard_batches(n: int, world: int, rank: int, bs: int) -> List[List[int]]:
+    """Batches of dataset indices rank ``rank`` evaluates (loader drop_last=True)."""
+    ids = sampler_indices(n, world, rank)
+    return [ids[i:i + bs] for i in range(0, len(ids) - bs + 1, bs)]
+
+
+def reinterleave(per_rank: Sequence[torch.Tensor]) -> torch.Tensor:
+    """per_rank[r] is the concatenation (over steps) of rank r's per-image rows.
+    Returns rows in dataset order: out[j] = per_rank[j % W][j // W] (eval.py:213-214)."""
+    w = len(per_rank)
+    stacked = torch.stack(list(per_rank), dim=1)  # [items_per_rank, W, ...]
+    return stacked.reshape((stacked.shape[0] * w,) + tuple(stacked.shape[2:]))
+
+
+# ----------------------------------------------------------------------------- process group
+def init_from_env(backend: Optional[str] = None) -> Dict[str, int]:
+    """env:// rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), one rank per GPU."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kwargs)
+    return {"rank": rank, "local_rank": local_rank, "world": world}
+
+
+# ----------------------------------------------------------------------------- packed record
+class StepRecord:
+    """Layout of one rank's per-step record: int32 words =
+    [ per-image metrics as fp32 bits (bs * n_metrics) | indices as uint16 pairs ]."""
+
+    def __init__(self, bs: int, tokens_per_image: int, n_metrics: int) -> None:
+        self.bs, self.tokens, self.n_metrics = bs, tokens_per_image, n_metrics
+        self.metric_words = bs * n_metrics
+        self.index_words = (bs * tokens_per_image + 1) // 2
+        self.words = self.metric_words + self.index_words
+
+    def pack(self, indices: torch.Tensor, metrics: torch.Tensor) -> torch.Tensor:
+        """indices: int64 [bs, ...] with values < 2^16; metrics: fp32 [bs, n_metrics]."""
+        dev = indices.device
+        rec = torch.empty(self.words, dtype=torch.int32, device=dev)
+        rec[: self.metric_words] = metrics.reshape(-1).to(torch.float32).view(torch.int32)
+        flat = indices.reshape(-1)
+        if flat.numel() % 2:
+            flat = torch.cat([flat, flat.new_zeros(1)])
+        u16 = flat.to(torch.int32)  # values < 65536
+        rec[self.metric_words:] = u16[0::2] | (u16[1::2] << 16)
+        return rec
+
+    def unpack(self, rec: torch.Tensor):
+        """rec: int32 [..., words] -> (indices int64 [..., bs, tokens], metrics fp32 [..., bs, n_metrics])."""
+        lead = rec.shape[:-1]
+        metrics = rec[..., : self.metric_words].contiguous().view(torch.float32).reshape(*lead, self.bs, self.n_metrics)
+        words = rec[..., self.metric_words:].to(torch.int64) & 0xFFFFFFFF
+        lo, hi = words & 0xFFFF, (words >> 16) & 0xFFFF
+        flat = torch.stack([lo, hi], dim=-1).reshape(*lead, -1)[..., : self.bs * self.tokens]
+        return flat.reshape(*lead, self.bs, self.tokens), metrics
+
+
+def gather_step(rec: torch.Tensor, world: int) -> torch.Tensor:
+    """ONE collective per step: [words] -> [world, words]."""
+    if world == 1:
+        return rec[None]
+    rec = rec.reshape(-1)
+    out = torch.empty(world * rec.numel(), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec)  # concatenated along dim 0 (works on RCCL and gloo)
+    return out.reshape(world, -1)
+
+
+def psnr_zero_mean(x: torch.Tensor, x_rec: torch.Tensor) -> torch.Tensor:
+    """get_psnr(zero_mean=True) of pit/evaluations/psnr.py:17-35, per image."""
+    a, b = (x + 1) * 127.5, (x_rec + 1) * 127.5
+    mse = torch.mean((a - b) ** 2, dim=[1, 2, 3])
+    return 20 * torch.log10(255.0 / torch.sqrt(mse))
+
+
+@torch.no_grad()
+def evaluate_sharded(model, images_for, n_images: int, bs: int, rank: int, world: int, device,
+                     tokens_per_image: int) -> Optional[Dict[str, torch.Tensor]]:
+    """The reference eval loop for this path: each rank encodes/decodes its shard, one gather per
+    step, rank 0 returns indices + PSNR in dataset order.  ``images_for(ids) -> [len(ids),3,H,W]``."""
+    batches = shard_batches(n_images, world, rank, bs)
+    layout = StepRecord(bs, tokens_per_image, n_metrics=1)
+    gathered = []
+    for ids in batches:
+        x = images_for(ids).to(device, non_blocking=True)
+        zhat, info = model.encode(x, return_reg_log=True)
+        rec_img = model.decode(zhat)
+        rec = layout.pack(info["indices"], psnr_zero_mean(x, rec_img)[:, None])
+        gathered.append(gather_step(rec, world))
+    if rank != 0 or not gathered:
+        return None
+    allrec = torch.stack(gathered, dim=1)  # [W, steps, words]
+    idx, met = layout.unpack(allrec)       # [W, steps, bs, tokens], [W, steps, bs, 1]
+    per_rank_idx = [idx[r].reshape(-1, tokens_per_image) for r in range(world)]
+    per_rank_psnr = [met[r].reshape(-1) for r in range(world)]
+    return {"indices": reinterleave(per_rank_idx), "psnr": reinterleave(per_rank_psnr)}

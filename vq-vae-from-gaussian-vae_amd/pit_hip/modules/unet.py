@@ -1,0 +1,239 @@
+"""SD3-style conv encoder / decoder, kept in PyTorch-ROCm (MIOpen / hipBLASLt).
+
+Mirror of the reference's ``pit/modules/unet.py`` interface for the hot path:
+``Encoder(**params)(x) -> [B, 2*z, H/8, W/8]`` (unet.py:317-436) and
+``Decoder(**params)(z) -> [B, 3, H, W]`` (unet.py:439-587).  The module tree is
+laid out so that ``state_dict()`` keys equal the reference's (``conv_in``,
+``down.{i}.block.{j}.norm1`` ... ``up.{i}.upsample.conv``), so a reference
+checkpoint's ``encoder.*`` / ``decoder.*`` tensors load unchanged.
+
+Only what the shipped SD3-UNet configs use is built: ``attn_type`` "vanilla"
+(single-head SDPA, unet.py:166-206) or "none"; ``temb_channels`` is always 0 on
+this path (unet.py:342, :473) so the time-embedding projection is not created.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _gn(ch: int) -> nn.GroupNorm:
+    # unet.py:54-57
+    return nn.GroupNorm(32, ch, eps=1e-6, affine=True)
+
+
+def _silu(x: torch.Tensor) -> torch.Tensor:
+    # unet.py:49-51 (x * sigmoid(x)); F.silu is the same function, one kernel.
+    return F.silu(x)
+
+
+def _conv3(cin: int, cout: int, padding_mode: str = "zeros", stride: int = 1, padding: int = 1) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, 3, stride, padding, padding_mode=padding_mode)
+
+
+class ResnetBlock(nn.Module):
+    """GN -> swish -> conv3 -> GN -> swish -> conv3 (+ 1x1 shortcut); unet.py:100-153."""
+
+    def __init__(self, cin: int, cout: int, dropout: float = 0.0, padding_mode: str = "zeros") -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.norm1 = _gn(cin)
+        self.conv1 = _conv3(cin, cout, padding_mode)
+        self.norm2 = _gn(cout)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = _conv3(cout, cout, padding_mode)
+        if cin != cout:
+            self.nin_shortcut = nn.Conv2d(cin, cout, 1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = self.conv1(_silu(self.norm1(x)))
+        h = self.conv2(self.dropout(_silu(self.norm2(h))))
+        if self.in_channels != self.out_channels:
+            x = self.nin_shortcut(x)
+        return x + h
+
+
+class AttnBlock(nn.Module):
+    """Single-head self attention over the h*w positions; unet.py:166-206."""
+
+    def __init__(self, ch: int) -> None:
+        super().__init__()
+        self.norm = _gn(ch)
+        self.q = nn.Conv2d(ch, ch, 1)
+        self.k = nn.Conv2d(ch, ch, 1)
+        self.v = nn.Conv2d(ch, ch, 1)
+        self.proj_out = nn.Conv2d(ch, ch, 1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        b, c, h, w = x.shape
+        y = self.norm(x)
+        # [b, c, h, w] -> [b, 1, hw, c]
+        q, k, v = (f(y).reshape(b, 1, c, h * w).transpose(2, 3).contiguous() for f in (self.q, self.k, self.v))
+        a = F.scaled_dot_product_attention(q, k, v)  # scale c**-0.5
+        a = a.transpose(2, 3).reshape(b, c, h, w)
+        return x + self.proj_out(a)
+
+
+class Downsample(nn.Module):
+    """Asymmetric (0,1,0,1) pad + stride-2 conv3; unet.py:76-97."""
+
+    def __init__(self, ch: int, with_conv: bool = True, padding_mode: str = "zeros") -> None:
+        super().__init__()
+        self.with_conv = with_conv
+        self.mode = "constant" if padding_mode == "zeros" else padding_mode
+        if with_conv:
+            self.conv = _conv3(ch, ch, stride=2, padding=0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.with_conv:
+            return F.avg_pool2d(x, 2, 2)
+        if self.mode == "constant":
+            x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+        else:
+            x = F.pad(x, (0, 1, 0, 1), mode=self.mode)
+        return self.conv(x)
+
+
+class Upsample(nn.Module):
+    """Nearest x2 + conv3; unet.py:60-73."""
+
+    def __init__(self, ch: int, with_conv: bool = True, padding_mode: str = "zeros") -> None:
+        super().__init__()
+        self.with_conv = with_conv
+        if with_conv:
+            self.conv = _conv3(ch, ch, padding_mode)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        return self.conv(x) if self.with_conv else x
+
+
+def _make_attn(ch: int, attn_type: str) -> nn.Module:
+    if attn_type == "vanilla":
+        return AttnBlock(ch)
+    if attn_type == "none":
+        return nn.Identity()
+    raise NotImplementedError(f"attn_type={attn_type!r} is not on the SD3-UNet hot path (reference unet.py:291-314)")
+
+
+class _Level(nn.Module):
+    """One resolution level: res blocks (+ per-block attention) and the optional resampler."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.block = nn.ModuleList()
+        self.attn = nn.ModuleList()
+
+    def run(self, h: torch.Tensor) -> torch.Tensor:
+        has_attn = len(self.attn) > 0
+        for i, blk in enumerate(self.block):
+            h = blk(h)
+            if has_attn:
+                h = self.attn[i](h)
+        return h
+
+
+class _Mid(nn.Module):
+    def __init__(self, ch: int, dropout: float, padding_mode: str) -> None:
+        super().__init__()
+        self.block_1 = ResnetBlock(ch, ch, dropout, padding_mode)
+        self.block_2 = ResnetBlock(ch, ch, dropout, padding_mode)  # no mid attention (unet.py:391, :500)
+
+    def forward(self, h: torch.Tensor) -> torch.Tensor:
+        return self.block_2(self.block_1(h))
+
+
+class Encoder(nn.Module):
+    def __init__(self, *, ch: int, out_ch: int = 3, ch_mult: Sequence[int] = (1, 2, 4, 8), num_res_blocks: int,
+                 attn_resolutions: Sequence[int], dropout: float = 0.0, resamp_with_conv: bool = True,
+                 in_channels: int, resolution: int, z_channels: int, double_z: bool = True,
+                 use_linear_attn: bool = False, attn_type: str = "vanilla", padding_mode: str = "zeros",
+                 **ignore_kwargs) -> None:
+        super().__init__()
+        if use_linear_attn:
+            attn_type = "linear"
+        self.ch, self.resolution, self.in_channels = ch, resolution, in_channels
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.conv_in = _conv3(in_channels, ch, padding_mode)
+        widths = [ch] + [ch * m for m in ch_mult]
+        res = resolution
+        self.down = nn.ModuleList()
+        for lvl in range(self.num_resolutions):
+            level = _Level()
+            cin = widths[lvl]
+            for _ in range(num_res_blocks):
+                level.block.append(ResnetBlock(cin, widths[lvl + 1], dropout, padding_mode))
+                cin = widths[lvl + 1]
+                if res in attn_resolutions:
+                    level.attn.append(_make_attn(cin, attn_type))
+            if lvl != self.num_resolutions - 1:
+                level.downsample = Downsample(cin, resamp_with_conv, padding_mode)
+                res //= 2
+            self.down.append(level)
+        top = widths[-1]
+        self.mid = _Mid(top, dropout, padding_mode)
+        self.norm_out = _gn(top)
+        self.conv_out = _conv3(top, 2 * z_channels if double_z else z_channels, padding_mode)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = self.conv_in(x)
+        for lvl, level in enumerate(self.down):
+            h = level.run(h)
+            if lvl != self.num_resolutions - 1:
+                h = level.downsample(h)
+        h = self.mid(h)
+        return self.conv_out(_silu(self.norm_out(h)))
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch: int, out_ch: int, ch_mult: Sequence[int] = (1, 2, 4, 8), num_res_blocks: int,
+                 attn_resolutions: Sequence[int], dropout: float = 0.0, resamp_with_conv: bool = True,
+                 in_channels: int, resolution: int, z_channels: int, give_pre_end: bool = False,
+                 tanh_out: bool = False, use_linear_attn: bool = False, attn_type: str = "vanilla",
+                 padding_mode: str = "zeros", **ignore_kwargs) -> None:
+        super().__init__()
+        if use_linear_attn:
+            attn_type = "linear"
+        self.ch, self.resolution, self.in_channels = ch, resolution, in_channels
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.give_pre_end, self.tanh_out = give_pre_end, tanh_out
+        top = ch * ch_mult[-1]
+        res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, res, res)
+        self.conv_in = _conv3(z_channels, top, padding_mode)
+        self.mid = _Mid(top, dropout, padding_mode)
+        levels = []
+        cin = top
+        for lvl in reversed(range(self.num_resolutions)):
+            level = _Level()
+            cout = ch * ch_mult[lvl]
+            for _ in range(num_res_blocks + 1):
+                level.block.append(ResnetBlock(cin, cout, dropout, padding_mode))
+                cin = cout
+                if res in attn_resolutions:
+                    level.attn.append(_make_attn(cin, attn_type))
+            if lvl != 0:
+                level.upsample = Upsample(cin, resamp_with_conv, padding_mode)
+                res *= 2
+            levels.append(level)
+        self.up = nn.ModuleList(reversed(levels))  # index = resolution level, like the reference
+        self.norm_out = _gn(cin)
+        self.conv_out = _conv3(cin, out_ch, padding_mode)
+
+    def get_last_layer(self, **kwargs) -> torch.Tensor:
+        return self.conv_out.weight
+
+    def forward(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
+        self.last_z_shape = z.shape
+        h = self.mid(self.conv_in(z))
+        for lvl in reversed(range(self.num_resolutions)):
+            h = self.up[lvl].run(h)
+            if lvl != 0:
+                h = self.up[lvl].upsample(h)
+        if self.give_pre_end:
+            return h
+        h = self.conv_out(_silu(self.norm_out(h)))
+        return torch.tanh(h) if self.tanh_out else h

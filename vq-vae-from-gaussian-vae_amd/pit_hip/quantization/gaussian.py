@@ -1,0 +1,241 @@
+"""Gaussian-quantisation regularizers, MI355X path.
+
+Drop-in mirrors of ``pit.quantization.gaussian`` (reference file
+pit/quantization/gaussian.py): same constructor keywords, same ``forward(z) ->
+(zhat, info)`` / ``dequant(indices) -> zhat`` contracts, same buffer names
+(``prior_samples``, ``normal_log_prob``, both non-persistent).  The eval branch
+(gaussian.py:120-160 and :273-331) runs as ONE call into libgqhip.so
+(``gq_quantize_z_f32``): chunk / clamp / exp, the group permutes, the
+rows x 65 536 score matrix, the arg-max and the codeword gather are all inside
+the HIP kernels and the score matrix never exists in HBM.
+
+backend:
+  "hip"   fused path (default here).
+  "cuda"  the reference's call sequence -- ``gq_cuda.ops.gq_cuda`` into a
+          persistent ``perturbed`` buffer, then ``torch.argmax`` and
+          ``index_select`` (gaussian.py:124-133) -- served by our HIP build of
+          the ``extension_cpp::gq`` op.  Kept for users who want the score
+          matrix; it is HBM-bound by construction.
+  "torch" accepted for config compatibility; runs the fused HIP path (the
+          indices are those of the reference's torch backend, bit for bit).
+There is no CPU implementation in this package: tensors must live on a HIP
+device (``pit_hip._lib`` raises otherwise).
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+from torch.distributions import Normal
+
+from .. import _lib
+
+
+def prior_samples(n_samples: int, n_variable: int, seed_rec: int) -> torch.Tensor:
+    """Scrambled-Sobol points mapped through the normal quantile (gaussian.py:15-19).
+
+    Third-party arithmetic (torch SobolEngine + scipy ``norm.ppf``), called the
+    same way as the reference so the codebook is identical (sha256 pinned in
+    tests/golden)."""
+    from scipy.stats import norm
+    from torch.quasirandom import SobolEngine
+
+    sobol = SobolEngine(n_variable, scramble=True, seed=seed_rec)
+    return torch.from_numpy(norm.ppf(sobol.draw(n_samples)))
+
+
+def _kl_bits(mu: torch.Tensor, var: torch.Tensor, logvar: torch.Tensor) -> torch.Tensor:
+    return 1.4426 * 0.5 * (torch.pow(mu, 2) + var - 1.0 - logvar)
+
+
+class _GaussianQuantBase(nn.Module):
+    def _setup(self, n_samples: int, dim: int, seed: int, beta: float, backend: str,
+               logvar_range: Sequence[float], tolerance: float, lam_factor: float, lam_range) -> None:
+        self.n_samples = n_samples
+        self.log_n_samples = int(math.log(n_samples, 2))
+        self.logvar_range = logvar_range
+        self.lam_factor, self.tolerance = lam_factor, tolerance
+        self.lam = self.lam_min = self.lam_max = 1.0
+        self.lam_range = lam_range
+        self.beta, self.seed = beta, seed
+        self.register_buffer("prior_samples", prior_samples(n_samples, dim, seed).float(), persistent=False)
+        self.normal_dist = Normal(torch.zeros([1, dim]), torch.ones([1, dim]))
+        self.register_buffer("normal_log_prob", self.normal_dist.log_prob(self.prior_samples).float(),
+                             persistent=False)
+        self.perturbed = None
+        if backend not in ("hip", "cuda", "torch"):
+            raise ValueError(f"unknown backend {backend!r}")
+        self.backend = backend
+        self._ws = _lib.Workspace()
+        self._absmax = float(self.prior_samples.abs().max())  # host-side once; passed to every call
+
+    # the reference's "cuda" call sequence on rows (gaussian.py:124-133 / :289-298)
+    def _compat_rows(self, mu: torch.Tensor, std: torch.Tensor, dim: int):
+        import gq_cuda
+
+        if self.perturbed is None or self.perturbed.shape[0] != mu.shape[0] or self.perturbed.device != mu.device:
+            self.perturbed = torch.zeros([mu.shape[0], self.n_samples], device=mu.device).contiguous()
+        gq_cuda.ops.gq_cuda(mu, std, self.prior_samples, self.perturbed, dim, mu.shape[0], self.n_samples, self.beta)
+        indices = torch.argmax(self.perturbed, dim=1).clone()
+        return torch.index_select(self.prior_samples, 0, indices), indices
+
+    def _update_lambdas(self, kl2_mean, kl2_min, kl2_max, buggy_lam_max: bool) -> None:
+        # gaussian.py:103-117 (GQ1) / :238-252 (GQ2, whose lam_max decrease is a no-op: line 251)
+        n, tol, f = self.log_n_samples, self.tolerance, self.lam_factor
+        self.lam = self.lam * f if kl2_mean > n else self.lam / f
+        if kl2_max > n + tol:
+            self.lam_max = self.lam_max * f
+        elif not buggy_lam_max:
+            self.lam_max = self.lam_max / f
+        self.lam_max = max(min(self.lam_max, self.lam_range[1]), 1.0)
+        self.lam_min = self.lam_min / f if kl2_min < n - tol else self.lam_min * f
+        self.lam_min = max(min(self.lam_min, 1.0), self.lam_range[0])
+
+    def _weighted_kl(self, kl2: torch.Tensor) -> torch.Tensor:
+        n, tol = self.log_n_samples, self.tolerance
+        ge = (kl2 > n + tol).type(kl2.dtype) * self.lam_max
+        eq = (kl2 <= n + tol).type(kl2.dtype) * (kl2 >= n - tol).type(kl2.dtype)
+        le = (kl2 < n - tol).type(kl2.dtype) * self.lam_min
+        return ge * kl2 + eq * kl2 + le * kl2
+
+
+class GaussianQuantRegularizer(_GaussianQuantBase):
+    """train(): Gaussian VAE sample + KL-to-log2(N) loss; eval(): VQ with the fixed
+    quasi-random codebook (reference gaussian.py:22-178)."""
+
+    def __init__(self, format, n_samples, group=1, logvar_range=[-30.0, 20.0], tolerance=0.5, lam_factor=1.01,
+                 seed=42, beta=1.0, backend="hip"):
+        super().__init__()
+        assert format in ["bchw", "blc"]
+        self.format, self.group = format, group
+        self._setup(n_samples, group, seed, beta, backend, logvar_range, tolerance, lam_factor, (1e-3, 1e3))
+
+    def forward(self, z):
+        z = z.float()
+        if self.format == "bchw":
+            b, c2, h, w = z.shape
+            l = h * w
+            zf = z.reshape(b, c2, l).transpose(1, 2)  # b (h w) c, a view
+        else:
+            b, l, c2 = z.shape
+            zf = z
+        c = c2 // 2
+        mu, logvar = zf.chunk(2, 2)
+        logvar = torch.clamp(logvar, self.logvar_range[0], self.logvar_range[1])
+        std = torch.exp(0.5 * logvar)
+
+        if self.training:
+            var = torch.exp(logvar)
+            zhat = mu + torch.randn_like(mu) * std
+            kl2 = _kl_bits(mu, var, logvar).reshape(b, l, self.group, c // self.group).sum(dim=2)
+            kl2_mean, kl2_min, kl2_max = torch.mean(kl2), torch.min(kl2), torch.max(kl2)
+            kl_loss = torch.sum(self._weighted_kl(kl2), dim=[1, 2])
+            kl_loss = torch.sum(kl_loss) / kl_loss.shape[0] * self.lam
+            self._update_lambdas(kl2_mean, kl2_min, kl2_max, buggy_lam_max=False)
+            if self.format == "bchw":
+                zhat = zhat.transpose(1, 2).reshape(b, c, h, w)
+            info = {"kl_loss": torch.mean(kl_loss), "bits-mean": kl2_mean, "bits-min": kl2_min,
+                    "bits-max": kl2_max, "lam": torch.zeros_like(kl_loss) + self.lam}
+            return zhat, info
+
+        zhat_noquant = mu + torch.randn_like(mu) * std  # consumes RNG in eval, like gaussian.py:121
+        k = c // self.group
+        if self.backend == "cuda":
+            mu_r = mu.reshape(b, l, self.group, k).permute(0, 1, 3, 2).reshape(-1, self.group)
+            std_r = std.reshape(b, l, self.group, k).permute(0, 1, 3, 2).reshape(-1, self.group)
+            zq, ind = self._compat_rows(mu_r.contiguous(), std_r.contiguous(), self.group)
+            zhat = zq.reshape(b, l, k, self.group).permute(0, 1, 3, 2).reshape(b, l, c).float()
+            indices = ind.reshape(b, l, k)
+            if self.format == "bchw":
+                zhat = zhat.transpose(1, 2).reshape(b, c, h, w)
+                indices = indices.transpose(1, 2).reshape(b, k, h, w)
+        else:
+            indices, zhat = _lib.gq_quantize_z(z, self.prior_samples, self.group, self.format,
+                                               _lib.GQHIP_GROUP_STRIDED, self.logvar_range, self.beta,
+                                               self._absmax, self._ws)
+        if self.format == "bchw":
+            zhat_noquant = zhat_noquant.transpose(1, 2).reshape(b, c, h, w)
+        return zhat, {"indices": indices, "zhat_noquant": zhat_noquant}
+
+    def dequant(self, indices):
+        return _lib.gq_dequant(indices, self.prior_samples, self.group, self.format, _lib.GQHIP_GROUP_STRIDED)
+
+
+class GaussianQuantRegularizer2(_GaussianQuantBase):
+    """Contiguous-channel grouping, arbitrary channel axis, Gaussian + VQ branches mixed
+    by a straight-through estimator (reference gaussian.py:181-362)."""
+
+    def __init__(self, dim, codebook_size, dim_idx=1, logvar_range=[-30.0, 20.0], tolerance=0.5, lam_factor=1.01,
+                 seed=42, beta=1.0, use_ste=True, backend="hip"):
+        super().__init__()
+        self.dim, self.dim_idx, self.use_ste = dim, dim_idx, use_ste
+        self._setup(codebook_size, dim, seed, beta, backend, logvar_range, tolerance, lam_factor, (1e-7, 1e7))
+
+    def _split(self, z):
+        z = torch.movedim(z, self.dim_idx, -1)
+        assert z.shape[-1] % (self.dim * 2) == 0
+        z_shape = z.shape
+        z = z.reshape(-1, z_shape[-1])
+        mu, logvar = z.chunk(2, -1)
+        logvar = torch.clamp(logvar, self.logvar_range[0], self.logvar_range[1])
+        return z, z_shape, mu, logvar, torch.exp(0.5 * logvar)
+
+    def _restore(self, t, z_shape):
+        return torch.movedim(t.reshape(*z_shape[:-1], -1), -1, self.dim_idx)
+
+    def quant_gaussian(self, z):
+        z2, z_shape, mu, logvar, std = self._split(z)
+        knum = z2.shape[-1] // (self.dim * 2)
+        var = torch.exp(logvar)
+        zhat = mu + torch.randn_like(mu) * std
+        kl2 = _kl_bits(mu, var, logvar).reshape(-1, knum, self.dim).sum(dim=-1)
+        kl2_mean, kl2_min, kl2_max = torch.mean(kl2), torch.min(kl2), torch.max(kl2)
+        kl_loss = torch.mean(self._weighted_kl(kl2)) * self.lam
+        self._update_lambdas(kl2_mean, kl2_min, kl2_max, buggy_lam_max=True)
+        info = {"kl_loss": torch.mean(kl_loss), "bits-mean": kl2_mean, "bits-min": kl2_min, "bits-max": kl2_max,
+                "lam-min": self.lam_min, "lam-max": self.lam_max, "lam": self.lam,
+                "mu": self._restore(mu, z_shape), "std": self._restore(std, z_shape),
+                "zhat_noquant": self._restore(zhat, z_shape)}
+        return info["zhat_noquant"], info
+
+    def quant_vq(self, z):
+        z2, z_shape, mu, _, std = self._split(z.float())
+        knum = z2.shape[-1] // (self.dim * 2)
+        if self.backend == "cuda":
+            zq, ind = self._compat_rows(mu.reshape(-1, self.dim).contiguous(), std.reshape(-1, self.dim).contiguous(),
+                                        self.dim)
+            zhat = zq.reshape(-1, knum * self.dim).float()
+            indices = ind.reshape(-1, knum)
+        else:
+            # rows are already "position-major, channel-last": one BLC image of L = #positions
+            ind, zq = _lib.gq_quantize_z(z2.contiguous()[None], self.prior_samples, self.dim, "blc",
+                                         _lib.GQHIP_GROUP_CONTIGUOUS, self.logvar_range, self.beta, self._absmax,
+                                         self._ws)
+            zhat, indices = zq[0], ind[0]
+        zhat = self._restore(zhat, z_shape)
+        indices = self._restore(indices, z_shape)
+        return zhat, {"indices": indices, "zhat_quant": zhat}
+
+    def forward(self, z):
+        zhat_g, info_g = self.quant_gaussian(z)
+        with torch.no_grad():
+            zhat_v, info_v = self.quant_vq(z)
+        if self.use_ste:
+            zhat = zhat_g - zhat_g.detach() + zhat_v
+        else:
+            zhat = zhat_g if self.training else zhat_v
+        return zhat, info_g | info_v
+
+    def dequant(self, indices):
+        ind = torch.movedim(indices, self.dim_idx, -1)
+        i_shape = ind.shape
+        flat = ind.reshape(1, -1, i_shape[-1]).contiguous()
+        zhat = _lib.gq_dequant(flat, self.prior_samples, self.dim, "blc", _lib.GQHIP_GROUP_CONTIGUOUS)[0]
+        return torch.movedim(zhat.reshape(*i_shape[:-1], -1), -1, self.dim_idx)
+
+
+class IdentityRegularizer(nn.Module):
+    def forward(self, z):
+        return z, dict()

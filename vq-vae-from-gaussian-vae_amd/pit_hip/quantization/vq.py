@@ -1,0 +1,68 @@
+"""VQQuantizer on the HIP arg-min path (reference pit/quantization/vq.py:8-129).
+
+Same constructor, same ``embedding.weight`` parameter (so checkpoints load), same
+``forward -> (z_q, {"indices", "codebook_loss"})`` / ``dequant`` contracts.  The
+``[rows, n]`` distance matrix of vq.py:58-69 is never built: the nearest code is
+found by the MFMA filter (``-|e|^2 + 2 z.e``) + an fp64 re-rank of its candidates
+(``vq_argmin_f32``)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class VQQuantizer(nn.Module):
+    def __init__(self, format, n, dim, beta=0.25, codebook_num=1, legacy=True):
+        super().__init__()
+        self.format, self.n, self.dim = format, n, dim
+        self.beta, self.legacy, self.codebook_num = beta, legacy, codebook_num
+        self.embedding = nn.Embedding(self.n, self.dim)
+        self.embedding.weight.data.uniform_(-1.0 / self.n, 1.0 / self.n)
+        self._ws = _lib.Workspace()
+
+    def get_trainable_parameters(self):
+        return self.embedding.parameters()
+
+    def _to_bhwc(self, t):
+        if self.format == "bchw":
+            return t.permute(0, 2, 3, 1).contiguous()
+        b, l, c = t.shape
+        h = int(np.sqrt(l))
+        assert h * h == l, "Input length must be a perfect square for blc format"
+        return t.reshape(b, h, h, c).contiguous()
+
+    def _from_bhwc(self, t):
+        if self.format == "bchw":
+            return t.permute(0, 3, 1, 2).contiguous()
+        b, h, w, c = t.shape
+        return t.reshape(b, h * w, c).contiguous()
+
+    def forward(self, z):
+        z = self._to_bhwc(z)
+        assert self.dim * self.codebook_num == z.shape[-1]
+        zf = z.reshape(-1, self.dim, self.codebook_num)  # channel = d*K + k (vq.py:53)
+        w = self.embedding.weight
+        z_q, indices = [], []
+        for k in range(self.codebook_num):
+            with torch.no_grad():
+                idx, _ = _lib.vq_argmin(zf[:, :, k].detach().float().contiguous(), w.detach().float(), ws=self._ws)
+            z_q.append(self.embedding(idx)[:, :, None])
+            indices.append(idx[:, None])
+        z_q = torch.cat(z_q, dim=2).view(z.shape)
+        indices = torch.cat(indices, dim=1).reshape(z.shape[0], z.shape[1], z.shape[2], self.codebook_num)
+        if not self.legacy:
+            loss = self.beta * torch.mean((z_q.detach() - z) ** 2) + torch.mean((z_q - z.detach()) ** 2)
+        else:
+            loss = torch.mean((z_q.detach() - z) ** 2) + self.beta * torch.mean((z_q - z.detach()) ** 2)
+        z_q = z + (z_q - z).detach()
+        return self._from_bhwc(z_q), {"indices": self._from_bhwc(indices), "codebook_loss": loss}
+
+    def dequant(self, indices):
+        ind = self._to_bhwc(indices)
+        b, h, w, _ = ind.shape
+        flat = ind.reshape(-1, self.codebook_num)
+        z_q = torch.cat([self.embedding(flat[:, k])[:, :, None] for k in range(self.codebook_num)], dim=2)
+        return self._from_bhwc(z_q.reshape(b, h, w, self.dim * self.codebook_num))
