@@ -52,7 +52,7 @@ def cpu_baseline(bs_sample: int = 1):
     from oracle import gq_oracle as O
     from pit_hip.modules.unet import Decoder, Encoder
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)  # torch-CPU convs stop scaling (and SMT hurts) beyond that
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     enc, dec = Encoder(**UNET).eval(), Decoder(**UNET).eval()

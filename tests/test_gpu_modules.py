@@ -144,8 +144,8 @@ def test_g6_vq_and_lfq():
         assert np.array_equal(ind, oind)                     # fp64 arbiter on both sides: exact
         clear = d["gap"] > 1e-4
         assert np.array_equal(ind[clear], d["indices"][clear])  # the reference's fp32 einsum path
-        assert np.array_equal(vq.dequant(info["indices"]).cpu().numpy(), O.vq_dequant(oind, d["emb"], k))
-        assert torch.allclose(zq, vq.dequant(info["indices"]), atol=1e-6)
+        assert np.array_equal(vq.dequant(info["indices"]).detach().cpu().numpy(), O.vq_dequant(oind, d["emb"], k))
+        assert torch.allclose(zq.detach(), vq.dequant(info["indices"]).detach(), atol=1e-6)
     d = load("g6_lfq.npz")
     lfq = LFQQuantizer("bchw", codebook_size=256, num_codebooks=2).eval().to(DEV)
     q, info = lfq(torch.from_numpy(d["x"]).to(DEV))

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel-trace stats of bench.py, then PMC passes on the
+# quantiser-only microbench (same filter kernel, same shape).  Summaries land in gpurun_out/.
+set -u
+R=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$R
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_stdout.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench_trace" -- python3 "$REPO/tools/kbench.py" --iters 20 > "$OUT/kbench_stdout.txt" 2>&1
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+  tag=$(echo "$C" | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$tag" -- python3 "$REPO/tools/kbench.py" --iters 5 > "$OUT/pmc_${tag}_stdout.txt" 2>&1
+done
+# compact summaries
+python3 "$REPO/tools/summarize_prof.py" "$OUT" > "$OUT/SUMMARY.txt" 2>&1
+find "$OUT" -name "*.csv" -size +2M -delete
+ls -R "$OUT" | head -50
