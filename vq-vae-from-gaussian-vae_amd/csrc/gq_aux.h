@@ -8,14 +8,6 @@
 
 namespace gqhip {
 
-__global__ void ws_init_kernel(WsHeader *hdr, float absmax) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    hdr->fb_count = 0;
-    hdr->reranked = 0ull;
-    hdr->absmax = absmax;
-  }
-}
-
 // max |cb| -> *out via integer atomicMax on the (non-negative) float bits; a
 // NaN/inf element maps to +inf so the fused paths fall back to exhaustive.
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ cb, long count,

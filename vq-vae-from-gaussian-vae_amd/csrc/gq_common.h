@@ -18,8 +18,9 @@ constexpr int kMaxDim = 64;
 __device__ __host__ constexpr float half_log_2pi() { return 0.91893853320467274178f; }
 
 // One candidate record per (row, code split), produced by the filter kernel.
-//   m1 >= m2 >= m3 : the three largest half-tile maxima of the filter score
-//   id1, id2       : half-tile ids (tile*2 + half) of m1 and m2
+//   m1 >= m2 >= m3 : the three largest half-pair maxima of the filter score
+//   id1, id2       : half-pair ids ((tile>>1)*2 + half) of m1 and m2; a half-pair
+//                    is the 2 x 16 codes one lane half sees in tiles 2p, 2p+1
 struct __attribute__((aligned(32))) Rec {
   float m1, m2, m3;
   int id1, id2;
@@ -30,11 +31,12 @@ struct __attribute__((aligned(32))) Rec {
 struct WsHeader {
   int fb_count;                       // rows routed to the exhaustive kernel
   int pad0;
-  unsigned long long reranked;        // half-tiles evaluated exactly
+  unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly
   float absmax;                       // max |cb| (device-computed when needed)
-  int pad1[59];
+  int pad1[27];
+  unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
 };
-static_assert(sizeof(WsHeader) == 256, "header is 256 bytes");
+static_assert(sizeof(WsHeader) == 512, "header is 512 bytes");
 
 // Insert (t, id) into a descending top-3 (ids kept for the top 2 only).
 __device__ __forceinline__ void top3_insert(float t, int id, float &m1, float &m2,

@@ -6,23 +6,27 @@
 // to a per-row constant when  A = beta/2 - 1/(2 sd^2),  B = mu / sd^2
 // (and equals -|z - e_j|^2 + |z|^2 for VQ with A = -1, B = 2 z; vq.py:58-69).
 // The score matrix never leaves registers: each lane keeps the three largest
-// half-tile maxima it has seen (+ the ids of the best two); the re-rank kernel
-// (gq_rerank.h) re-evaluates those few half-tiles in the reference's exact
+// "half-pair" maxima it has seen (+ the ids of the best two); the re-rank kernel
+// (gq_rerank.h) re-evaluates those few half-pairs in the reference's exact
 // operation order, which is what makes the indices bit-identical.
 //
 // Tiling (wave64, v_mfma_f32_32x32x2_f32):
 //   D[i = code in tile][j = row in tile] ; lane l: c = l & 31, h = l >> 5
-//   A operand, k-step s : codebook value  cb[tile*32 + c][h*HD + s]   (squared for s < HD)
+//   A operand, k-step s : codebook value  cb[tile*32 + c][h*HD + s]   (its square for s < HD)
 //   B operand, k-step s : row coefficient A|B[row c][h*HD + s]
-//   D regs of lane (c,h): row c, codes (reg&3) + 8*(reg>>2) + 4*h  -> "half-tile" h
+//   D regs of lane (c,h): row c, codes (reg&3) + 8*(reg>>2) + 4*h of the tile
 // so all 16 accumulator registers of a lane belong to ONE row and the running
-// maximum is a v_max3 chain with no cross-lane traffic in the loop.
+// maximum is a v_max3 chain with no cross-lane traffic in the loop.  A half-pair
+// (pair p, half h) = those 16 codes in tiles 2p and 2p+1 -> 32 codes.
 // A block = 4 waves x RT row tiles (128*RT rows); the code axis is split
 // `nsplit` ways over blockIdx so that blockIdx % 8 (the XCD a block lands on)
 // selects the code split: each XCD's L2 only ever holds 1/8 of the codebook.
 // Codebook chunks of CT tiles are staged through LDS (double buffered,
-// register-staged 16-byte loads) and shared by the block's 4 waves.
+// register-staged 16-byte loads; the squares are formed once per chunk while
+// staging) and shared by the block's 4 waves.
 #pragma once
+#include <type_traits>
+
 #include "gq_common.h"
 
 namespace gqhip {
@@ -37,6 +41,9 @@ struct FilterParams {
   int rows, n;
   float beta;
   int nsplit, tiles_total, tiles_per_split;
+  WsHeader *hdr;        // block 0 initialises the workspace header
+  float absmax;         // caller-provided max|cb| (<= 0: a later kernel computes it)
+  void *dbg;            // diagnostic builds only
 };
 
 template <int HD>
@@ -53,73 +60,81 @@ __device__ __forceinline__ void lds_read_half(const float *p, float (&a)[HD]) {
   }
 }
 
-__device__ __forceinline__ float max16(const f32x16 &d) {
-  float t = __builtin_fmaxf(__builtin_fmaxf(d[0], d[1]), d[2]);
-  t = __builtin_fmaxf(__builtin_fmaxf(t, d[3]), d[4]);
-  t = __builtin_fmaxf(__builtin_fmaxf(t, d[5]), d[6]);
-  t = __builtin_fmaxf(__builtin_fmaxf(t, d[7]), d[8]);
-  t = __builtin_fmaxf(__builtin_fmaxf(t, d[9]), d[10]);
-  t = __builtin_fmaxf(__builtin_fmaxf(t, d[11]), d[12]);
-  t = __builtin_fmaxf(__builtin_fmaxf(t, d[13]), d[14]);
-  return __builtin_fmaxf(t, d[15]);
+// Running maximum over the 16 accumulators of a lane, seeded with t0: 8 v_max3.
+__device__ __forceinline__ float max_chain(float t0, const f32x16 &d) {
+  float t = __builtin_fmaxf(__builtin_fmaxf(t0, d[0]), d[1]);
+  t = __builtin_fmaxf(__builtin_fmaxf(t, d[2]), d[3]);
+  t = __builtin_fmaxf(__builtin_fmaxf(t, d[4]), d[5]);
+  t = __builtin_fmaxf(__builtin_fmaxf(t, d[6]), d[7]);
+  t = __builtin_fmaxf(__builtin_fmaxf(t, d[8]), d[9]);
+  t = __builtin_fmaxf(__builtin_fmaxf(t, d[10]), d[11]);
+  t = __builtin_fmaxf(__builtin_fmaxf(t, d[12]), d[13]);
+  return __builtin_fmaxf(__builtin_fmaxf(t, d[14]), d[15]);
 }
 
-// One 32-code tile against the wave's RT row tiles: RT independent MFMA chains
-// are issued first, the max/top-3 epilogues follow (chain rt+1 runs on the
-// matrix pipe while the VALU reduces chain rt).  MASKED handles the single
-// partial tile at the end of the codebook (codes >= n score -inf).
-template <int DIM, int RT, bool MASKED>
-__device__ __forceinline__ void tile_step(const float (&a)[DIM / 2], const float (&coefA)[RT][DIM / 2],
-                                          const float (&coefB)[RT][DIM / 2], int tile, int n, int h,
-                                          float (&m1)[RT], float (&m2)[RT], float (&m3)[RT],
-                                          int (&i1)[RT], int (&i2)[RT]) {
+// MFMA k-steps [S0, S1) of one 32-code tile against the wave's RT row tiles
+// (k-step s < HD multiplies the squares by A, s >= HD the values by B).  The RT
+// chains alternate in program order (A1 B1 A2 B2 ...) so a chain's next MFMA is
+// never issued back-to-back with its predecessor.
+template <int DIM, int RT, int S0, int S1>
+__device__ __forceinline__ void tile_mfma(const float (&a)[DIM / 2], const float (&a2)[DIM / 2],
+                                          const float (&coefA)[RT][DIM / 2],
+                                          const float (&coefB)[RT][DIM / 2], f32x16 (&d)[RT]) {
   constexpr int HD = DIM / 2;
-  float a2[HD];
+  if constexpr (S0 == 0) {
 #pragma unroll
-  for (int s = 0; s < HD; ++s) a2[s] = a[s] * a[s];
-  f32x16 d[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    d[rt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < HD; ++s)
-      d[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], coefA[rt][s], d[rt], 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < HD; ++s)
-      d[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], coefB[rt][s], d[rt], 0, 0, 0);
+    for (int rt = 0; rt < RT; ++rt)
+      d[rt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    if constexpr (MASKED) {
+  for (int s = S0; s < S1; ++s)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int code = tile * kTileCodes + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (code >= n) d[rt][r] = -__builtin_inff();
-      }
+    for (int rt = 0; rt < RT; ++rt) {
+      if (s < HD)
+        d[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], coefA[rt][s], d[rt], 0, 0, 0);
+      else
+        d[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s - HD], coefB[rt][s - HD], d[rt], 0, 0, 0);
     }
-    const float t = max16(d[rt]);
-    top3_insert(t, tile, m1[rt], m2[rt], m3[rt], i1[rt], i2[rt]);
-  }
 }
 
+// fp32 MFMA and VALU share the SIMD's fp32 datapath on gfx950 (measured: every VALU
+// instruction next to a v_mfma_f32_32x32x2_f32 stream costs ~4.4 matrix-pipe cycles,
+// tools/mfma_peak.hip), so the epilogue is kept to the minimum instruction count:
+// 8 v_max3 per 16-MFMA chain, and ONE top-3 update per PAIR of tiles (a candidate
+// "half-pair" = the 2 x 16 codes a lane saw in tiles 2p and 2p+1).  The main loop is
+// software pipelined so that nothing but those VALU instructions ever keeps the
+// matrix pipe waiting: the LDS operands of tile t+1 are fetched before the MFMAs of
+// tile t, and the epilogue of tile t-1 runs as ONE cluster right after the first
+// MFMAs of tile t (no wait for the accumulators to drain; each MFMA<->VALU switch
+// costs ~9 cycles, so the VALU work is clustered, not spread).
 template <int DIM, int RT, int CT, int MODE>
 __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p) {
   constexpr int HD = DIM / 2;                 // dims per lane half
   constexpr int TILE_F = kTileCodes * DIM;    // floats per 32-code tile
-  constexpr int CHUNK_F = CT * TILE_F;        // floats per LDS chunk
+  constexpr int CHUNK_F = CT * TILE_F;        // floats per LDS chunk (per array)
   constexpr int R4 = CHUNK_F / 4 / 256;       // 16-byte loads per thread per chunk
-  static_assert(R4 >= 1 && CHUNK_F % 1024 == 0, "chunk must be a multiple of 4 KiB");
-  __shared__ __attribute__((aligned(16))) float lds[2][CHUNK_F];
+  static_assert(R4 >= 1 && CHUNK_F % 1024 == 0 && CT % 2 == 0, "chunk: multiple of 4 KiB, even tile count");
+  // [buffer][0 = values, 1 = squares]
+  __shared__ __attribute__((aligned(16))) float lds[2][2][CHUNK_F];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int split = blockIdx.x % p.nsplit;
   const int rowblk = blockIdx.x / p.nsplit;
-  const int t_begin = split * p.tiles_per_split;
+  const int t_begin = split * p.tiles_per_split;          // even (tiles_per_split is even)
   const int t_end = min(t_begin + p.tiles_per_split, p.tiles_total);
-  const int t_full_end = min(t_end, p.n / kTileCodes);   // complete tiles only
-  const long cb_last4 = (long)p.n * DIM - 4;  // last valid 16-byte load offset (floats)
+  const int t_full_end = min(t_end, p.n / kTileCodes);    // complete tiles only
+  const long cb_last4 = (long)p.n * DIM - 4;              // last valid 16-byte load offset (floats)
+
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (blockIdx.x == 0 && tid == 0) {  // workspace header for the kernels that follow on the stream
+    p.hdr->fb_count = 0;
+    p.hdr->reranked = 0ull;
+    if (p.absmax > 0.f) p.hdr->absmax = p.absmax;
+  }
 
   // ---- row coefficients (B operands), fixed for the whole kernel ----------
   float coefA[RT][HD], coefB[RT][HD];
@@ -143,15 +158,15 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   }
 
   const float NEG_INF = -__builtin_inff();
-  float m1[RT], m2[RT], m3[RT];
+  float m1[RT], m2[RT], m3[RT], tpend[RT];
   int i1[RT], i2[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    m1[rt] = m2[rt] = m3[rt] = NEG_INF;
+    m1[rt] = m2[rt] = m3[rt] = tpend[rt] = NEG_INF;
     i1[rt] = i2[rt] = 0;
   }
 
-  // ---- chunk staging -------------------------------------------------------
+  // ---- chunk staging: global -> registers -> LDS (values and their squares) ----
   f32x4 stage[R4];
   auto load_chunk = [&](int tile0) {
     const long base = (long)tile0 * TILE_F;
@@ -164,8 +179,27 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < R4; ++r)
-      *reinterpret_cast<f32x4 *>(&lds[buf][(tid + 256 * r) * 4]) = stage[r];
+    for (int r = 0; r < R4; ++r) {
+      *reinterpret_cast<f32x4 *>(&lds[buf][0][(tid + 256 * r) * 4]) = stage[r];
+      *reinterpret_cast<f32x4 *>(&lds[buf][1][(tid + 256 * r) * 4]) = stage[r] * stage[r];
+    }
+  };
+  auto read_ops = [&](const float *val, const float *sq, float (&a)[HD], float (&a2)[HD]) {
+    lds_read_half<HD>(val, a);
+    lds_read_half<HD>(sq, a2);
+  };
+  auto close_pair = [&](int tile) {   // after the 2nd tile of a pair (or a lone last tile)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      top3_insert(tpend[rt], tile >> 1, m1[rt], m2[rt], m3[rt], i1[rt], i2[rt]);
+      tpend[rt] = NEG_INF;
+    }
+  };
+  // epilogue of a finished tile: fold its accumulators into the pending pair maximum
+  auto fold = [&](f32x16 (&d)[RT], int tile, bool odd) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) tpend[rt] = max_chain(tpend[rt], d[rt]);
+    if (odd) close_pair(tile);
   };
 
   const int ntiles = t_full_end - t_begin;
@@ -176,35 +210,115 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   }
   __syncthreads();
 
+  constexpr int S0 = 2;             // k-steps issued before the previous tile's epilogue
+  f32x16 dprev[RT];                 // accumulators of the previous tile, epilogue pending
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dprev[rt][r] = NEG_INF;   // neutral element
+  int tprev = t_begin - 1;          // odd -> its (no-op) epilogue closes an empty pair
+  bool have_prev = false;           // dprev holds a real tile whose epilogue is still pending
+
   for (int ch = 0; ch < nchunks; ++ch) {
     const int tile0 = t_begin + ch * CT;
     if (ch + 1 < nchunks) load_chunk(tile0 + CT);
     const int nt = min(CT, t_full_end - tile0);
-    const float *buf = lds[ch & 1] + c * DIM + h * HD;
-    for (int tt = 0; tt < nt; ++tt) {
-      float a[HD];
-      lds_read_half<HD>(buf + tt * TILE_F, a);
-      tile_step<DIM, RT, false>(a, coefA, coefB, tile0 + tt, p.n, h, m1, m2, m3, i1, i2);
+    const float *val = lds[ch & 1][0] + c * DIM + h * HD;
+    const float *sq = lds[ch & 1][1] + c * DIM + h * HD;
+    if (nt == CT) {
+      float a[HD], a2[HD];
+      read_ops(val, sq, a, a2);
+      // PREV_ODD: the tile whose epilogue runs in this step is the 2nd of its pair
+      // (tile0 is even, so that is static); LAST: no operand prefetch for a next tile.
+      auto step = [&](int tt, auto prev_odd, auto last) {
+        constexpr bool PREV_ODD = decltype(prev_odd)::value, LAST = decltype(last)::value;
+        float an[HD], a2n[HD];
+        if constexpr (!LAST) read_ops(val + (tt + 1) * TILE_F, sq + (tt + 1) * TILE_F, an, a2n);
+        f32x16 d[RT];
+        tile_mfma<DIM, RT, 0, S0>(a, a2, coefA, coefB, d);
+        fold(dprev, tprev, PREV_ODD);
+        tile_mfma<DIM, RT, S0, 2 * HD>(a, a2, coefA, coefB, d);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) dprev[rt] = d[rt];
+        tprev = tile0 + tt;
+        if constexpr (!LAST) {
+#pragma unroll
+          for (int s = 0; s < HD; ++s) { a[s] = an[s]; a2[s] = a2n[s]; }
+          __builtin_amdgcn_sched_group_barrier(0x100, HD >= 4 ? HD / 2 : 2, 0);
+        }
+        // pin the order: LDS reads | first MFMAs | ONE VALU cluster | remaining MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, S0 * RT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, RT * (PREV_ODD ? 18 : 9), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (2 * HD - S0) * RT, 0);
+      };
+      using T = std::true_type;
+      using F = std::false_type;
+#pragma unroll
+      for (int tt = 0; tt < CT - 2; tt += 2) {
+        step(tt, T{}, F{});
+        step(tt + 1, F{}, F{});
+      }
+      step(CT - 2, T{}, F{});
+      step(CT - 1, F{}, T{});
+      have_prev = true;
+    } else {
+      if (have_prev) fold(dprev, tprev, (tprev & 1) != 0);  // drain the pipeline, then plain tiles
+      have_prev = false;
+      for (int tt = 0; tt < nt; ++tt) {
+        float a[HD], a2[HD];
+        read_ops(val + tt * TILE_F, sq + tt * TILE_F, a, a2);
+        f32x16 d[RT];
+        tile_mfma<DIM, RT, 0, 2 * HD>(a, a2, coefA, coefB, d);
+        fold(d, tile0 + tt, (tt & 1) != 0);
+      }
     }
     if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
     __syncthreads();
   }
+  if (have_prev) fold(dprev, tprev, (tprev & 1) != 0);      // last pipelined tile
 
-  // ---- the one partial tile (n % 32 != 0), straight from global ------------
+  // ---- leftovers: a lone full tile and/or the one partial tile (n % 32 != 0) ----
+  const bool pending = ntiles > 0 && (ntiles & 1);   // tile t_full_end-1 opened a pair
   if (t_end > t_full_end) {
     const int tile = t_full_end;
     const int code = min(tile * kTileCodes + c, p.n - 1);
-    float a[HD];
+    float a[HD], a2[HD];
 #pragma unroll
-    for (int s = 0; s < HD; ++s) a[s] = p.cb[(long)code * DIM + h * HD + s];
-    tile_step<DIM, RT, true>(a, coefA, coefB, tile, p.n, h, m1, m2, m3, i1, i2);
+    for (int s = 0; s < HD; ++s) {
+      a[s] = p.cb[(long)code * DIM + h * HD + s];
+      a2[s] = a[s] * a[s];
+    }
+    f32x16 d[RT];
+    tile_mfma<DIM, RT, 0, 2 * HD>(a, a2, coefA, coefB, d);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = tile * kTileCodes + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (cc >= p.n) d[rt][r] = NEG_INF;
+      }
+      tpend[rt] = max_chain(tpend[rt], d[rt]);
+    }
+    close_pair(tile);
+  } else if (pending) {
+    close_pair(t_full_end - 1);
   }
 
+#ifdef GQHIP_CLOCK_STAMPS
+  if (tid == 0 && blockIdx.x < 2048) {   // diagnostic build only: per-block timeline + placement
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + 4 * blockIdx.x;
+    o[0] = st_r0;
+    o[1] = __builtin_amdgcn_s_memrealtime();
+    o[2] = __builtin_amdgcn_s_memtime() - st_c0;
+    o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+           (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
   // ---- merge the two lane halves of each row, write one record -------------
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt];
-    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h;
+    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h;   // half-pair ids
     const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32);
     const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32);
     top3_insert(b1, k1, a1, a2v, a3, j1, j2);

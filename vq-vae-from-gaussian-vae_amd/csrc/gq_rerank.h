@@ -8,9 +8,9 @@
 // every code j,  |filter(r,j) + const(r) - ref_score(r,j)| <= E(r), where E is
 // the rigorous rounding bound computed below from (mu, sd, max|cb|, dim).  The
 // reference's arg-max j* therefore satisfies filter(r,j*) >= max_j filter(r,j)
-// - 2E, i.e. it lies in a half-tile whose maximum is within `margin` = 2.5 E of
+// - 2E, i.e. it lies in a half-pair whose maximum is within `margin` = 2.5 E of
 // the row maximum.  The filter keeps, per (row, split), the best two such
-// half-tiles by id and the third by value; if the third is also within the
+// half-pairs by id and the third by value; if the third is also within the
 // margin (or the row has non-finite operands / bound) the row goes to the
 // exhaustive kernel instead.  Either way no approximation reaches the output.
 #pragma once
@@ -60,7 +60,7 @@ struct RerankParams {
   float beta;
   int nsplit;
   int all_rows;       // exhaustive kernel: process every row (no filter ran)
-  int stats;          // count re-ranked half-tiles (debug)
+  int stats;          // count re-ranked half-pairs (debug)
   OutMap omap;
 };
 
@@ -71,14 +71,52 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// Row operands shared by all lanes of the wave/block that scores one row:
+// mu, var2 = 2*(sd*sd), lsd = log sd  (GQ)  |  z (VQ).
+struct RowOps {
+  float mu[kMaxDim], var2[kMaxDim], lsd[kMaxDim];
+};
+
+__device__ __forceinline__ void load_row_ops(const RerankParams &p, long row, int i, RowOps &ro) {
+#pragma clang fp contract(off)
+  const float m = p.mu[row * p.dim + i];
+  ro.mu[i] = m;
+  if (p.sd) {
+    const float s = p.sd[row * p.dim + i];
+    ro.var2[i] = 2.0f * (s * s);
+    ro.lsd[i] = p.lsd ? p.lsd[row * p.dim + i] : (float)log((double)s);
+  }
+}
+
+// torch.sum(dim=2) order: 8 strided accumulators, left-to-right combine
+// (oracle/gq_oracle.c:gq_row_score).
+__device__ inline float ref_score_ops(const float *__restrict__ n, const RowOps &ro, int dim, float beta) {
+#pragma clang fp contract(off)
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    acc[k] = k < dim ? ref_term(n[k], ro.mu[k], ro.var2[k], ro.lsd[k], beta) : 0.0f;
+  for (int i0 = 8; i0 < dim; i0 += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k;
+      if (i < dim) acc[k] = acc[k] + ref_term(n[i], ro.mu[i], ro.var2[i], ro.lsd[i], beta);
+    }
+  }
+  float s = acc[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+    if (k < dim) s = s + acc[k];
+  return s;
+}
+
 template <int MODE>
-__device__ __forceinline__ double exact_score(const RerankParams &p, long row, int code) {
+__device__ __forceinline__ double exact_score(const RerankParams &p, const RowOps &ro, int code) {
   const float *n = p.cb + (long)code * p.dim;
   if constexpr (MODE == kModeGQ) {
-    const float *lsd = p.lsd ? p.lsd + row * p.dim : nullptr;
-    return (double)ref_score(n, p.mu + row * p.dim, p.sd + row * p.dim, lsd, p.dim, p.beta);
+    return (double)ref_score_ops(n, ro, p.dim, p.beta);
   } else {
-    return vq_neg_dist(n, p.mu + row * p.dim, p.dim);
+    return vq_neg_dist(n, ro.mu, p.dim);
   }
 }
 
@@ -99,6 +137,7 @@ __device__ __forceinline__ void write_result(const RerankParams &p, long row, in
 template <int MODE>
 __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   __shared__ int cand[4][2 * kMaxSplit];
+  __shared__ RowOps rops[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= p.rows) return;
@@ -158,22 +197,24 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   const int total = n1 + __popcll(b2);
   if (c1) cand[wave][__popcll(b1 & lt)] = r.id1;
   if (c2) cand[wave][n1 + __popcll(b2 & lt)] = r.id2;
+  if (lane < p.dim) load_row_ops(p, row, lane, rops[wave]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- exact scores of every code in the flagged half-tiles ---------------
+  // ---- exact scores of every code in the flagged half-pairs (32 codes each) ----
   double best_s = 0.0;
   int best_i = 0x7fffffff;
   bool have = false;
-  for (int g = 0; g * 4 < total; ++g) {
-    const int e = g * 4 + (lane >> 4);
+  for (int g = 0; g * 2 < total; ++g) {
+    const int e = g * 2 + (lane >> 5);
     if (e < total) {
       const int id = cand[wave][e];
-      const int rr = lane & 15;
-      const int code = (id >> 1) * kTileCodes + (rr & 3) + 8 * (rr >> 2) + 4 * (id & 1);
+      const int rr = lane & 31;
+      const int tile = (id >> 1) * 2 + (rr >> 4);
+      const int code = tile * kTileCodes + (rr & 3) + 8 * ((rr & 15) >> 2) + 4 * (id & 1);
       if (code < p.n) {
-        const double s = exact_score<MODE>(p, row, code);
+        const double s = exact_score<MODE>(p, rops[wave], code);
         if (!have || better_d(s, code, best_s, best_i)) {
           best_s = s;
           best_i = code;
@@ -204,15 +245,18 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gq_exhaustive_kernel(const RerankParams p) {
   __shared__ double sh_s[256];
   __shared__ int sh_i[256];
+  __shared__ RowOps rops;
   const int tid = threadIdx.x;
   const int count = p.all_rows ? p.rows : p.hdr->fb_count;
   for (int e = blockIdx.x; e < count; e += gridDim.x) {
     const long row = p.all_rows ? e : p.fb_list[e];
+    if (tid < p.dim) load_row_ops(p, row, tid, rops);
+    __syncthreads();
     double best_s = 0.0;
     int best_i = 0x7fffffff;
     bool have = false;
     for (int j = tid; j < p.n; j += 256) {
-      const double s = exact_score<MODE>(p, row, j);
+      const double s = exact_score<MODE>(p, rops, j);
       if (!have || better_d(s, j, best_s, best_i)) {
         best_s = s;
         best_i = j;

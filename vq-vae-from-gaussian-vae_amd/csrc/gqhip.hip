@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -43,17 +44,22 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   Plan pl{};
   pl.mfma = (dim == 4 || dim == 8 || dim == 16 || dim == 32) && n >= 1 && rows >= 1;
   pl.tiles_total = (int)((n + kTileCodes - 1) / kTileCodes);
+  static const int env_rt = getenv("GQHIP_RT") ? atoi(getenv("GQHIP_RT")) : 0;
+  static const int env_blocks = getenv("GQHIP_TARGET_BLOCKS") ? atoi(getenv("GQHIP_TARGET_BLOCKS")) : 0;
   pl.rt = rows >= 8192 ? 2 : 1;
+  if (env_rt == 1 || env_rt == 2) pl.rt = env_rt;
   pl.rows_per_block = 128 * pl.rt;
   pl.row_blocks = (int)((rows + pl.rows_per_block - 1) / pl.rows_per_block);
   // ~2 blocks per CU on 256 CUs; splits in multiples of 8 so that
   // blockIdx % 8 (XCD) == split % 8.
-  int s = (512 + pl.row_blocks - 1) / (pl.row_blocks > 0 ? pl.row_blocks : 1);
+  const int target = env_blocks > 0 ? env_blocks : 512;
+  int s = (target + pl.row_blocks - 1) / (pl.row_blocks > 0 ? pl.row_blocks : 1);
   s = ((s + 7) / 8) * 8;
   if (s > kMaxSplit) s = kMaxSplit;
   if (s > pl.tiles_total) s = pl.tiles_total;
   if (s < 1) s = 1;
   pl.tiles_per_split = (pl.tiles_total + s - 1) / s;
+  pl.tiles_per_split += pl.tiles_per_split & 1;   // even: a tile pair never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   return pl;
 }
@@ -68,7 +74,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   const Plan pl = make_plan(rows, n, dim);
   WsLayout w{};
   int64_t off = 0;
-  w.hdr = off; off += 256;
+  w.hdr = off; off += (int64_t)sizeof(WsHeader);
   w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit : 0));
   w.fb = off;  off += align256(4 * rows);
   w.mu = off;  off += align256(4 * rows * dim);
@@ -148,13 +154,13 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
   WsHeader *hdr = reinterpret_cast<WsHeader *>(ws + w.hdr);
   const Plan pl = make_plan(rows, n, dim);
 
-  hipLaunchKernelGGL(ws_init_kernel, dim3(1), dim3(64), 0, st, hdr, cb_absmax > 0.f ? cb_absmax : 0.f);
-  if (!(cb_absmax > 0.f)) {
+  auto launch_absmax = [&]() {
     const long count = (long)n * dim;
     const int blocks = (int)((count + 256 * 16 - 1) / (256 * 16));
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(256), 0,
                        st, cb, count, &hdr->absmax);
-  }
+  };
+  const bool need_absmax = !(cb_absmax > 0.f);
 
   RerankParams rp{};
   rp.mu = mu; rp.sd = sd; rp.lsd = lsd; rp.cb = cb;
@@ -171,13 +177,19 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
     fp.rec = reinterpret_cast<Rec *>(ws + w.rec);
     fp.rows = (int)rows; fp.n = (int)n; fp.beta = (float)beta;
     fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
+    fp.hdr = hdr; fp.absmax = cb_absmax;
+    fp.dbg = ws + w.mu;   // scratch rows area (unused by gq_argmax_f32); read by diagnostic builds only
+    if (need_absmax && hipMemsetAsync(&hdr->absmax, 0, sizeof(float), st) != hipSuccess) return check_launch();
     int rc = launch_filter<MODE>(pl, fp, (int)dim, st);
     if (rc != GQHIP_OK) return rc;
+    if (need_absmax) launch_absmax();   // after the filter (it owns the header init), before the re-rank
     hipLaunchKernelGGL((gq_rerank_kernel<MODE>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rp);
     rc = check_launch();
     if (rc != GQHIP_OK) return rc;
   }
-  const int ex_blocks = (int)(rows < 2048 ? rows : 2048);
+  if (!pl.mfma && hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
+  const int ex_cap = pl.mfma ? 256 : 4096;
+  const int ex_blocks = (int)(rows < ex_cap ? rows : ex_cap);
   hipLaunchKernelGGL((gq_exhaustive_kernel<MODE>), dim3((unsigned)ex_blocks), dim3(256), 0, st, rp);
   return check_launch();
 }

@@ -15,7 +15,7 @@ from typing import Optional, Tuple
 import torch
 
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
-LIB_PATH = os.path.join(_CSRC, "libgqhip.so")
+LIB_PATH = os.environ.get("GQHIP_LIB", os.path.join(_CSRC, "libgqhip.so"))  # GQHIP_LIB: diagnostic builds
 
 GQHIP_LAYOUT = {"bchw": 0, "blc": 1}
 GQHIP_GROUP_STRIDED = 0
