@@ -305,6 +305,36 @@ for n, w, bs in ((37, 2, 4), (64, 8, 4), (100, 8, 16), (17, 4, 2), (5, 8, 1), (2
     g8.append({"n": n, "world": w, "bs": bs, "per_rank": per_rank})
 meta["cases"]["G8"] = g8
 
+# ---------------------------------------------------------------- G9 train-mode branch
+print("G9 train-mode branch")
+from pit_hip.quantization.gaussian import GaussianQuantRegularizer as MyGQ  # noqa: E402
+from pit_hip.quantization.gaussian import GaussianQuantRegularizer2 as MyGQ2  # noqa: E402
+
+g9 = {}
+zt = realistic_z(16, 2, 8, 8, seed=9) * 1.7
+for tag, ref_m, my_m in (("gq1", RefGQ("bchw", 1024, group=16, backend="torch"), MyGQ("bchw", 1024, group=16)),
+                         ("gq2", RefGQ2(4, 1024, backend="torch"), MyGQ2(4, 1024))):
+    steps = []
+    outs = []
+    for m in (ref_m, my_m):
+        m.train()
+        torch.manual_seed(123)
+        rec = []
+        for it in range(3):
+            if tag == "gq1":
+                zh, info = m(zt + 0.1 * it)
+            else:
+                zh, info = m.quant_gaussian(zt + 0.1 * it)
+            rec.append({"kl_loss": float(info["kl_loss"]), "bits_mean": float(info["bits-mean"]),
+                        "bits_min": float(info["bits-min"]), "bits_max": float(info["bits-max"]),
+                        "lam": float(m.lam), "lam_min": float(m.lam_min), "lam_max": float(m.lam_max),
+                        "zhat_sha": sha(zh.numpy())})
+        outs.append(rec)
+    assert outs[0] == outs[1], f"train branch of {tag} differs from the reference"
+    g9[tag] = outs[0]
+np.savez_compressed(os.path.join(HERE, "g9_train_z.npz"), z=zt.numpy())
+meta["cases"]["G9"] = g9
+
 with open(os.path.join(HERE, "meta.json"), "w") as f:
     json.dump(meta, f, indent=1)
 print("meta.json written; all oracle-vs-reference checks passed")

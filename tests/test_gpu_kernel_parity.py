@@ -119,3 +119,58 @@ def test_compat_scores_op_matches_cuda_formula():
         ridx, _, best, second = O.argmax_rows(mu.numpy(), sd.numpy(), cb, 1.0, with_gap=True)
         clear = (best - second) > 1e-3
         assert np.array_equal(got.argmax(1)[clear], ridx[clear])
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 at full size (16 384 rows x 65 536 codes), size-independent properties:
+    row-permutation equivariance, determinism, dequant round trip, idempotence of re-quantising
+    the chosen codeword, and a checksum-of-indices agreement between the two entry points."""
+    from pit_hip import _lib
+
+    dim, n, rows = 16, 65536, 16384
+    dev = torch.device("cuda:0")
+    cb = torch.from_numpy(O.codebook(n, dim, 42)).to(dev)
+    mu, sd = _inputs(rows, dim, seed=0)
+    mu, sd = mu.to(dev), sd.to(dev)
+    lsd = sd.log()
+    idx, zhat = _lib.gq_argmax(mu, sd, cb, 1.0, logsd=lsd)
+    idx2, _ = _lib.gq_argmax(mu, sd, cb, 1.0, logsd=lsd)
+    assert torch.equal(idx, idx2)                                   # deterministic
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(1)).to(dev)
+    idx_p, _ = _lib.gq_argmax(mu[perm].contiguous(), sd[perm].contiguous(), cb, 1.0, logsd=lsd[perm].contiguous())
+    assert torch.equal(idx_p, idx[perm])                            # rows are independent
+    assert torch.equal(zhat, cb[idx])                               # gather round trip
+    # a row centred on a codeword with a tiny sigma must select that codeword (or an exact duplicate)
+    tiny = torch.full_like(sd, 1e-3)
+    idx_c, _ = _lib.gq_argmax(zhat.contiguous(), tiny, cb, 1.0)
+    assert torch.equal(cb[idx_c], zhat)
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    assert idx.unique().numel() > 0.2 * rows                        # codebook usage is broad, not collapsed
+
+
+@pytest.mark.parametrize("cfg,c,group,rows_expected", [("gq_1.00", 16, 4, 65536), ("gq_0.50", 16, 8, 32768)])
+def test_config4_group_sweep_full_batch(cfg, c, group, rows_expected):
+    """BASELINE config 4: sd3unet_gq_1.00 (dim 4, K=4) / gq_0.50 (dim 8, K=2) at bs=16, 256x256:
+    module path at full size; oracle on a strided sample of the rows the kernels derived."""
+    from pit_hip import _lib
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    z = torch.cat([0.9 * torch.randn(16, c, 32, 32, generator=g), -1.5 + 0.3 * torch.randn(16, c, 32, 32, generator=g)], 1)
+    cbn = O.codebook(65536, group, 42)
+    cb = torch.from_numpy(cbn).to(dev)
+    idx, zhat, mu_r, sd_r = _lib.gq_quantize_z(z.to(dev), cb, group, "bchw", _lib.GQHIP_GROUP_STRIDED,
+                                               return_operands=True)
+    K = c // group
+    assert idx.shape == (16, K, 32, 32) and mu_r.shape[0] == rows_expected
+    rows_idx = idx.permute(0, 2, 3, 1).reshape(-1).cpu().numpy()
+    sel = np.arange(0, rows_expected, 64)
+    sdn = sd_r.cpu().numpy()
+    lsd = np.log(sdn.astype(np.float64)).astype(np.float32)
+    oi, _ = O.argmax_rows(mu_r.cpu().numpy()[sel], sdn[sel], cbn, 1.0, logstd=lsd[sel])
+    assert np.array_equal(rows_idx[sel], oi)
+    # layout: the operands are the strided-channel gather of gaussian.py:122-123
+    zf = z.reshape(16, 2 * c, 1024).permute(0, 2, 1)
+    mu_ref = zf[:, :, :c].reshape(16, 1024, group, K).permute(0, 1, 3, 2).reshape(-1, group)
+    assert torch.equal(mu_r.cpu(), mu_ref)
+    assert torch.equal(_lib.gq_dequant(idx, cb, group, "bchw", _lib.GQHIP_GROUP_STRIDED), zhat)

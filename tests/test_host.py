@@ -152,3 +152,26 @@ def test_cpu_plumbing_config0_single_image_encode_indices_decode():
     assert float(np.abs(xr.numpy() - d["x_rec"].astype(np.float32)).max()) < 5e-3  # fp16-stored golden
     st = d["x_rec_stats"]
     assert abs(float(xr.mean()) - st[0]) < 1e-4 and abs(float(xr.std()) - st[1]) < 1e-4
+
+
+def test_train_mode_branch_matches_reference_goldens():
+    """train() branch (reparameterised sample, KL-to-log2(N) loss, adaptive
+    lambda state machine, incl. GQ2's no-op lam_max decrease) -- pure torch, bit-identical on CPU."""
+    import hashlib
+
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer, GaussianQuantRegularizer2
+
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    z = torch.from_numpy(np.load(os.path.join(G, "g9_train_z.npz"))["z"])
+    for tag, m in (("gq1", GaussianQuantRegularizer("bchw", 1024, group=16)),
+                   ("gq2", GaussianQuantRegularizer2(4, 1024))):
+        m.train()
+        torch.manual_seed(123)
+        for it, want in enumerate(META["cases"]["G9"][tag]):
+            zh, info = m(z + 0.1 * it) if tag == "gq1" else m.quant_gaussian(z + 0.1 * it)
+            got = {"kl_loss": float(info["kl_loss"]), "bits_mean": float(info["bits-mean"]),
+                   "bits_min": float(info["bits-min"]), "bits_max": float(info["bits-max"]),
+                   "lam": float(m.lam), "lam_min": float(m.lam_min), "lam_max": float(m.lam_max),
+                   "zhat_sha": sha(zh.detach().numpy())}
+            assert got == want, (tag, it)
+    assert set(info) >= {"kl_loss", "bits-mean", "bits-min", "bits-max", "lam"}
