@@ -24,7 +24,8 @@
  *   gq_dequant_f32   pit/quantization/gaussian.py:162-178, :347-362.
  *   vq_argmin_f32    pit/quantization/vq.py:58-73.
  *   lfq_pack_f32     pit/quantization/lfq.py:147-158.
- *   lfq_unpack_f32   pit/quantization/lfq.py:210-228.
+ *   lfq_unpack_f32   pit/quantization/lfq.py:210-228 (also BSQ: pit/quantization/bsq.py:85-156).
+ *   fsq_quantize_f32 / fsq_dequant_f32  pit/quantization/fsq.py:29-89.
  *   gq_index_histogram eval.py:127,137-141,152-154 (stubbed-out histogram).
  */
 #ifndef GQHIP_H_
@@ -124,6 +125,14 @@ int lfq_pack_f32(const float *x, int64_t *idx, float *q_or_null, int64_t rows,
                  int64_t nbits, void *stream);
 int lfq_unpack_f32(const int64_t *idx, float *q, int64_t rows, int64_t nbits,
                    void *stream);
+
+/* ---- FSQ: tanh-bounded rounding + mixed-radix pack (pit/quantization/fsq.py:29-89) ----
+ * z, zhat [rows, nlev] fp32; idx [rows] int32 (the reference's dtype); levels_host: nlev (<= 16)
+ * positive ints on the HOST.  tanh/atanh are evaluated in fp64 and rounded once. */
+int fsq_quantize_f32(const float *z, const int32_t *levels_host, int64_t nlev, float *zhat,
+                     int32_t *idx, int64_t rows, void *stream);
+int fsq_dequant_f32(const int32_t *idx, const int32_t *levels_host, int64_t nlev, float *zhat,
+                    int64_t rows, void *stream);
 
 /* ---- index wire format / usage histogram ----------------------------------- */
 int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n,

@@ -12,6 +12,8 @@ Reference lines restated (paths relative to /root/reference):
   GaussianQuantRegularizer2   pit/quantization/gaussian.py:273-362 (quant_vq, dequant)
   VQQuantizer                 pit/quantization/vq.py:39-129
   LFQQuantizer                pit/quantization/lfq.py:127-228
+  BSQQuantizer                pit/quantization/bsq.py:64-156
+  FSQQuantizer                pit/quantization/fsq.py:29-89
 
 The inner (row x code) arithmetic lives in ``gq_oracle.c``; this file holds the
 layout glue (numpy) and the two transcendental calls the reference makes
@@ -344,6 +346,89 @@ def lfq_dequant(indices: np.ndarray, nbits: int = 16, fmt: str = "bchw") -> np.n
         # "b (h w) c n -> b (c n) h w"
         q = q.reshape(b, h, w, ng, nbits).transpose(0, 3, 4, 1, 2).reshape(b, ng * nbits, h, w)
     return np.ascontiguousarray(q)
+
+
+# --------------------------------------------------------------------------- f3: BSQ / FSQ
+def bsq_forward(x: np.ndarray, num_codebooks: int = 16, codebook_dim: int = 1, fmt: str = "bchw"):
+    """BSQQuantizer.forward eval values (bsq.py:64-131): F.normalize -> sign -> 16-bit pack over the
+    codebook axis, output scaled by 1/sqrt(embed_dim).  torch-CPU ops for the normalisation."""
+    import torch
+    import torch.nn.functional as F
+
+    xt = torch.from_numpy(_f32(x))
+    if fmt == "bchw":
+        b, c, h, w = xt.shape
+        xt = xt.reshape(b, c, h * w).permute(0, 2, 1)
+    else:
+        b, _, c = xt.shape
+    l = xt.shape[1]
+    xn = F.normalize(xt, dim=-1).reshape(b, l, num_codebooks, codebook_dim)
+    q = torch.where(xn > 0, torch.tensor(1.0), torch.tensor(-1.0))
+    bits = ((q + 1.0) / 2.0).to(torch.long)
+    idx = torch.zeros_like(bits[:, :, 0, :])
+    for i in range(16):
+        idx = idx * 2 + bits[:, :, i, :]
+    out = (xn + (q - xn)) * (1.0 / (num_codebooks * codebook_dim) ** 0.5)
+    out = out.reshape(b, l, c)
+    if fmt == "bchw":
+        out = out.permute(0, 2, 1).reshape(b, c, h, w)
+        idx = idx.permute(0, 2, 1).reshape(b, codebook_dim, h, w)
+    return np.ascontiguousarray(out.numpy()), np.ascontiguousarray(idx.numpy())
+
+
+def bsq_dequant(indices: np.ndarray, embed_dim: int = 16, fmt: str = "bchw") -> np.ndarray:
+    """BSQQuantizer.dequant (bsq.py:133-156)."""
+    return lfq_dequant(indices, 16, fmt) * np.float32(1.0 / embed_dim ** 0.5)
+
+
+def fsq_forward(z: np.ndarray, levels, fmt: str = "bchw", with_margin: bool = False):
+    """FSQQuantizer.forward (fsq.py:29-68) with torch-CPU tanh/atanh.  Returns (zhat, packed int32
+    indices[, distance of the bounded value to the nearest rounding boundary])."""
+    import torch
+
+    zt = torch.from_numpy(_f32(z))
+    if fmt == "bchw":
+        b, c, h, w = zt.shape
+        zt = zt.reshape(b, c, h * w).permute(0, 2, 1)
+    else:
+        b, _, c = zt.shape
+    lev = torch.tensor(list(levels), dtype=torch.int32)
+    half_l = (lev - 1) * (1 + 1e-3) / 2
+    offset = torch.where(lev % 2 == 0, 0.5, 0.0)
+    shift = (offset / half_l).atanh()
+    bounded = (zt + shift).tanh() * half_l - offset
+    half_width = lev // 2
+    r = bounded.round()
+    zhat = r / half_width
+    ind = (r + half_width).to(torch.int32)
+    packed = torch.zeros_like(ind[:, :, 0:1])
+    for i in range(len(levels)):
+        packed = packed * lev[i] + ind[:, :, i:i + 1]
+    margin = (0.5 - (bounded - bounded.floor() - 0.5).abs()).amin(dim=-1, keepdim=True)
+    if fmt == "bchw":
+        zhat = zhat.permute(0, 2, 1).reshape(b, c, h, w)
+        packed = packed.permute(0, 2, 1).reshape(b, 1, h, w)
+        margin = margin.permute(0, 2, 1).reshape(b, 1, h, w)
+    out = (np.ascontiguousarray(zhat.numpy()), np.ascontiguousarray(packed.numpy()))
+    return out + (np.ascontiguousarray(margin.numpy()),) if with_margin else out
+
+
+def fsq_dequant(indices: np.ndarray, levels, fmt: str = "bchw") -> np.ndarray:
+    """FSQQuantizer.dequant (fsq.py:70-89)."""
+    ind = np.asarray(indices).astype(np.int64)
+    if fmt == "bchw":
+        b, _, h, w = ind.shape
+        ind = ind.reshape(b, 1, h * w).transpose(0, 2, 1)
+    digits = []
+    for lv in reversed(list(levels)):
+        digits.append(ind % lv)
+        ind = ind // lv
+    d = np.concatenate(digits[::-1], axis=2)
+    hw = (np.asarray(list(levels)) // 2).astype(np.int64)
+    zhat = ((d - hw).astype(np.float32) / hw.astype(np.float32)).astype(np.float32)
+    if fmt == "bchw":
+        zhat = zhat.transpose(0, 2, 1).reshape(b, len(levels), h, w)
+    return np.ascontiguousarray(zhat)
 
 
 # --------------------------------------------------------------------------- a12 (index logic only)

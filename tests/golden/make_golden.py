@@ -305,6 +305,32 @@ for n, w, bs in ((37, 2, 4), (64, 8, 4), (100, 8, 16), (17, 4, 2), (5, 8, 1), (2
     g8.append({"n": n, "world": w, "bs": bs, "per_rank": per_rank})
 meta["cases"]["G8"] = g8
 
+# ---------------------------------------------------------------- G10 BSQ / FSQ
+print("G10 BSQ / FSQ")
+from pit.quantization.bsq import BSQQuantizer as RefBSQ  # noqa: E402
+from pit.quantization.fsq import FSQQuantizer as RefFSQ  # noqa: E402
+
+gq10 = torch.Generator().manual_seed(110)
+xb = torch.randn(2, 16, 8, 8, generator=gq10)
+xb[0, :, 0, 0] = 0.0
+bsq = RefBSQ("bchw", codebook_size=2, num_codebooks=16).eval()
+qb, ib = bsq(xb)
+oq, oi = O.bsq_forward(xb.numpy())
+assert np.array_equal(oi, ib["indices"].numpy()) and np.array_equal(oq, qb.numpy())
+assert np.array_equal(O.bsq_dequant(oi), bsq.dequant(ib["indices"]).numpy())
+save("g10_bsq.npz", x=xb.numpy(), indices=ib["indices"].numpy().astype(np.int32), q=qb.numpy(),
+     deq=bsq.dequant(ib["indices"]).numpy())
+LEVELS = [8, 8, 8, 5, 5, 5]
+xf = torch.randn(2, 6, 8, 8, generator=gq10) * 1.5
+fsq = RefFSQ(LEVELS, "bchw").eval()
+qf, inf_ = fsq(xf)
+ozf, oif, marg = O.fsq_forward(xf.numpy(), LEVELS, with_margin=True)
+assert np.array_equal(oif, inf_["indices"].numpy()) and np.array_equal(ozf, qf.numpy())
+assert np.array_equal(O.fsq_dequant(oif, LEVELS), fsq.dequant(inf_["indices"]).numpy())
+assert np.allclose(fsq.dequant(inf_["indices"]).numpy(), qf.numpy())
+save("g10_fsq.npz", x=xf.numpy(), indices=inf_["indices"].numpy(), zhat=qf.numpy(), margin=marg,
+     levels=np.array(LEVELS, np.int32))
+
 # ---------------------------------------------------------------- G9 train-mode branch
 print("G9 train-mode branch")
 from pit_hip.quantization.gaussian import GaussianQuantRegularizer as MyGQ  # noqa: E402

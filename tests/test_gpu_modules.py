@@ -258,3 +258,32 @@ def test_smoke_entry():
     import __graft_entry__ as ge
 
     ge.smoke()
+
+
+def test_g10_bsq_and_fsq_modules():
+    """BSQ / FSQ eval + dequant through the same boundary."""
+    from pit_hip.quantization.bsq import BSQQuantizer
+    from pit_hip.quantization.fsq import FSQQuantizer
+
+    d = load("g10_bsq.npz")
+    bsq = BSQQuantizer("bchw", codebook_size=2, num_codebooks=16).eval().to(DEV)
+    q, info = bsq(torch.from_numpy(d["x"]).to(DEV))
+    assert np.array_equal(info["indices"].cpu().numpy(), d["indices"])
+    np.testing.assert_allclose(q.cpu().numpy(), d["q"], atol=1e-6)      # F.normalize on device: fp32 rounding
+    assert np.array_equal(bsq.dequant(info["indices"]).cpu().numpy(), d["deq"])
+    assert info["indices"].shape == (2, 1, 8, 8) and info["indices"].dtype == torch.int64
+
+    d = load("g10_fsq.npz")
+    levels = d["levels"].tolist()
+    fsq = FSQQuantizer(levels, "bchw").eval().to(DEV)
+    zhat, info = fsq(torch.from_numpy(d["x"]).to(DEV))
+    got = info["indices"].cpu().numpy()
+    assert got.dtype == np.int32 and got.shape == d["indices"].shape
+    # tanh/atanh are libm specific: an index may differ only where the bounded value sits on a
+    # rounding boundary (|distance| < 1e-5); everywhere else bit-equal.
+    diff = got != d["indices"]
+    assert np.all(d["margin"][diff] < 1e-5) and diff.mean() < 0.01
+    same = ~np.broadcast_to(diff, d["zhat"].shape[:1] + (1,) + d["zhat"].shape[2:]).repeat(len(levels), 1)
+    assert np.array_equal(zhat.cpu().numpy()[same], d["zhat"][same])
+    assert np.array_equal(fsq.dequant(info["indices"]).cpu().numpy(), O.fsq_dequant(got, levels))
+    assert float(info["bits"]) == float(np.sum(np.log2(levels)) * 6 * 64)

@@ -142,3 +142,14 @@ def test_cuda_formula_equals_twice_the_torch_score_up_to_row_constant():
     diff = a - 2 * b
     assert np.all(np.abs(diff - diff[:, :1]) < 2e-3)  # out = 2*s + const(r)
     assert np.array_equal(a.argmax(1), b.argmax(1))
+
+
+def test_g10_bsq_fsq():
+    d = load("g10_bsq.npz")
+    q, ind = O.bsq_forward(d["x"])
+    assert np.array_equal(ind, d["indices"]) and np.array_equal(q, d["q"])
+    assert np.array_equal(O.bsq_dequant(ind), d["deq"])
+    d = load("g10_fsq.npz")
+    zhat, ind, margin = O.fsq_forward(d["x"], d["levels"].tolist(), with_margin=True)
+    assert np.array_equal(ind, d["indices"]) and np.array_equal(zhat, d["zhat"])
+    assert np.array_equal(O.fsq_dequant(ind, d["levels"].tolist()), d["zhat"])

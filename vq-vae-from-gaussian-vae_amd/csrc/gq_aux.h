@@ -183,6 +183,48 @@ __global__ __launch_bounds__(256) void lfq_unpack_kernel(const int64_t *__restri
   q[t] = ((v >> (nbits - 1 - i)) & 1) ? 1.0f : -1.0f;
 }
 
+// ---- FSQ (fsq.py:29-89) ------------------------------------------------------
+struct FsqLevels {
+  int n;
+  int lev[16];
+};
+
+__global__ __launch_bounds__(256) void fsq_quantize_kernel(const float *__restrict__ z, FsqLevels L,
+                                                           float *__restrict__ zhat,
+                                                           int32_t *__restrict__ idx, long rows) {
+#pragma clang fp contract(off)
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  int packed = 0;
+  for (int l = 0; l < L.n; ++l) {
+    const int lv = L.lev[l];
+    const float half_l = (float)(lv - 1) * (1.0f + 1e-3f) / 2.0f;          // (levels-1)*(1+eps)/2
+    const float offset = (lv % 2 == 0) ? 0.5f : 0.0f;
+    const float shift = (float)atanh((double)(offset / half_l));
+    const float x = z[r * L.n + l] + shift;
+    const float b = (float)tanh((double)x) * half_l - offset;
+    const float q = rintf(b);                                              // torch.round: half to even
+    const int hw = lv / 2;
+    if (zhat) zhat[r * L.n + l] = q / (float)hw;
+    packed = packed * lv + (int)(q + (float)hw);
+  }
+  idx[r] = packed;
+}
+
+__global__ __launch_bounds__(256) void fsq_dequant_kernel(const int32_t *__restrict__ idx, FsqLevels L,
+                                                          float *__restrict__ zhat, long rows) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  int v = idx[r];
+  for (int l = L.n - 1; l >= 0; --l) {
+    const int lv = L.lev[l];
+    const int d = v % lv;
+    v /= lv;
+    const int hw = lv / 2;
+    zhat[r * L.n + l] = (float)(d - hw) / (float)hw;
+  }
+}
+
 // ---- index histogram + u16 wire format (eval.py:127,137-141,152-154) --------
 __global__ __launch_bounds__(256) void hist_kernel(const int64_t *__restrict__ idx, long count, int n,
                                                    int *__restrict__ hist) {

@@ -339,6 +339,40 @@ int lfq_unpack_f32(const int64_t *idx, float *q, int64_t rows, int64_t nbits, vo
   return check_launch();
 }
 
+static int fsq_levels(const int32_t *levels_host, int64_t nlev, FsqLevels *L) {
+  if (!levels_host || nlev < 1 || nlev > 16) return GQHIP_ERR_INVALID_ARG;
+  L->n = (int)nlev;
+  long prod = 1;
+  for (int i = 0; i < 16; ++i) L->lev[i] = 1;
+  for (int i = 0; i < nlev; ++i) {
+    if (levels_host[i] < 2) return GQHIP_ERR_INVALID_ARG;
+    L->lev[i] = levels_host[i];
+    prod *= levels_host[i];
+    if (prod > 0x7fffffffL) return GQHIP_ERR_INVALID_ARG;   // the packed index is an int32
+  }
+  return GQHIP_OK;
+}
+
+int fsq_quantize_f32(const float *z, const int32_t *levels_host, int64_t nlev, float *zhat, int32_t *idx,
+                     int64_t rows, void *stream) {
+  FsqLevels L;
+  if (!z || !idx || rows < 0 || fsq_levels(levels_host, nlev, &L) != GQHIP_OK) return GQHIP_ERR_INVALID_ARG;
+  if (rows == 0) return GQHIP_OK;
+  hipLaunchKernelGGL(fsq_quantize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), z, L, zhat, idx, (long)rows);
+  return check_launch();
+}
+
+int fsq_dequant_f32(const int32_t *idx, const int32_t *levels_host, int64_t nlev, float *zhat, int64_t rows,
+                    void *stream) {
+  FsqLevels L;
+  if (!idx || !zhat || rows < 0 || fsq_levels(levels_host, nlev, &L) != GQHIP_OK) return GQHIP_ERR_INVALID_ARG;
+  if (rows == 0) return GQHIP_OK;
+  hipLaunchKernelGGL(fsq_dequant_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), idx, L, zhat, (long)rows);
+  return check_launch();
+}
+
 int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n, int32_t *hist, void *stream) {
   if (!idx || !hist || count < 0 || n < 1) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "vq_argmin_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _i64, _vp]),
     "lfq_pack_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "lfq_unpack_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "fsq_quantize_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _vp, _i64, _vp]),
+    "fsq_dequant_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _i64, _vp]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "gq_indices_from_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -248,6 +250,35 @@ def lfq_unpack(idx, nbits: int):
     with torch.cuda.device(idx.device):
         _check(lib().lfq_unpack_f32(idx.data_ptr(), q.data_ptr(), rows, nbits, _stream()), "lfq_unpack_f32")
     return q
+
+
+def _levels(levels):
+    arr = (ctypes.c_int32 * len(levels))(*[int(v) for v in levels])
+    return arr, len(levels)
+
+
+def fsq_quantize(z, levels):
+    """z [rows, nlev] -> (zhat [rows, nlev] fp32, packed indices [rows] int32)."""
+    z = _dev(z, torch.float32, "z")
+    rows, nlev = z.shape
+    arr, n = _levels(levels)
+    assert n == nlev
+    zhat = torch.empty_like(z)
+    idx = torch.empty(rows, dtype=torch.int32, device=z.device)
+    with torch.cuda.device(z.device):
+        _check(lib().fsq_quantize_f32(z.data_ptr(), arr, n, zhat.data_ptr(), idx.data_ptr(), rows, _stream()),
+               "fsq_quantize_f32")
+    return zhat, idx
+
+
+def fsq_dequant(idx, levels):
+    idx = _dev(idx, torch.int32, "indices")
+    arr, n = _levels(levels)
+    rows = idx.numel()
+    zhat = torch.empty(rows, n, dtype=torch.float32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _check(lib().fsq_dequant_f32(idx.data_ptr(), arr, n, zhat.data_ptr(), rows, _stream()), "fsq_dequant_f32")
+    return zhat
 
 
 def index_histogram(idx, n: int):
