@@ -26,6 +26,7 @@
  *   lfq_pack_f32     pit/quantization/lfq.py:147-158.
  *   lfq_unpack_f32   pit/quantization/lfq.py:210-228 (also BSQ: pit/quantization/bsq.py:85-156).
  *   fsq_quantize_f32 / fsq_dequant_f32  pit/quantization/fsq.py:29-89.
+ *   gn_silu_f32      pit/modules/unet.py:49-57 (Normalize + nonlinearity pairs).
  *   gq_index_histogram eval.py:127,137-141,152-154 (stubbed-out histogram).
  */
 #ifndef GQHIP_H_
@@ -133,6 +134,16 @@ int fsq_quantize_f32(const float *z, const int32_t *levels_host, int64_t nlev, f
                      int32_t *idx, int64_t rows, void *stream);
 int fsq_dequant_f32(const int32_t *idx, const int32_t *levels_host, int64_t nlev, float *zhat,
                     int64_t rows, void *stream);
+
+/* ---- fused GroupNorm (+ SiLU) for the conv stack -----------------------------------
+ * y = act( (x - mean_g) * rstd_g * gamma_c + beta_c ), act = SiLU when apply_silu != 0.
+ * Replaces the GroupNorm -> swish pairs of pit/modules/unet.py:54-57,49-51,137-153,432-435
+ * (three PyTorch kernels, five HBM passes) by a stats pass + one apply pass (three passes).
+ * x, y [B, C, HW] fp32 contiguous (NCHW), groups | C; stats_ws: 2*B*groups doubles of
+ * caller scratch.  x and y may alias. */
+int gn_silu_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B,
+                int64_t C, int64_t HW, int64_t groups, double eps, int apply_silu,
+                double *stats_ws, void *stream);
 
 /* ---- index wire format / usage histogram ----------------------------------- */
 int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n,

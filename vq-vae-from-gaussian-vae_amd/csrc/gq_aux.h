@@ -225,6 +225,72 @@ __global__ __launch_bounds__(256) void fsq_dequant_kernel(const int32_t *__restr
   }
 }
 
+// ---- fused GroupNorm (+SiLU), NCHW fp32 --------------------------------------------
+// stats: each block reduces a contiguous slice of one (b, g) chunk; fp32 per-thread partials,
+// fp64 across threads/blocks (two atomics per block).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, double *__restrict__ stats,
+                                                       long chunk, int slices) {
+  const long bg = blockIdx.x / slices;
+  const int sl = blockIdx.x % slices;
+  const long per = ((chunk / 4 + slices - 1) / slices) * 4;      // floats per slice (multiple of 4)
+  const long lo = sl * per, hi = lo + per < chunk ? lo + per : chunk;
+  const float *base = x + bg * chunk;
+  float s = 0.f, q = 0.f;
+  for (long i = lo + threadIdx.x * 4; i + 3 < hi; i += 256 * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(base + i);
+    s += (v.x + v.y) + (v.z + v.w);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  double ds = (double)s, dq = (double)q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ds += __shfl_xor(ds, o);
+    dq += __shfl_xor(dq, o);
+  }
+  __shared__ double sh[8];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[wave] = ds; sh[4 + wave] = dq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[2 * bg], (sh[0] + sh[1]) + (sh[2] + sh[3]));
+    atomicAdd(&stats[2 * bg + 1], (sh[4] + sh[5]) + (sh[6] + sh[7]));
+  }
+}
+
+template <int SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float *__restrict__ y,
+                                                       const double *__restrict__ stats, int C, long HW, int cpg,
+                                                       double eps, int segs) {
+  const long row = blockIdx.x / segs;          // (b, c)
+  const int seg = blockIdx.x % segs;
+  const int c = (int)(row % C);
+  const long b = row / C;
+  const long bg = b * (C / cpg) + c / cpg;
+  const double n = (double)cpg * (double)HW;
+  const double mean = stats[2 * bg] / n;
+  double var = stats[2 * bg + 1] / n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + eps);
+  const float a = (float)(rstd * (double)gamma[c]);
+  const float sh = (float)((double)beta[c] - mean * rstd * (double)gamma[c]);
+  const long per = ((HW / 4 + segs - 1) / segs) * 4;
+  const long lo = seg * per, hi = lo + per < HW ? lo + per : HW;
+  const float *xi = x + row * HW;
+  float *yo = y + row * HW;
+  for (long i = lo + threadIdx.x * 4; i + 3 < hi; i += 256 * 4) {
+    f32x4 v = *reinterpret_cast<const f32x4 *>(xi + i);
+    v = v * a + sh;
+    if (SILU) {
+      v.x = v.x / (1.0f + __expf(-v.x));
+      v.y = v.y / (1.0f + __expf(-v.y));
+      v.z = v.z / (1.0f + __expf(-v.z));
+      v.w = v.w / (1.0f + __expf(-v.w));
+    }
+    *reinterpret_cast<f32x4 *>(yo + i) = v;
+  }
+}
+
 // ---- index histogram + u16 wire format (eval.py:127,137-141,152-154) --------
 __global__ __launch_bounds__(256) void hist_kernel(const int64_t *__restrict__ idx, long count, int n,
                                                    int *__restrict__ hist) {

@@ -339,6 +339,35 @@ int lfq_unpack_f32(const int64_t *idx, float *q, int64_t rows, int64_t nbits, vo
   return check_launch();
 }
 
+int gn_silu_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B, int64_t C, int64_t HW,
+                int64_t groups, double eps, int apply_silu, double *stats_ws, void *stream) {
+  if (!x || !gamma || !beta || !y || !stats_ws || B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0)
+    return GQHIP_ERR_INVALID_ARG;
+  if (HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;   // callers fall back to torch for odd spatial sizes
+  if (B == 0) return GQHIP_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t bg = B * groups, cpg = C / groups, chunk = cpg * HW;
+  if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * bg, st) != hipSuccess) return check_launch();
+  // ~16 KiB of input per block keeps >= 2k blocks in flight at the big resolutions
+  int slices = (int)((chunk + 4095) / 4096);
+  if (slices > 256) slices = 256;
+  if (slices < 1) slices = 1;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(bg * slices)), dim3(256), 0, st, x, stats_ws, (long)chunk,
+                     slices);
+  int rc = check_launch();
+  if (rc != GQHIP_OK) return rc;
+  int segs = (int)((HW + 8191) / 8192);
+  if (segs < 1) segs = 1;
+  const dim3 grid((unsigned)(B * C * segs));
+  if (apply_silu)
+    hipLaunchKernelGGL((gn_apply_kernel<1>), grid, dim3(256), 0, st, x, gamma, beta, y, stats_ws, (int)C, (long)HW,
+                       (int)cpg, eps, segs);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<0>), grid, dim3(256), 0, st, x, gamma, beta, y, stats_ws, (int)C, (long)HW,
+                       (int)cpg, eps, segs);
+  return check_launch();
+}
+
 static int fsq_levels(const int32_t *levels_host, int64_t nlev, FsqLevels *L) {
   if (!levels_host || nlev < 1 || nlev > 16) return GQHIP_ERR_INVALID_ARG;
   L->n = (int)nlev;

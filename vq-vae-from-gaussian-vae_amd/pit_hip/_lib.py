@@ -45,6 +45,7 @@ _SIGNATURES = {
     "lfq_unpack_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "fsq_quantize_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _vp, _i64, _vp]),
     "fsq_dequant_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _i64, _vp]),
+    "gn_silu_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "gq_indices_from_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -279,6 +280,25 @@ def fsq_dequant(idx, levels):
     with torch.cuda.device(idx.device):
         _check(lib().fsq_dequant_f32(idx.data_ptr(), arr, n, zhat.data_ptr(), rows, _stream()), "fsq_dequant_f32")
     return zhat
+
+
+_gn_ws = {}
+
+
+def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True):
+    """Fused GroupNorm(+SiLU) on an NCHW fp32 HIP tensor (see gqhip.h:gn_silu_f32)."""
+    x = _dev(x, torch.float32, "x")
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    key = (x.device, B * groups)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        ws = _gn_ws[key] = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().gn_silu_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), B, C, HW, groups,
+                                 float(eps), 1 if silu else 0, ws.data_ptr(), _stream()), "gn_silu_f32")
+    return y
 
 
 def index_histogram(idx, n: int):

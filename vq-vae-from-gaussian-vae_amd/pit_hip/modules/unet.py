@@ -30,6 +30,26 @@ def _silu(x: torch.Tensor) -> torch.Tensor:
     return F.silu(x)
 
 
+def _use_fused(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
+    """HIP fused GroupNorm(+SiLU) applies to inference on HIP devices, NCHW fp32, HW % 4 == 0;
+    training / autograd / CPU tensors stay on the ATen ops (this stack is PyTorch by design)."""
+    return (FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and x.dim() == 4 and x.is_contiguous() and (x.shape[2] * x.shape[3]) % 4 == 0 and norm.affine)
+
+
+def _norm_act(norm: nn.GroupNorm, x: torch.Tensor, act: bool = True) -> torch.Tensor:
+    """GroupNorm followed by swish (unet.py:140-141, :146-147, :432-433) -- one fused HIP pass pair."""
+    if _use_fused(x, norm):
+        from .. import _lib
+
+        return _lib.gn_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=act)
+    y = norm(x)
+    return _silu(y) if act else y
+
+
+FUSED_GN = True  # module-level switch (tests / A-B timing)
+
+
 def _conv3(cin: int, cout: int, padding_mode: str = "zeros", stride: int = 1, padding: int = 1) -> nn.Conv2d:
     return nn.Conv2d(cin, cout, 3, stride, padding, padding_mode=padding_mode)
 
@@ -49,8 +69,8 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        h = self.conv1(_silu(self.norm1(x)))
-        h = self.conv2(self.dropout(_silu(self.norm2(h))))
+        h = self.conv1(_norm_act(self.norm1, x))
+        h = self.conv2(self.dropout(_norm_act(self.norm2, h)))
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut(x)
         return x + h
@@ -69,7 +89,7 @@ class AttnBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b, c, h, w = x.shape
-        y = self.norm(x)
+        y = _norm_act(self.norm, x, act=False)
         # [b, c, h, w] -> [b, 1, hw, c]
         q, k, v = (f(y).reshape(b, 1, c, h * w).transpose(2, 3).contiguous() for f in (self.q, self.k, self.v))
         a = F.scaled_dot_product_attention(q, k, v)  # scale c**-0.5
@@ -185,7 +205,7 @@ class Encoder(nn.Module):
             if lvl != self.num_resolutions - 1:
                 h = level.downsample(h)
         h = self.mid(h)
-        return self.conv_out(_silu(self.norm_out(h)))
+        return self.conv_out(_norm_act(self.norm_out, h))
 
 
 class Decoder(nn.Module):
@@ -235,5 +255,5 @@ class Decoder(nn.Module):
                 h = self.up[lvl].upsample(h)
         if self.give_pre_end:
             return h
-        h = self.conv_out(_silu(self.norm_out(h)))
+        h = self.conv_out(_norm_act(self.norm_out, h))
         return torch.tanh(h) if self.tanh_out else h
