@@ -44,6 +44,25 @@ def build_model(device):
     return vae.eval().to(device)
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per filter launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_*.csv,
+    separate FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py at this shape).  Units are KiB; gfx950
+    reports half of a wide coalesced read stream, so FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM)."""
+    import csv
+
+    vals = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", "r01", f"pmc_{name}.csv")
+        if not os.path.exists(path):
+            return None
+        rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                if "gq_filter_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+        if not rows:
+            return None
+        vals[name] = sum(rows) / len(rows)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(bs_sample: int = 1):
     """The CPU restatement (oracle + the same torch modules on CPU) on a bounded sample:
     `bs_sample` 256x256 images through encoder -> oracle quantiser -> decoder, all host cores."""
@@ -83,6 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miopen-benchmark", type=int, default=int(os.environ.get("GQ_MIOPEN_BENCHMARK", "0")))
     ap.add_argument("--channels-last", type=int, default=int(os.environ.get("GQ_CHANNELS_LAST", "0")))
     args = ap.parse_args()
 
@@ -94,7 +114,9 @@ def main():
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     device = torch.device("cuda", env["local_rank"])
     torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = True  # MIOpen find mode (the reference sets trainer.benchmark: True)
+    # 0 = MIOpen immediate mode (measured: same steady-state img/s as find mode, 35 s vs 248 s of warm-up on a
+    # fresh box); 1 = find mode like the reference's trainer.benchmark: True
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
 
     vae = build_model(device)
     g = torch.Generator().manual_seed(1000 + rank)
@@ -154,8 +176,11 @@ def main():
                        "parallelism": f"dp{world} image-sharded, one packed all_gather/step"},
             "roofline": {"kernel": "gq_filter_kernel<16,2,8,GQ> (fp32 MFMA filter of the fused quantiser)",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
+                         "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01 PMC passes; "
+                                         "algorithmic bytes 7.5e6 (+4.2e6 candidate records)",
                          "launches": launches, "avg_launch_us": round(avg_ms * 1e3, 2),
+                         "timing": "hipEvents attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream",
                          "algorithmic_flops_per_launch": flops},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -23,7 +23,8 @@ raw = ws.buf[off:off + nblk * 32].cpu().numpy().view(np.uint64).reshape(nblk, 4)
 t0 = raw[:, 0].min()
 start = (raw[:, 0] - t0) / 100.0   # us
 end = (raw[:, 1] - t0) / 100.0
-cyc = raw[:, 2]
+pro = (raw[:, 2] >> 32) / 100.0
+loop_end = (raw[:, 2] & 0xFFFFFFFF) / 100.0
 hw = raw[:, 3] & 0xFFFFFFFF
 xcc = (raw[:, 3] >> 32) & 0xF
 cu = (hw >> 8) & 0xF
@@ -37,5 +38,8 @@ print(f"distinct (xcc,se,sh,cu) = {len(uniq)}; blocks per CU histogram: {np.binc
 print("blocks per XCC:", np.bincount(xcc.astype(int), minlength=8).tolist())
 late = start > 50
 print(f"late starters: {late.sum()}, their median start {np.median(start[late]) if late.any() else 0:.1f} us")
-clk = cyc / ((raw[:, 1] - raw[:, 0]) * 10.0) # cycles per ns
-print(f"in-kernel clock median {np.median(clk):.3f} GHz")
+dur = end - start
+print(f"prologue (block start -> first barrier) min/med/max {pro.min():.1f}/{np.median(pro):.1f}/{pro.max():.1f} us")
+print(f"main loop min/med/max {np.min(loop_end-pro):.1f}/{np.median(loop_end-pro):.1f}/{np.max(loop_end-pro):.1f} us")
+print(f"tail (loop end -> block end) min/med/max {np.min(dur-loop_end):.1f}/{np.median(dur-loop_end):.1f}/{np.max(dur-loop_end):.1f} us")
+print(f"last loop end at {np.max(start+loop_end):.1f} us, first block start {start.min():.2f}, last block start {start.max():.2f} us")

@@ -7,7 +7,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_stdout.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 "$REPO/bench.py" --steps 6 --warmup 3 --no-cpu-baseline > "$OUT/bench_stdout.txt" 2>&1
+python3 "$REPO/tools/steady_profile.py" "$OUT/bench_trace" 4 > "$OUT/STEADY_STATE.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench_trace" -- python3 "$REPO/tools/kbench.py" --iters 20 > "$OUT/kbench_stdout.txt" 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   tag=$(echo "$C" | tr ' ' '_' | cut -c1-40)

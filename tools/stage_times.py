@@ -33,7 +33,7 @@ def main():
     dev = torch.device("cuda:0")
     from pit_hip.modules import unet
     unet.FUSED_GN = bool(a.fused_gn)
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = False
     vae = bench.build_model(dev)
     x = (torch.rand(a.batch, 3, 256, 256) * 2 - 1).to(dev)
     if a.channels_last:

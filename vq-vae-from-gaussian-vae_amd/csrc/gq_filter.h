@@ -62,6 +62,9 @@ __device__ __forceinline__ void lds_read_half(const float *p, float (&a)[HD]) {
 
 // Running maximum over the 16 accumulators of a lane, seeded with t0: 8 v_max3.
 __device__ __forceinline__ float max_chain(float t0, const f32x16 &d) {
+#ifdef GQHIP_ABLATE_EPI   // diagnostic only: price the 7 other v_max3 of the chain
+  return __builtin_fmaxf(__builtin_fmaxf(t0, d[0]), d[15]);
+#endif
   float t = __builtin_fmaxf(__builtin_fmaxf(t0, d[0]), d[1]);
   t = __builtin_fmaxf(__builtin_fmaxf(t, d[2]), d[3]);
   t = __builtin_fmaxf(__builtin_fmaxf(t, d[4]), d[5]);
@@ -185,8 +188,17 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     }
   };
   auto read_ops = [&](const float *val, const float *sq, float (&a)[HD], float (&a2)[HD]) {
+#ifdef GQHIP_ABLATE_LDS   // diagnostic only: operands stay in registers (opaque to the optimiser), no LDS reads
+#pragma unroll
+    for (int s = 0; s < HD; ++s) {
+      a[s] = coefB[0][s];
+      a2[s] = coefA[0][s];
+      asm volatile("" : "+v"(a[s]), "+v"(a2[s]));
+    }
+#else
     lds_read_half<HD>(val, a);
     lds_read_half<HD>(sq, a2);
+#endif
   };
   auto close_pair = [&](int tile) {   // after the 2nd tile of a pair (or a lone last tile)
 #pragma unroll
@@ -210,6 +222,9 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   }
   __syncthreads();
 
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int S0 = 2;             // k-steps issued before the previous tile's epilogue
   f32x16 dprev[RT];                 // accumulators of the previous tile, epilogue pending
 #pragma unroll
@@ -276,6 +291,9 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     __syncthreads();
   }
   if (have_prev) fold(dprev, tprev, (tprev & 1) != 0);      // last pipelined tile
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_r2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- leftovers: a lone full tile and/or the one partial tile (n % 32 != 0) ----
   const bool pending = ntiles > 0 && (ntiles & 1);   // tile t_full_end-1 opened a pair
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + 4 * blockIdx.x;
     o[0] = st_r0;
     o[1] = __builtin_amdgcn_s_memrealtime();
-    o[2] = __builtin_amdgcn_s_memtime() - st_c0;
+    o[2] = ((st_r1 - st_r0) << 32) | (st_r2 - st_r0);   // prologue end, loop end (100 MHz ticks from block start)
     o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
            (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   }

@@ -2,6 +2,7 @@
 // gfx950 only; built by `make -C vq-vae-from-gaussian-vae_amd/csrc`.
 #include "gqhip.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -55,6 +56,8 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   const int target = env_blocks > 0 ? env_blocks : 512;
   int s = (target + pl.row_blocks - 1) / (pl.row_blocks > 0 ? pl.row_blocks : 1);
   s = ((s + 7) / 8) * 8;
+  static const int env_nsplit = getenv("GQHIP_NSPLIT") ? atoi(getenv("GQHIP_NSPLIT")) : 0;
+  if (env_nsplit > 0) s = env_nsplit;
   if (s > kMaxSplit) s = kMaxSplit;
   if (s > pl.tiles_total) s = pl.tiles_total;
   if (s < 1) s = 1;
@@ -90,22 +93,22 @@ bool g_prof_on = false;
 int g_debug_stats = 0;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 
+// When profiling is on, the filter is launched through hipExtLaunchKernelGGL with a start and a
+// stop event attached to the dispatch itself, so the elapsed time is the kernel's own duration on
+// its stream (what rocprofv3 --kernel-trace reports), not a marker-to-marker bracket.
 struct ProfScope {
-  hipStream_t st;
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
-  explicit ProfScope(hipStream_t s) : st(s) {
+  ProfScope() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     on = g_prof_on;
     if (on) {
       (void)hipEventCreate(&a);
       (void)hipEventCreate(&b);
-      (void)hipEventRecord(a, st);
     }
   }
   ~ProfScope() {
     if (on) {
-      (void)hipEventRecord(b, st);
       std::lock_guard<std::mutex> lk(g_prof_mu);
       g_prof_events.emplace_back(a, b);
     }
@@ -115,9 +118,14 @@ struct ProfScope {
 template <int MODE>
 int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t st) {
   const dim3 grid((unsigned)(pl.row_blocks * pl.nsplit)), block(256);
-  ProfScope prof(st);
-#define GQ_LAUNCH(D, R, C) \
-  hipLaunchKernelGGL((gq_filter_kernel<D, R, C, MODE>), grid, block, 0, st, fp)
+  ProfScope prof;
+#define GQ_LAUNCH(D, R, C)                                                                            \
+  do {                                                                                                \
+    if (prof.on)                                                                                      \
+      hipExtLaunchKernelGGL((gq_filter_kernel<D, R, C, MODE>), grid, block, 0, st, prof.a, prof.b, 0, fp); \
+    else                                                                                              \
+      hipLaunchKernelGGL((gq_filter_kernel<D, R, C, MODE>), grid, block, 0, st, fp);                  \
+  } while (0)
   if (pl.rt == 2) {
     switch (dim) {
       case 4: GQ_LAUNCH(4, 2, 8); break;
