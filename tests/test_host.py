@@ -174,3 +174,31 @@ def test_train_mode_branch_matches_reference_goldens():
                    "zhat_sha": sha(zh.detach().numpy())}
             assert got == want, (tag, it)
     assert set(info) >= {"kl_loss", "bits-mean", "bits-min", "bits-max", "lam"}
+
+
+def test_simple_dataset_transform_semantics(tmp_path):
+    """Resize(shorter edge) -> CenterCrop -> ToTensor -> Normalize(0.5)."""
+    from PIL import Image
+
+    from pit_hip.data import SimpleDataset
+
+    rng = np.random.default_rng(0)
+    (tmp_path / "sub").mkdir()
+    Image.fromarray(rng.integers(0, 256, (40, 64, 3), dtype=np.uint8)).save(tmp_path / "sub" / "b.png")
+    Image.fromarray(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)).save(tmp_path / "a.png")
+    Image.fromarray(rng.integers(0, 256, (50, 30, 3), dtype=np.uint8)).save(tmp_path / "c.jpg")
+    ds = SimpleDataset(str(tmp_path), 32)
+    assert [os.path.basename(p) for p in ds.fpaths] == ["c.jpg", "a.png", "b.png"]  # jpg glob before png
+    item = ds[1]
+    assert item["img"].shape == (3, 32, 32) and item["img"].dtype == torch.float32
+    raw = np.asarray(Image.open(tmp_path / "a.png").convert("RGB"), dtype=np.float32)
+    assert torch.equal(item["img"], (torch.from_numpy(raw).permute(2, 0, 1) / 255 - 0.5) / 0.5)  # 32x32: identity
+    wide = ds[2]["img"]  # 40x64 -> resize to 32x51 -> centre crop 32x32
+    assert wide.shape == (3, 32, 32) and -1.0 <= float(wide.min()) and float(wide.max()) <= 1.0
+    ref = Image.open(tmp_path / "sub" / "b.png").convert("RGB").resize((51, 32), Image.BILINEAR)
+    left = int(round((51 - 32) / 2.0))
+    ref = np.asarray(ref, dtype=np.float32)[:, left:left + 32]
+    assert torch.equal(wide, (torch.from_numpy(ref).permute(2, 0, 1) / 255 - 0.5) / 0.5)
+    lst = tmp_path / "list.txt"
+    lst.write_text(str(tmp_path / "a.png") + "\n")
+    assert len(SimpleDataset(str(lst), 32)) == 1
