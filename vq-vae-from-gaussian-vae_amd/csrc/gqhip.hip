@@ -152,10 +152,10 @@ template <int MODE>
 int run_argmax(const float *mu, const float *sd, const float *lsd, const float *cb, int64_t *idx,
                float *zhat, int64_t dim, int64_t rows, int64_t n, double beta, float cb_absmax,
                void *workspace, int64_t workspace_bytes, const OutMap &omap, hipStream_t st) {
-  if (!mu || !cb || !idx || (MODE == kModeGQ && !sd)) return GQHIP_ERR_INVALID_ARG;
   if (dim < 1 || dim > kMaxDim || rows < 0 || n < 1 || n > 0x3fffffff || rows > 0x3fffffff)
     return GQHIP_ERR_INVALID_ARG;
-  if (rows == 0) return GQHIP_OK;
+  if (rows == 0) return GQHIP_OK;   // empty batch: nothing to do (pointers may be NULL)
+  if (!mu || !cb || !idx || (MODE == kModeGQ && !sd)) return GQHIP_ERR_INVALID_ARG;
   const WsLayout w = ws_layout(rows, n, dim);
   if (!workspace || workspace_bytes < w.total) return GQHIP_ERR_WORKSPACE;
   char *ws = static_cast<char *>(workspace);
@@ -239,9 +239,9 @@ int gqhip_codebook_absmax(const float *cb, int64_t n, int64_t dim, float *absmax
 
 int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out, int64_t dim,
                   int64_t rows, int64_t n, double beta, void *stream) {
-  if (!mu || !sd || !cb || !out || dim < 1 || rows < 0 || n < 1 || n > 0x7fffffff || rows > 0x7fffffff)
-    return GQHIP_ERR_INVALID_ARG;
+  if (dim < 1 || rows < 0 || n < 1 || n > 0x7fffffff || rows > 0x7fffffff) return GQHIP_ERR_INVALID_ARG;
   if (rows == 0) return GQHIP_OK;
+  if (!mu || !sd || !cb || !out) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned gx = (unsigned)((n + 255) / 256);
   constexpr int ROWS = 16;
