@@ -140,10 +140,15 @@ int fsq_dequant_f32(const int32_t *idx, const int32_t *levels_host, int64_t nlev
  * Replaces the GroupNorm -> swish pairs of pit/modules/unet.py:54-57,49-51,137-153,432-435
  * (three PyTorch kernels, five HBM passes) by a stats pass + one apply pass (three passes).
  * x, y [B, C, HW] fp32 contiguous (NCHW), groups | C; stats_ws: 2*B*groups doubles of
- * caller scratch.  x and y may alias. */
-int gn_silu_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B,
-                int64_t C, int64_t HW, int64_t groups, double eps, int apply_silu,
-                double *stats_ws, void *stream);
+ * caller scratch.  x and y may alias.  pre_bias_or_null [C]: a per-channel bias still pending
+ * on x (the producing conv was run without its bias) -- normalises x + pre_bias[c] without a
+ * separate bias pass. */
+int gn_silu_f32(const float *x, const float *gamma, const float *beta,
+                const float *pre_bias_or_null, float *y, int64_t B, int64_t C, int64_t HW,
+                int64_t groups, double eps, int apply_silu, double *stats_ws, void *stream);
+/* y = a + b (+ bias[c]): residual add with the pending conv biases folded in (unet.py:153). */
+int add_bias_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B,
+                 int64_t C, int64_t HW, void *stream);
 
 /* ---- index wire format / usage histogram ----------------------------------- */
 int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n,

@@ -319,50 +319,29 @@ def test_unet_fused_and_aten_paths_agree():
     enc, dec = unet.Encoder(**cfg).eval().to(DEV), unet.Decoder(**cfg).eval().to(DEV)
     x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV)
     with torch.no_grad():
-        unet.FUSED_GN = True
-        z1 = enc(x); r1 = dec(z1[:, :16])
-        unet.FUSED_GN = False
-        z2 = enc(x); r2 = dec(z2[:, :16])
-        unet.FUSED_GN = True
-    torch.testing.assert_close(z1, z2, atol=1e-4, rtol=1e-4)
-    torch.testing.assert_close(r1, r2, atol=1e-4, rtol=1e-4)
+        outs = []
+        for fused, defer in ((True, True), (True, False), (False, False)):
+            unet.FUSED_GN, unet.DEFER_BIAS = fused, defer
+            z = enc(x)
+            outs.append((z, dec(z[:, :16])))
+        unet.FUSED_GN = unet.DEFER_BIAS = True
+    for z, r in outs[:2]:
+        torch.testing.assert_close(z, outs[2][0], atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(r, outs[2][1], atol=1e-4, rtol=1e-4)
 
 
-def test_empty_input_streams_workspace_reuse_noncontiguous():
+def test_gn_prebias_and_add_bias_kernels():
     from pit_hip import _lib
 
-    dev = torch.device(DEV)
-    cb = torch.from_numpy(O.codebook(2048, 16, 42)).to(dev)
-    ws = _lib.Workspace()
-    idx, zhat = _lib.gq_argmax(torch.empty(0, 16, device=dev), torch.empty(0, 16, device=dev), cb, ws=ws)
-    assert idx.shape == (0,) and zhat.shape == (0, 16)
-    g = torch.Generator().manual_seed(2)
-    mu = (0.9 * torch.randn(16, 700, generator=g)).to(dev).t()          # non-contiguous view [700, 16]
-    sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(700, 16, generator=g))).to(dev)
-    a, _ = _lib.gq_argmax(mu, sd, cb, ws=ws)
-    big_mu, big_sd = mu.repeat(8, 1), sd.repeat(8, 1)
-    b, _ = _lib.gq_argmax(big_mu, big_sd, cb, ws=ws)                      # workspace grows
-    c, _ = _lib.gq_argmax(mu, sd, cb, ws=ws)                              # ... and is reused for the small call
-    assert torch.equal(a, c) and torch.equal(b[:700], a) and torch.equal(b[700:1400], a)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        d, _ = _lib.gq_argmax(mu, sd, cb, ws=_lib.Workspace())           # launched on a non-default stream
-    side.synchronize()
-    assert torch.equal(a, d)
-    ref, _ = O.argmax_rows(mu.cpu().numpy(), sd.cpu().numpy(), cb.cpu().numpy(), 1.0,
-                           logstd=np.log(sd.cpu().numpy().astype(np.float64)).astype(np.float32))
-    assert np.array_equal(a.cpu().numpy(), ref)
-
-
-def test_eval_cli_single_rank():
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "eval_sharded.py"), "--base",
-                          os.path.join(G, "tiny_config.yaml"), "--img_size", "32", "--bs", "4", "--num", "10"],
-                         env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert "PSNR:" in out.stdout and "over 8 images" in out.stdout and "codebook usage" in out.stdout
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 16, 24, generator=g).to(DEV)
+    pb = torch.randn(64, generator=g).to(DEV)
+    gn = torch.nn.GroupNorm(32, 64, eps=1e-6).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(64, generator=g)); gn.bias.copy_(torch.randn(64, generator=g))
+        want = torch.nn.functional.silu(gn(x + pb[None, :, None, None]))
+        got = _lib.gn_silu(x, gn.weight, gn.bias, 32, 1e-6, silu=True, pre_bias=pb)
+        torch.testing.assert_close(got, want, atol=2e-5, rtol=1e-5)
+        y = torch.randn(2, 64, 16, 24, generator=g).to(DEV)
+        assert torch.equal(_lib.add_bias(x, y, None), x + y)
+        torch.testing.assert_close(_lib.add_bias(x, y, pb), x + y + pb[None, :, None, None], atol=1e-6, rtol=1e-6)

@@ -183,6 +183,17 @@ __global__ __launch_bounds__(256) void lfq_unpack_kernel(const int64_t *__restri
   q[t] = ((v >> (nbits - 1 - i)) & 1) ? 1.0f : -1.0f;
 }
 
+// y = a + b (+ bias[c]): the residual add of a ResnetBlock with the pending conv biases folded in.
+__global__ __launch_bounds__(256) void add_bias_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                       const float *__restrict__ bias, float *__restrict__ y, int C,
+                                                       long HW, long total4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4 *>(a)[i] + reinterpret_cast<const f32x4 *>(b)[i];
+    if (bias) v = v + bias[(int)(((i * 4) / HW) % C)];
+    reinterpret_cast<f32x4 *>(y)[i] = v;
+  }
+}
+
 // ---- FSQ (fsq.py:29-89) ------------------------------------------------------
 struct FsqLevels {
   int n;
@@ -228,16 +239,21 @@ __global__ __launch_bounds__(256) void fsq_dequant_kernel(const int32_t *__restr
 // ---- fused GroupNorm (+SiLU), NCHW fp32 --------------------------------------------
 // stats: each block reduces a contiguous slice of one (b, g) chunk; fp32 per-thread partials,
 // fp64 across threads/blocks (two atomics per block).
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, double *__restrict__ stats,
-                                                       long chunk, int slices) {
+// pre_bias (nullable, [C]): a per-channel bias still pending on x (the producing conv ran without
+// its bias); it is added on the fly so the separate bias pass disappears.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, const float *__restrict__ pre_bias,
+                                                       double *__restrict__ stats, long chunk, int slices, long HW,
+                                                       int cpg, int groups) {
   const long bg = blockIdx.x / slices;
   const int sl = blockIdx.x % slices;
   const long per = ((chunk / 4 + slices - 1) / slices) * 4;      // floats per slice (multiple of 4)
   const long lo = sl * per, hi = lo + per < chunk ? lo + per : chunk;
   const float *base = x + bg * chunk;
+  const int c0 = (int)(bg % groups) * cpg;
   float s = 0.f, q = 0.f;
   for (long i = lo + threadIdx.x * 4; i + 3 < hi; i += 256 * 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(base + i);
+    f32x4 v = *reinterpret_cast<const f32x4 *>(base + i);
+    if (pre_bias) v = v + pre_bias[c0 + (int)(i / HW)];
     s += (v.x + v.y) + (v.z + v.w);
     q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
@@ -260,7 +276,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
 template <int SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, float *__restrict__ y,
-                                                       const double *__restrict__ stats, int C, long HW, int cpg,
+                                                       const double *__restrict__ stats,
+                                                       const float *__restrict__ pre_bias, int C, long HW, int cpg,
                                                        double eps, int segs) {
   const long row = blockIdx.x / segs;          // (b, c)
   const int seg = blockIdx.x % segs;
@@ -273,7 +290,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   var = var > 0.0 ? var : 0.0;
   const double rstd = 1.0 / sqrt(var + eps);
   const float a = (float)(rstd * (double)gamma[c]);
-  const float sh = (float)((double)beta[c] - mean * rstd * (double)gamma[c]);
+  const double pb = pre_bias ? (double)pre_bias[c] : 0.0;
+  const float sh = (float)((double)beta[c] + (pb - mean) * rstd * (double)gamma[c]);
   const long per = ((HW / 4 + segs - 1) / segs) * 4;
   const long lo = seg * per, hi = lo + per < HW ? lo + per : HW;
   const float *xi = x + row * HW;

@@ -347,8 +347,9 @@ int lfq_unpack_f32(const int64_t *idx, float *q, int64_t rows, int64_t nbits, vo
   return check_launch();
 }
 
-int gn_silu_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B, int64_t C, int64_t HW,
-                int64_t groups, double eps, int apply_silu, double *stats_ws, void *stream) {
+int gn_silu_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null, float *y,
+                int64_t B, int64_t C, int64_t HW, int64_t groups, double eps, int apply_silu, double *stats_ws,
+                void *stream) {
   if (!x || !gamma || !beta || !y || !stats_ws || B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0)
     return GQHIP_ERR_INVALID_ARG;
   if (HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;   // callers fall back to torch for odd spatial sizes
@@ -360,19 +361,32 @@ int gn_silu_f32(const float *x, const float *gamma, const float *beta, float *y,
   int slices = (int)((chunk + 4095) / 4096);
   if (slices > 256) slices = 256;
   if (slices < 1) slices = 1;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(bg * slices)), dim3(256), 0, st, x, stats_ws, (long)chunk,
-                     slices);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(bg * slices)), dim3(256), 0, st, x, pre_bias_or_null, stats_ws,
+                     (long)chunk, slices, (long)HW, (int)cpg, (int)groups);
   int rc = check_launch();
   if (rc != GQHIP_OK) return rc;
   int segs = (int)((HW + 8191) / 8192);
   if (segs < 1) segs = 1;
   const dim3 grid((unsigned)(B * C * segs));
   if (apply_silu)
-    hipLaunchKernelGGL((gn_apply_kernel<1>), grid, dim3(256), 0, st, x, gamma, beta, y, stats_ws, (int)C, (long)HW,
-                       (int)cpg, eps, segs);
+    hipLaunchKernelGGL((gn_apply_kernel<1>), grid, dim3(256), 0, st, x, gamma, beta, y, stats_ws, pre_bias_or_null,
+                       (int)C, (long)HW, (int)cpg, eps, segs);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<0>), grid, dim3(256), 0, st, x, gamma, beta, y, stats_ws, (int)C, (long)HW,
-                       (int)cpg, eps, segs);
+    hipLaunchKernelGGL((gn_apply_kernel<0>), grid, dim3(256), 0, st, x, gamma, beta, y, stats_ws, pre_bias_or_null,
+                       (int)C, (long)HW, (int)cpg, eps, segs);
+  return check_launch();
+}
+
+int add_bias_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B, int64_t C,
+                 int64_t HW, void *stream) {
+  if (B < 0 || C < 1 || HW < 1 || HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!a || !b || !y) return GQHIP_ERR_INVALID_ARG;
+  const long total4 = (long)(B * C * HW / 4);
+  long blocks = (total4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(add_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, b,
+                     bias_or_null, y, (int)C, (long)HW, total4);
   return check_launch();
 }
 

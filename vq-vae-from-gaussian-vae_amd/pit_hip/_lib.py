@@ -45,7 +45,9 @@ _SIGNATURES = {
     "lfq_unpack_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "fsq_quantize_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _vp, _i64, _vp]),
     "fsq_dequant_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _i64, _vp]),
-    "gn_silu_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp]),
+    "gn_silu_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp,
+                                   _vp]),
+    "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "gq_indices_from_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -285,7 +287,7 @@ def fsq_dequant(idx, levels):
 _gn_ws = {}
 
 
-def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True):
+def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True, pre_bias=None):
     """Fused GroupNorm(+SiLU) on an NCHW fp32 HIP tensor (see gqhip.h:gn_silu_f32)."""
     x = _dev(x, torch.float32, "x")
     B, C = x.shape[0], x.shape[1]
@@ -296,8 +298,20 @@ def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True):
         ws = _gn_ws[key] = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        _check(lib().gn_silu_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), B, C, HW, groups,
-                                 float(eps), 1 if silu else 0, ws.data_ptr(), _stream()), "gn_silu_f32")
+        _check(lib().gn_silu_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), y.data_ptr(), B, C, HW,
+                                 groups, float(eps), 1 if silu else 0, ws.data_ptr(), _stream()), "gn_silu_f32")
+    return y
+
+
+def add_bias(a, b, bias=None):
+    """y = a + b (+ bias[c]) on NCHW fp32 HIP tensors (see gqhip.h:add_bias_f32)."""
+    a, b = _dev(a, torch.float32, "a"), _dev(b, torch.float32, "b")
+    B, C = a.shape[0], a.shape[1]
+    HW = a[0, 0].numel()
+    y = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _check(lib().add_bias_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, _stream()),
+               "add_bias_f32")
     return y
 
 

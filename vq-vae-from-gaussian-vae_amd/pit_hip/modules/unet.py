@@ -37,17 +37,48 @@ def _use_fused(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
             and x.dim() == 4 and x.is_contiguous() and (x.shape[2] * x.shape[3]) % 4 == 0 and norm.affine)
 
 
-def _norm_act(norm: nn.GroupNorm, x: torch.Tensor, act: bool = True) -> torch.Tensor:
-    """GroupNorm followed by swish (unet.py:140-141, :146-147, :432-433) -- one fused HIP pass pair."""
+def _materialize(x: torch.Tensor, pre_bias) -> torch.Tensor:
+    return x if pre_bias is None else x + pre_bias[None, :, None, None]
+
+
+def _norm_act(norm: nn.GroupNorm, x: torch.Tensor, act: bool = True, pre_bias=None) -> torch.Tensor:
+    """GroupNorm followed by swish (unet.py:140-141, :146-147, :432-433) -- one fused HIP pass pair.
+    ``pre_bias``: per-channel bias still pending on ``x`` (see ``_conv``)."""
     if _use_fused(x, norm):
         from .. import _lib
 
-        return _lib.gn_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=act)
-    y = norm(x)
+        return _lib.gn_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=act, pre_bias=pre_bias)
+    y = norm(_materialize(x, pre_bias))
     return _silu(y) if act else y
 
 
-FUSED_GN = True  # module-level switch (tests / A-B timing)
+def _defer_ok(x: torch.Tensor, conv: nn.Conv2d) -> bool:
+    """Deferred-bias path: inference on HIP, NCHW fp32, zero padding, output HW % 4 == 0."""
+    return (FUSED_GN and DEFER_BIAS and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and conv.bias is not None and conv.padding_mode == "zeros")
+
+
+def _conv(conv: nn.Conv2d, x: torch.Tensor):
+    """Run ``conv`` and return (y, pending_bias).  ATen's MIOpen path adds the bias in a separate
+    elementwise pass over the whole output; on the deferred path the conv runs bias-free and the
+    bias is handed to the consumer (the next fused GroupNorm or residual add), which folds it in."""
+    if _defer_ok(x, conv):
+        return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
+    return conv(x), None
+
+
+def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
+    """a + b (+ bias[c]) -- the residual add with the pending biases folded in."""
+    if (bias is not None and a.is_cuda and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+            and a.dtype == torch.float32 and not torch.is_grad_enabled() and (a.shape[2] * a.shape[3]) % 4 == 0):
+        from .. import _lib
+
+        return _lib.add_bias(a, b, bias)
+    return _materialize(a + b, bias)
+
+
+FUSED_GN = True    # module-level switches (tests / A-B timing)
+DEFER_BIAS = True
 
 
 def _conv3(cin: int, cout: int, padding_mode: str = "zeros", stride: int = 1, padding: int = 1) -> nn.Conv2d:
@@ -68,12 +99,21 @@ class ResnetBlock(nn.Module):
         if cin != cout:
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        h = self.conv1(_norm_act(self.norm1, x))
-        h = self.conv2(self.dropout(_norm_act(self.norm2, h)))
+    def forward(self, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
+        """``pre_bias``: bias of the conv that produced ``x``, not yet added (deferred path)."""
+        h, b1 = _conv(self.conv1, _norm_act(self.norm1, x, pre_bias=pre_bias))
+        h, bias = _conv(self.conv2, self.dropout(_norm_act(self.norm2, h, pre_bias=b1)))
         if self.in_channels != self.out_channels:
-            x = self.nin_shortcut(x)
-        return x + h
+            # nin(x + pb) = nin_nobias(x) + W.pb + nin.bias : every constant goes into the fused add
+            xs, bs = _conv(self.nin_shortcut, x)
+            if pre_bias is not None:
+                wpb = self.nin_shortcut.weight.reshape(self.out_channels, self.in_channels) @ pre_bias
+                bs = wpb if bs is None else bs + wpb
+        else:
+            xs, bs = x, pre_bias
+        if bs is not None:
+            bias = bs if bias is None else bias + bs
+        return _add(xs, h, bias)
 
 
 class AttnBlock(nn.Module):
@@ -94,7 +134,8 @@ class AttnBlock(nn.Module):
         q, k, v = (f(y).reshape(b, 1, c, h * w).transpose(2, 3).contiguous() for f in (self.q, self.k, self.v))
         a = F.scaled_dot_product_attention(q, k, v)  # scale c**-0.5
         a = a.transpose(2, 3).reshape(b, c, h, w)
-        return x + self.proj_out(a)
+        p, pb = _conv(self.proj_out, a)
+        return _add(x, p, pb)
 
 
 class Downsample(nn.Module):
@@ -107,14 +148,15 @@ class Downsample(nn.Module):
         if with_conv:
             self.conv = _conv3(ch, ch, stride=2, padding=0)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor):
+        """Returns (y, pending_bias) -- see ``_conv``."""
         if not self.with_conv:
-            return F.avg_pool2d(x, 2, 2)
+            return F.avg_pool2d(x, 2, 2), None
         if self.mode == "constant":
             x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
         else:
             x = F.pad(x, (0, 1, 0, 1), mode=self.mode)
-        return self.conv(x)
+        return _conv(self.conv, x)
 
 
 class Upsample(nn.Module):
@@ -126,9 +168,10 @@ class Upsample(nn.Module):
         if with_conv:
             self.conv = _conv3(ch, ch, padding_mode)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor):
+        """Returns (y, pending_bias) -- see ``_conv``."""
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-        return self.conv(x) if self.with_conv else x
+        return _conv(self.conv, x) if self.with_conv else (x, None)
 
 
 def _make_attn(ch: int, attn_type: str) -> nn.Module:
@@ -147,10 +190,10 @@ class _Level(nn.Module):
         self.block = nn.ModuleList()
         self.attn = nn.ModuleList()
 
-    def run(self, h: torch.Tensor) -> torch.Tensor:
+    def run(self, h: torch.Tensor, pre_bias=None) -> torch.Tensor:
         has_attn = len(self.attn) > 0
         for i, blk in enumerate(self.block):
-            h = blk(h)
+            h = blk(h, pre_bias if i == 0 else None)
             if has_attn:
                 h = self.attn[i](h)
         return h
@@ -162,8 +205,8 @@ class _Mid(nn.Module):
         self.block_1 = ResnetBlock(ch, ch, dropout, padding_mode)
         self.block_2 = ResnetBlock(ch, ch, dropout, padding_mode)  # no mid attention (unet.py:391, :500)
 
-    def forward(self, h: torch.Tensor) -> torch.Tensor:
-        return self.block_2(self.block_1(h))
+    def forward(self, h: torch.Tensor, pre_bias=None) -> torch.Tensor:
+        return self.block_2(self.block_1(h, pre_bias))
 
 
 class Encoder(nn.Module):
@@ -199,12 +242,12 @@ class Encoder(nn.Module):
         self.conv_out = _conv3(top, 2 * z_channels if double_z else z_channels, padding_mode)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        h = self.conv_in(x)
+        h, pb = _conv(self.conv_in, x)
         for lvl, level in enumerate(self.down):
-            h = level.run(h)
+            h, pb = level.run(h, pb), None
             if lvl != self.num_resolutions - 1:
-                h = level.downsample(h)
-        h = self.mid(h)
+                h, pb = level.downsample(h)
+        h = self.mid(h, pb)
         return self.conv_out(_norm_act(self.norm_out, h))
 
 
@@ -248,11 +291,12 @@ class Decoder(nn.Module):
 
     def forward(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
         self.last_z_shape = z.shape
-        h = self.mid(self.conv_in(z))
+        h, pb = _conv(self.conv_in, z)
+        h, pb = self.mid(h, pb), None
         for lvl in reversed(range(self.num_resolutions)):
-            h = self.up[lvl].run(h)
+            h, pb = self.up[lvl].run(h, pb), None
             if lvl != 0:
-                h = self.up[lvl].upsample(h)
+                h, pb = self.up[lvl].upsample(h)
         if self.give_pre_end:
             return h
         h = self.conv_out(_norm_act(self.norm_out, h))
