@@ -103,7 +103,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--miopen-benchmark", type=int, default=int(os.environ.get("GQ_MIOPEN_BENCHMARK", "0")))
-    ap.add_argument("--channels-last", type=int, default=int(os.environ.get("GQ_CHANNELS_LAST", "0")))
+    ap.add_argument("--channels-last", type=int, default=int(os.environ.get("GQ_CHANNELS_LAST", "1")),
+                    help="1: conv stack in torch channels_last (NHWC) -- MIOpen's fp32 igemm kernels run without the "
+                         "NCHW<->NHWC transposes and the fused GroupNorm/bias kernels have NHWC variants (+8%)")
     args = ap.parse_args()
 
     from pit_hip import _lib

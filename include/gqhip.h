@@ -143,12 +143,15 @@ int fsq_dequant_f32(const int32_t *idx, const int32_t *levels_host, int64_t nlev
  * caller scratch.  x and y may alias.  pre_bias_or_null [C]: a per-channel bias still pending
  * on x (the producing conv was run without its bias) -- normalises x + pre_bias[c] without a
  * separate bias pass. */
+#define GQHIP_LAYOUT_NCHW 0   /* x[b][c][hw] */
+#define GQHIP_LAYOUT_NHWC 1   /* x[b][hw][c] (torch channels_last): needs (C/groups) % 4 == 0, (C/4) | 256 */
 int gn_silu_f32(const float *x, const float *gamma, const float *beta,
                 const float *pre_bias_or_null, float *y, int64_t B, int64_t C, int64_t HW,
-                int64_t groups, double eps, int apply_silu, double *stats_ws, void *stream);
+                int64_t groups, double eps, int apply_silu, int layout, double *stats_ws,
+                void *stream);
 /* y = a + b (+ bias[c]): residual add with the pending conv biases folded in (unet.py:153). */
 int add_bias_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B,
-                 int64_t C, int64_t HW, void *stream);
+                 int64_t C, int64_t HW, int layout, void *stream);
 
 /* ---- index wire format / usage histogram ----------------------------------- */
 int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n,

@@ -345,3 +345,39 @@ def test_gn_prebias_and_add_bias_kernels():
         y = torch.randn(2, 64, 16, 24, generator=g).to(DEV)
         assert torch.equal(_lib.add_bias(x, y, None), x + y)
         torch.testing.assert_close(_lib.add_bias(x, y, pb), x + y + pb[None, :, None, None], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 32, 32), (1, 256, 16, 24), (2, 512, 8, 8)])
+def test_fused_groupnorm_nhwc_and_add_bias_nhwc(shape):
+    import torch.nn.functional as F
+    from pit_hip import _lib
+
+    g = torch.Generator().manual_seed(shape[1] + 1)
+    x = (torch.randn(*shape, generator=g) * 1.5 - 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
+    pb = torch.randn(shape[1], generator=g).to(DEV)
+    gn = torch.nn.GroupNorm(32, shape[1], eps=1e-6).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(shape[1], generator=g)); gn.bias.copy_(torch.randn(shape[1], generator=g))
+        want = F.silu(gn(x + pb[None, :, None, None]))
+        got = _lib.gn_silu(x, gn.weight, gn.bias, 32, 1e-6, silu=True, pre_bias=pb)
+        assert got.is_contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(got, want, atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(_lib.gn_silu(x, gn.weight, gn.bias, 32, 1e-6, silu=False), gn(x), atol=2e-5, rtol=1e-5)
+        y = torch.randn(*shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(_lib.add_bias(x, y, pb), x + y + pb[None, :, None, None], atol=1e-6, rtol=1e-6)
+
+
+def test_unet_channels_last_matches_nchw():
+    from pit_hip.modules import unet
+
+    cfg = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=64, in_channels=3, out_ch=3, ch=128,
+               ch_mult=[1, 2, 4], num_res_blocks=1, attn_resolutions=[16], dropout=0.0)
+    torch.manual_seed(1234)
+    enc, dec = unet.Encoder(**cfg).eval().to(DEV), unet.Decoder(**cfg).eval().to(DEV)
+    x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        z1 = enc(x); r1 = dec(z1[:, :16].contiguous())
+        enc_cl, dec_cl = enc.to(memory_format=torch.channels_last), dec.to(memory_format=torch.channels_last)
+        z2 = enc_cl(x.contiguous(memory_format=torch.channels_last)); r2 = dec_cl(z2[:, :16].contiguous())
+    torch.testing.assert_close(z1, z2, atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(r1, r2, atol=2e-4, rtol=2e-4)

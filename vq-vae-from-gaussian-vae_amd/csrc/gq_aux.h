@@ -183,6 +183,88 @@ __global__ __launch_bounds__(256) void lfq_unpack_kernel(const int64_t *__restri
   q[t] = ((v >> (nbits - 1 - i)) & 1) ? 1.0f : -1.0f;
 }
 
+// ---- NHWC (channels_last) variants: x[b][hw][c], the layout MIOpen's fp32 igemm kernels want ----
+// A block owns a slab of pixels of one image and ALL channels: thread -> channel quad q = tid % (C/4)
+// (4 consecutive channels of ONE group since cpg % 4 == 0), pixel lane = tid / (C/4).
+__global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const float *__restrict__ x,
+                                                            const float *__restrict__ pre_bias,
+                                                            double *__restrict__ stats, int C, long HW, int cpg,
+                                                            int slabs) {
+  __shared__ double red[2 * 64];   // per-group (sum, sumsq), groups <= 64
+  const int groups = C / cpg, quads = C / 4, lanes = 256 / quads;
+  const long b = blockIdx.x / slabs;
+  const int slab = blockIdx.x % slabs;
+  const long per = (HW + slabs - 1) / slabs;
+  const long lo = slab * per, hi = lo + per < HW ? lo + per : HW;
+  const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
+  if (threadIdx.x < 2 * groups) red[threadIdx.x] = 0.0;
+  __syncthreads();
+  f32x4 pb = {0.f, 0.f, 0.f, 0.f};
+  if (pre_bias) pb = *reinterpret_cast<const f32x4 *>(pre_bias + 4 * q);
+  const float *base = x + (b * HW) * C + 4 * q;
+  float s = 0.f, ss = 0.f;
+  for (long p = lo + pl; p < hi; p += lanes) {
+    f32x4 v = *reinterpret_cast<const f32x4 *>(base + p * C) + pb;
+    s += (v.x + v.y) + (v.z + v.w);
+    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  const int g = (4 * q) / cpg;
+  atomicAdd(&red[2 * g], (double)s);
+  atomicAdd(&red[2 * g + 1], (double)ss);
+  __syncthreads();
+  if (threadIdx.x < 2 * groups) atomicAdd(&stats[2 * (b * groups) + threadIdx.x], red[threadIdx.x]);
+}
+
+template <int SILU>
+__global__ __launch_bounds__(256) void gn_apply_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ y,
+                                                            const double *__restrict__ stats,
+                                                            const float *__restrict__ pre_bias, int C, long HW,
+                                                            int cpg, double eps, int slabs) {
+  const int groups = C / cpg, quads = C / 4, lanes = 256 / quads;
+  const long b = blockIdx.x / slabs;
+  const int slab = blockIdx.x % slabs;
+  const long per = (HW + slabs - 1) / slabs;
+  const long lo = slab * per, hi = lo + per < HW ? lo + per : HW;
+  const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
+  const int g = (4 * q) / cpg;
+  const double n = (double)cpg * (double)HW;
+  const double mean = stats[2 * (b * groups + g)] / n;
+  double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + eps);
+  f32x4 a, sh;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * q + k;
+    const double pbk = pre_bias ? (double)pre_bias[c] : 0.0;
+    a[k] = (float)(rstd * (double)gamma[c]);
+    sh[k] = (float)((double)beta[c] + (pbk - mean) * rstd * (double)gamma[c]);
+  }
+  const float *xi = x + (b * HW) * C + 4 * q;
+  float *yo = y + (b * HW) * C + 4 * q;
+  for (long p = lo + pl; p < hi; p += lanes) {
+    f32x4 v = *reinterpret_cast<const f32x4 *>(xi + p * C) * a + sh;
+    if (SILU) {
+      v.x = v.x / (1.0f + __expf(-v.x));
+      v.y = v.y / (1.0f + __expf(-v.y));
+      v.z = v.z / (1.0f + __expf(-v.z));
+      v.w = v.w / (1.0f + __expf(-v.w));
+    }
+    *reinterpret_cast<f32x4 *>(yo + p * C) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_bias_nhwc_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                            const float *__restrict__ bias, float *__restrict__ y,
+                                                            int C, long total4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4 *>(a)[i] + reinterpret_cast<const f32x4 *>(b)[i];
+    if (bias) v = v + *reinterpret_cast<const f32x4 *>(bias + (int)((i * 4) % C));
+    reinterpret_cast<f32x4 *>(y)[i] = v;
+  }
+}
+
 // y = a + b (+ bias[c]): the residual add of a ResnetBlock with the pending conv biases folded in.
 __global__ __launch_bounds__(256) void add_bias_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                        const float *__restrict__ bias, float *__restrict__ y, int C,

@@ -348,14 +348,34 @@ int lfq_unpack_f32(const int64_t *idx, float *q, int64_t rows, int64_t nbits, vo
 }
 
 int gn_silu_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null, float *y,
-                int64_t B, int64_t C, int64_t HW, int64_t groups, double eps, int apply_silu, double *stats_ws,
-                void *stream) {
-  if (!x || !gamma || !beta || !y || !stats_ws || B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0)
-    return GQHIP_ERR_INVALID_ARG;
-  if (HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;   // callers fall back to torch for odd spatial sizes
+                int64_t B, int64_t C, int64_t HW, int64_t groups, double eps, int apply_silu, int layout,
+                double *stats_ws, void *stream) {
+  if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
+  if (!x || !gamma || !beta || !y || !stats_ws) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t bg = B * groups, cpg = C / groups, chunk = cpg * HW;
+  if (layout == GQHIP_LAYOUT_NHWC) {
+    // thread <-> channel-quad mapping needs cpg % 4 == 0, (C/4) | 256, <= 64 groups
+    if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
+    if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * bg, st) != hipSuccess) return check_launch();
+    const int lanes = (int)(256 / (C / 4));
+    int slabs = (int)((HW + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16));   // ~16 pixels per thread
+    if (slabs > 1024) slabs = 1024;
+    if (slabs < 1) slabs = 1;
+    hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, pre_bias_or_null,
+                       stats_ws, (int)C, (long)HW, (int)cpg, slabs);
+    int rc = check_launch();
+    if (rc != GQHIP_OK) return rc;
+    if (apply_silu)
+      hipLaunchKernelGGL((gn_apply_nhwc_kernel<1>), dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, gamma, beta, y,
+                         stats_ws, pre_bias_or_null, (int)C, (long)HW, (int)cpg, eps, slabs);
+    else
+      hipLaunchKernelGGL((gn_apply_nhwc_kernel<0>), dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, gamma, beta, y,
+                         stats_ws, pre_bias_or_null, (int)C, (long)HW, (int)cpg, eps, slabs);
+    return check_launch();
+  }
+  if (layout != GQHIP_LAYOUT_NCHW || HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;   // callers fall back to torch
   if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * bg, st) != hipSuccess) return check_launch();
   // ~16 KiB of input per block keeps >= 2k blocks in flight at the big resolutions
   int slices = (int)((chunk + 4095) / 4096);
@@ -378,15 +398,23 @@ int gn_silu_f32(const float *x, const float *gamma, const float *beta, const flo
 }
 
 int add_bias_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B, int64_t C,
-                 int64_t HW, void *stream) {
-  if (B < 0 || C < 1 || HW < 1 || HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+                 int64_t HW, int layout, void *stream) {
+  if (B < 0 || C < 1 || HW < 1) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!a || !b || !y) return GQHIP_ERR_INVALID_ARG;
   const long total4 = (long)(B * C * HW / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(add_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, b,
-                     bias_or_null, y, (int)C, (long)HW, total4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (layout == GQHIP_LAYOUT_NHWC) {
+    if (C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(add_bias_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, bias_or_null, y, (int)C,
+                       total4);
+  } else {
+    if (layout != GQHIP_LAYOUT_NCHW || HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(add_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, bias_or_null, y, (int)C,
+                       (long)HW, total4);
+  }
   return check_launch();
 }
 

@@ -45,9 +45,9 @@ _SIGNATURES = {
     "lfq_unpack_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "fsq_quantize_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _vp, _i64, _vp]),
     "fsq_dequant_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _i64, _vp]),
-    "gn_silu_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp,
-                                   _vp]),
-    "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "gn_silu_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int,
+                                   ctypes.c_int, _vp, _vp]),
+    "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "gq_indices_from_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -287,30 +287,50 @@ def fsq_dequant(idx, levels):
 _gn_ws = {}
 
 
+def image_layout(x: torch.Tensor):
+    """0 = NCHW contiguous, 1 = NHWC (torch channels_last) dense, None = neither (caller falls back)."""
+    if x.dim() != 4:
+        return None
+    if x.is_contiguous():
+        return 0
+    if x.is_contiguous(memory_format=torch.channels_last):
+        return 1
+    return None
+
+
+def gn_nhwc_ok(C: int, groups: int) -> bool:
+    cpg = C // groups
+    return cpg % 4 == 0 and 256 % (C // 4) == 0 and groups <= 64
+
+
 def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True, pre_bias=None):
-    """Fused GroupNorm(+SiLU) on an NCHW fp32 HIP tensor (see gqhip.h:gn_silu_f32)."""
-    x = _dev(x, torch.float32, "x")
+    """Fused GroupNorm(+SiLU) on an NCHW or channels_last fp32 HIP tensor (see gqhip.h:gn_silu_f32)."""
+    layout = image_layout(x)
+    if not x.is_cuda or x.dtype != torch.float32 or layout is None:
+        raise GqHipError("gn_silu needs a dense fp32 NCHW / channels_last HIP tensor")
     B, C = x.shape[0], x.shape[1]
-    HW = x[0, 0].numel()
+    HW = x.shape[2] * x.shape[3]
     key = (x.device, B * groups)
     ws = _gn_ws.get(key)
     if ws is None:
         ws = _gn_ws[key] = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x)  # preserves the memory format
     with torch.cuda.device(x.device):
         _check(lib().gn_silu_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), y.data_ptr(), B, C, HW,
-                                 groups, float(eps), 1 if silu else 0, ws.data_ptr(), _stream()), "gn_silu_f32")
+                                 groups, float(eps), 1 if silu else 0, layout, ws.data_ptr(), _stream()), "gn_silu_f32")
     return y
 
 
 def add_bias(a, b, bias=None):
-    """y = a + b (+ bias[c]) on NCHW fp32 HIP tensors (see gqhip.h:add_bias_f32)."""
-    a, b = _dev(a, torch.float32, "a"), _dev(b, torch.float32, "b")
+    """y = a + b (+ bias[c]) on NCHW / channels_last fp32 HIP tensors of the same layout."""
+    layout = image_layout(a)
+    if layout is None or image_layout(b) != layout or not a.is_cuda or a.dtype != torch.float32:
+        raise GqHipError("add_bias needs two dense fp32 HIP tensors of the same layout")
     B, C = a.shape[0], a.shape[1]
-    HW = a[0, 0].numel()
+    HW = a.shape[2] * a.shape[3]
     y = torch.empty_like(a)
     with torch.cuda.device(a.device):
-        _check(lib().add_bias_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, _stream()),
+        _check(lib().add_bias_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, layout, _stream()),
                "add_bias_f32")
     return y
 

@@ -33,8 +33,15 @@ def _silu(x: torch.Tensor) -> torch.Tensor:
 def _use_fused(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
     """HIP fused GroupNorm(+SiLU) applies to inference on HIP devices, NCHW fp32, HW % 4 == 0;
     training / autograd / CPU tensors stay on the ATen ops (this stack is PyTorch by design)."""
-    return (FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-            and x.dim() == 4 and x.is_contiguous() and (x.shape[2] * x.shape[3]) % 4 == 0 and norm.affine)
+    if not (FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and x.dim() == 4 and norm.affine):
+        return False
+    from .. import _lib
+
+    layout = _lib.image_layout(x)
+    if layout == 0:
+        return (x.shape[2] * x.shape[3]) % 4 == 0
+    return layout == 1 and _lib.gn_nhwc_ok(x.shape[1], norm.num_groups)
 
 
 def _materialize(x: torch.Tensor, pre_bias) -> torch.Tensor:
@@ -69,11 +76,14 @@ def _conv(conv: nn.Conv2d, x: torch.Tensor):
 
 def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
     """a + b (+ bias[c]) -- the residual add with the pending biases folded in."""
-    if (bias is not None and a.is_cuda and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
-            and a.dtype == torch.float32 and not torch.is_grad_enabled() and (a.shape[2] * a.shape[3]) % 4 == 0):
+    if (bias is not None and a.is_cuda and a.shape == b.shape and a.dtype == torch.float32
+            and not torch.is_grad_enabled()):
         from .. import _lib
 
-        return _lib.add_bias(a, b, bias)
+        la, lb = _lib.image_layout(a), _lib.image_layout(b)
+        if la is not None and la == lb and ((la == 0 and (a.shape[2] * a.shape[3]) % 4 == 0) or
+                                            (la == 1 and a.shape[1] % 4 == 0)):
+            return _lib.add_bias(a, b, bias)
     return _materialize(a + b, bias)
 
 
@@ -131,9 +141,15 @@ class AttnBlock(nn.Module):
         b, c, h, w = x.shape
         y = _norm_act(self.norm, x, act=False)
         # [b, c, h, w] -> [b, 1, hw, c]
-        q, k, v = (f(y).reshape(b, 1, c, h * w).transpose(2, 3).contiguous() for f in (self.q, self.k, self.v))
-        a = F.scaled_dot_product_attention(q, k, v)  # scale c**-0.5
-        a = a.transpose(2, 3).reshape(b, c, h, w)
+        if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
+            # channels_last: [b, hw, c] is a free view of the conv output and of the result
+            q, k, v = (f(y).permute(0, 2, 3, 1).reshape(b, 1, h * w, c) for f in (self.q, self.k, self.v))
+            a = F.scaled_dot_product_attention(q, k, v)
+            a = a.reshape(b, h, w, c).permute(0, 3, 1, 2)
+        else:
+            q, k, v = (f(y).reshape(b, 1, c, h * w).transpose(2, 3).contiguous() for f in (self.q, self.k, self.v))
+            a = F.scaled_dot_product_attention(q, k, v)  # scale c**-0.5
+            a = a.transpose(2, 3).reshape(b, c, h, w)
         p, pb = _conv(self.proj_out, a)
         return _add(x, p, pb)
 
