@@ -16,8 +16,9 @@
 //   B operand, k-step s : row coefficient A|B[row c][h*HD + s]
 //   D regs of lane (c,h): row c, codes (reg&3) + 8*(reg>>2) + 4*h of the tile
 // so all 16 accumulator registers of a lane belong to ONE row and the running
-// maximum is a v_max3 chain with no cross-lane traffic in the loop.  A half-pair
-// (pair p, half h) = those 16 codes in tiles 2p and 2p+1 -> 32 codes.
+// maximum is a v_max3 chain with no cross-lane traffic in the loop.  A half-group
+// (group p of GT tiles, half h) = those 16 codes in tiles GT*p .. GT*p+GT-1 -> 16*GT codes
+// (GT = 2, "half-pair", for dim >= 16; GT = 4 for dim <= 8 where a tile has few MFMAs).
 // A block = 4 waves x RT row tiles (128*RT rows); the code axis is split
 // `nsplit` ways over blockIdx so that blockIdx % 8 (the XCD a block lands on)
 // selects the code split: each XCD's L2 only ever holds 1/8 of the codebook.
@@ -110,13 +111,13 @@ __device__ __forceinline__ void tile_mfma(const float (&a)[DIM / 2], const float
 // tile t, and the epilogue of tile t-1 runs as ONE cluster right after the first
 // MFMAs of tile t (no wait for the accumulators to drain; each MFMA<->VALU switch
 // costs ~9 cycles, so the VALU work is clustered, not spread).
-template <int DIM, int RT, int CT, int MODE>
+template <int DIM, int RT, int CT, int MODE, int GT>
 __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p) {
   constexpr int HD = DIM / 2;                 // dims per lane half
   constexpr int TILE_F = kTileCodes * DIM;    // floats per 32-code tile
   constexpr int CHUNK_F = CT * TILE_F;        // floats per LDS chunk (per array)
   constexpr int R4 = CHUNK_F / 4 / 256;       // 16-byte loads per thread per chunk
-  static_assert(R4 >= 1 && CHUNK_F % 1024 == 0 && CT % 2 == 0, "chunk: multiple of 4 KiB, even tile count");
+  static_assert(R4 >= 1 && CHUNK_F % 1024 == 0 && CT % GT == 0, "chunk: multiple of 4 KiB, whole tile groups");
   // [buffer][0 = values, 1 = squares]
   __shared__ __attribute__((aligned(16))) float lds[2][2][CHUNK_F];
 
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   const int c = lane & 31, h = lane >> 5;
   const int split = blockIdx.x % p.nsplit;
   const int rowblk = blockIdx.x / p.nsplit;
-  const int t_begin = split * p.tiles_per_split;          // even (tiles_per_split is even)
+  const int t_begin = split * p.tiles_per_split;          // multiple of GT (tiles_per_split is)
   const int t_end = min(t_begin + p.tiles_per_split, p.tiles_total);
   const int t_full_end = min(t_end, p.n / kTileCodes);    // complete tiles only
   const long cb_last4 = (long)p.n * DIM - 4;              // last valid 16-byte load offset (floats)
@@ -200,10 +201,10 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     lds_read_half<HD>(sq, a2);
 #endif
   };
-  auto close_pair = [&](int tile) {   // after the 2nd tile of a pair (or a lone last tile)
+  auto close_pair = [&](int tile) {   // after the last tile of a group of GT tiles (or a lone last tile)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      top3_insert(tpend[rt], tile >> 1, m1[rt], m2[rt], m3[rt], i1[rt], i2[rt]);
+      top3_insert(tpend[rt], tile / GT, m1[rt], m2[rt], m3[rt], i1[rt], i2[rt]);
       tpend[rt] = NEG_INF;
     }
   };
@@ -243,15 +244,15 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     if (nt == CT) {
       float a[HD], a2[HD];
       read_ops(val, sq, a, a2);
-      // PREV_ODD: the tile whose epilogue runs in this step is the 2nd of its pair
-      // (tile0 is even, so that is static); LAST: no operand prefetch for a next tile.
-      auto step = [&](int tt, auto prev_odd, auto last) {
-        constexpr bool PREV_ODD = decltype(prev_odd)::value, LAST = decltype(last)::value;
+      // PREV_CLOSES: the tile whose epilogue runs in this step is the last of its group of GT tiles
+      // (tile0 is a multiple of GT, so that is static); LAST: no operand prefetch for a next tile.
+      auto step = [&](int tt, auto prev_closes, auto last) {
+        constexpr bool PREV_CLOSES = decltype(prev_closes)::value, LAST = decltype(last)::value;
         float an[HD], a2n[HD];
         if constexpr (!LAST) read_ops(val + (tt + 1) * TILE_F, sq + (tt + 1) * TILE_F, an, a2n);
         f32x16 d[RT];
         tile_mfma<DIM, RT, 0, S0>(a, a2, coefA, coefB, d);
-        fold(dprev, tprev, PREV_ODD);
+        fold(dprev, tprev, PREV_CLOSES);
         tile_mfma<DIM, RT, S0, 2 * HD>(a, a2, coefA, coefB, d);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) dprev[rt] = d[rt];
@@ -263,40 +264,44 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
         }
         // pin the order: LDS reads | first MFMAs | ONE VALU cluster | remaining MFMAs
         __builtin_amdgcn_sched_group_barrier(0x008, S0 * RT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, RT * (PREV_ODD ? 18 : 9), 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, RT * (PREV_CLOSES ? 18 : 9), 0);
         __builtin_amdgcn_sched_group_barrier(0x008, (2 * HD - S0) * RT, 0);
       };
-      using T = std::true_type;
-      using F = std::false_type;
-#pragma unroll
-      for (int tt = 0; tt < CT - 2; tt += 2) {
-        step(tt, T{}, F{});
-        step(tt + 1, F{}, F{});
-      }
-      step(CT - 2, T{}, F{});
-      step(CT - 1, F{}, T{});
+      auto run_all = [&](auto... is) {
+        (step(decltype(is)::value, std::bool_constant<(decltype(is)::value % GT) == 0>{},
+              std::bool_constant<decltype(is)::value == CT - 1>{}), ...);
+      };
+      using std::integral_constant;
+      if constexpr (CT == 8)
+        run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
+                integral_constant<int, 3>{}, integral_constant<int, 4>{}, integral_constant<int, 5>{},
+                integral_constant<int, 6>{}, integral_constant<int, 7>{});
+      else
+        run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
+                integral_constant<int, 3>{});
+      static_assert(CT == 8 || CT == 4, "unrolled tile loop is written for 4 or 8 tiles per chunk");
       have_prev = true;
     } else {
-      if (have_prev) fold(dprev, tprev, (tprev & 1) != 0);  // drain the pipeline, then plain tiles
+      if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);  // drain the pipeline, then plain tiles
       have_prev = false;
       for (int tt = 0; tt < nt; ++tt) {
         float a[HD], a2[HD];
         read_ops(val + tt * TILE_F, sq + tt * TILE_F, a, a2);
         f32x16 d[RT];
         tile_mfma<DIM, RT, 0, 2 * HD>(a, a2, coefA, coefB, d);
-        fold(d, tile0 + tt, (tt & 1) != 0);
+        fold(d, tile0 + tt, ((tile0 + tt) % GT) == GT - 1);
       }
     }
     if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
     __syncthreads();
   }
-  if (have_prev) fold(dprev, tprev, (tprev & 1) != 0);      // last pipelined tile
+  if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);      // last pipelined tile
 #ifdef GQHIP_CLOCK_STAMPS
   const unsigned long long st_r2 = __builtin_amdgcn_s_memrealtime();
 #endif
 
   // ---- leftovers: a lone full tile and/or the one partial tile (n % 32 != 0) ----
-  const bool pending = ntiles > 0 && (ntiles & 1);   // tile t_full_end-1 opened a pair
+  const bool pending = ntiles > 0 && (ntiles % GT) != 0;   // the last group is still open
   if (t_end > t_full_end) {
     const int tile = t_full_end;
     const int code = min(tile * kTileCodes + c, p.n - 1);
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt];
-    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h;   // half-pair ids
+    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h;   // half-group ids
     const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32);
     const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32);
     top3_insert(b1, k1, a1, a2v, a3, j1, j2);

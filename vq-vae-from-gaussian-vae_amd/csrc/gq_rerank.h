@@ -59,6 +59,7 @@ struct RerankParams {
   int rows, n, dim;
   float beta;
   int nsplit;
+  int gt;             // tiles per candidate group (2 or 4) -- must match the filter's GT
   int all_rows;       // exhaustive kernel: process every row (no filter ran)
   int stats;          // count re-ranked half-pairs (debug)
   OutMap omap;
@@ -202,16 +203,18 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- exact scores of every code in the flagged half-pairs (32 codes each) ----
+  // ---- exact scores of every code in the flagged half-groups (16*gt codes each) ----
   double best_s = 0.0;
   int best_i = 0x7fffffff;
   bool have = false;
-  for (int g = 0; g * 2 < total; ++g) {
-    const int e = g * 2 + (lane >> 5);
+  const int per = 16 * p.gt;          // codes per candidate: 32 or 64
+  const int cpp = 64 / per;           // candidates per wave pass
+  for (int g = 0; g * cpp < total; ++g) {
+    const int e = g * cpp + lane / per;
     if (e < total) {
       const int id = cand[wave][e];
-      const int rr = lane & 31;
-      const int tile = (id >> 1) * 2 + (rr >> 4);
+      const int rr = lane % per;
+      const int tile = (id >> 1) * p.gt + (rr >> 4);
       const int code = tile * kTileCodes + (rr & 3) + 8 * ((rr & 15) >> 2) + 4 * (id & 1);
       if (code < p.n) {
         const double s = exact_score<MODE>(p, rops[wave], code);

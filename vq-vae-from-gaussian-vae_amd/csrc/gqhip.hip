@@ -39,6 +39,7 @@ struct Plan {
   int nsplit;           // code splits
   int tiles_total;
   int tiles_per_split;
+  int gt;               // tiles per candidate group: 4 for dim <= 8, else 2
 };
 
 Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
@@ -62,7 +63,8 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   if (s > pl.tiles_total) s = pl.tiles_total;
   if (s < 1) s = 1;
   pl.tiles_per_split = (pl.tiles_total + s - 1) / s;
-  pl.tiles_per_split += pl.tiles_per_split & 1;   // even: a tile pair never straddles two splits
+  pl.gt = dim <= 8 ? 4 : 2;
+  pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   return pl;
 }
@@ -119,27 +121,27 @@ template <int MODE>
 int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t st) {
   const dim3 grid((unsigned)(pl.row_blocks * pl.nsplit)), block(256);
   ProfScope prof;
-#define GQ_LAUNCH(D, R, C)                                                                            \
+#define GQ_LAUNCH(D, R, C, G)                                                                           \
   do {                                                                                                \
     if (prof.on)                                                                                      \
-      hipExtLaunchKernelGGL((gq_filter_kernel<D, R, C, MODE>), grid, block, 0, st, prof.a, prof.b, 0, fp); \
+      hipExtLaunchKernelGGL((gq_filter_kernel<D, R, C, MODE, G>), grid, block, 0, st, prof.a, prof.b, 0, fp); \
     else                                                                                              \
-      hipLaunchKernelGGL((gq_filter_kernel<D, R, C, MODE>), grid, block, 0, st, fp);                  \
+      hipLaunchKernelGGL((gq_filter_kernel<D, R, C, MODE, G>), grid, block, 0, st, fp);                  \
   } while (0)
   if (pl.rt == 2) {
     switch (dim) {
-      case 4: GQ_LAUNCH(4, 2, 8); break;
-      case 8: GQ_LAUNCH(8, 2, 8); break;
-      case 16: GQ_LAUNCH(16, 2, 8); break;
-      case 32: GQ_LAUNCH(32, 2, 4); break;
+      case 4: GQ_LAUNCH(4, 2, 8, 4); break;
+      case 8: GQ_LAUNCH(8, 2, 8, 4); break;
+      case 16: GQ_LAUNCH(16, 2, 8, 2); break;
+      case 32: GQ_LAUNCH(32, 2, 4, 2); break;
       default: return GQHIP_ERR_INVALID_ARG;
     }
   } else {
     switch (dim) {
-      case 4: GQ_LAUNCH(4, 1, 8); break;
-      case 8: GQ_LAUNCH(8, 1, 8); break;
-      case 16: GQ_LAUNCH(16, 1, 8); break;
-      case 32: GQ_LAUNCH(32, 1, 4); break;
+      case 4: GQ_LAUNCH(4, 1, 8, 4); break;
+      case 8: GQ_LAUNCH(8, 1, 8, 4); break;
+      case 16: GQ_LAUNCH(16, 1, 8, 2); break;
+      case 32: GQ_LAUNCH(32, 1, 4, 2); break;
       default: return GQHIP_ERR_INVALID_ARG;
     }
   }
@@ -176,7 +178,7 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
   rp.idx = idx; rp.zhat = zhat; rp.hdr = hdr;
   rp.fb_list = reinterpret_cast<int *>(ws + w.fb);
   rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
-  rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
+  rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
 
   if (pl.mfma) {
