@@ -186,7 +186,7 @@ def main():
                          "algorithmic_flops_per_launch": flops},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(1)
+            line["cpu_baseline"] = cpu_baseline(4)   # ~10 s of host work
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -174,3 +174,34 @@ def test_config4_group_sweep_full_batch(cfg, c, group, rows_expected):
     mu_ref = zf[:, :, :c].reshape(16, 1024, group, K).permute(0, 1, 3, 2).reshape(-1, group)
     assert torch.equal(mu_r.cpu(), mu_ref)
     assert torch.equal(_lib.gq_dequant(idx, cb, group, "bchw", _lib.GQHIP_GROUP_STRIDED), zhat)
+
+
+def test_reference_smoke_loop_shape_max_size():
+    """The shape of the reference's own test loop (gq_cuda_extension/test/test_extension.py:10-14:
+    b = 1024*4*8*8 = 262 144 rows, dim 16, 65 536 codes -- a 64 GiB score matrix there, never
+    materialised here) plus the compat op on a slice of it; oracle on a strided sample."""
+    from pit_hip import _lib
+
+    dim, n, rows = 16, 65536, 1024 * 4 * 8 * 8
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(123)
+    noise = torch.randn(n, dim, generator=g)                      # the test's own codebook: randn
+    mu = torch.randn(rows, dim, generator=g)
+    sd = torch.abs(torch.randn(rows, dim, generator=g)) + 1e-3    # abs(randn) as in the loop (kept > 0)
+    ws = _lib.Workspace()
+    idx, zhat = _lib.gq_argmax(mu.to(dev), sd.to(dev), noise.to(dev), 1.0, ws=ws)
+    torch.cuda.synchronize()
+    fb, _ = _lib.debug_counters(ws)
+    assert idx.shape == (rows,) and int(idx.min()) >= 0 and int(idx.max()) < n
+    assert torch.equal(zhat.cpu(), noise[idx.cpu()])
+    sel = np.arange(0, rows, 1024)
+    lsd = np.log(sd.numpy()[sel].astype(np.float64)).astype(np.float32)
+    oi, _ = O.argmax_rows(mu.numpy()[sel], sd.numpy()[sel], noise.numpy(), 1.0, logstd=lsd)
+    assert np.array_equal(idx.cpu().numpy()[sel], oi)
+    assert fb < rows // 100, f"fallback rows {fb}"
+    # compat op on the first 64 rows: same arg-max wherever the top-2 gap is not a rounding tie
+    out = torch.zeros(64, n, device=dev)
+    _lib.gq_scores(mu[:64].to(dev), sd[:64].to(dev), noise.to(dev), out, 1.0)
+    ri, _, best, second = O.argmax_rows(mu.numpy()[:64], sd.numpy()[:64], noise.numpy(), 1.0, with_gap=True)
+    clear = (best - second) > 1e-3 * np.maximum(1.0, np.abs(best))
+    assert np.array_equal(out.argmax(1).cpu().numpy()[clear], ri[clear])
