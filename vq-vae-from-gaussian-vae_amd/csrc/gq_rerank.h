@@ -121,6 +121,19 @@ __device__ __forceinline__ double exact_score(const RerankParams &p, const RowOp
   }
 }
 
+// Out-of-line copy for the fp64 second stage: keeps the rarely taken exact evaluation out of the
+// register budget of its hot fp64 loops.
+template <int MODE>
+__device__ __attribute__((noinline)) double exact_score_cold(const float *cb, const RowOps *ro, int code, int dim,
+                                                             float beta) {
+  const float *n = cb + (long)code * dim;
+  if constexpr (MODE == kModeGQ) {
+    return (double)ref_score_ops(n, *ro, dim, beta);
+  } else {
+    return vq_neg_dist(n, ro->mu, dim);
+  }
+}
+
 // comparator on (double score, index) with torch.argmax semantics
 __device__ __forceinline__ bool better_d(double sa, int ia, double sb, int ib) {
   const bool na = sa != sa, nb = sb != sb;
@@ -239,6 +252,125 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   }
   if (p.stats && lane == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)total);
   write_result(p, row, best_i, lane);
+}
+
+// Second-stage filter for the rows the fp32 filter could not decide (fallback list).
+// When one sigma is tiny the expansion A n^2 + B n cancels catastrophically in fp32 and hundreds
+// of codes fall inside the fp32 margin; in fp64 the same expansion is accurate to ~1e-16 * T, so
+// the candidate window shrinks to the reference's OWN rounding noise around the maximum:
+//   |s_ref(j) - s(j)| <= c_u * (sum_i |t_ji| + R),  sum_i |t_ji| = C_r + (beta/2)|n_j|^2 - f(j)
+// (all t <= 0), i.e. for codes near the maximum it is small.  With g_j = fmax - f_j and
+// Q = C_r + beta*dim*N2/2 - fmax, a code can win only if g_j <= 2 c_u (Q + R) / (1 - c_u).
+// Pass 1: fp64 row maxima; pass 2: re-evaluate, exact reference-order score for the few codes
+// inside the window.  A block = 8 rows x 32 code lanes: a thread keeps its row's fp64 coefficients
+// in registers and walks every 32nd code, so the 8 rows of a block share each code row through L1.
+// Rows with non-finite operands get an infinite window = the exhaustive semantics.
+constexpr int kFallbackRows = 8;
+
+template <int MODE, int DIM>
+__global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParams p) {
+  constexpr int FR = kFallbackRows;
+  __shared__ RowOps rops[FR];
+  const int tid = threadIdx.x;
+  const int r = tid >> 5, cl = tid & 31;     // row slot, code lane (a half-wave per row)
+  const int count = p.hdr->fb_count;
+  const double INF = __builtin_inf();
+  for (int grp = blockIdx.x; grp * FR < count; grp += gridDim.x) {
+    const int nrow = min(FR, count - grp * FR);
+    const bool live = r < nrow;
+    const long row = live ? p.fb_list[grp * FR + r] : 0;
+    __syncthreads();
+    if (live && cl < DIM) load_row_ops(p, row, cl, rops[r]);
+    if (live && cl + 32 < DIM) load_row_ops(p, row, cl + 32, rops[r]);
+    __syncthreads();
+    // fp64 coefficients + the window constants of this thread's row (redundant per lane, cheap)
+    double cA[DIM], cB[DIM];
+    const double u = 5.9604644775390625e-08, N1 = (double)p.hdr->absmax, N2 = N1 * N1;
+    const double bb = fabs((double)p.beta), c = (double)half_log_2pi();
+    double Cr = 0.0, R = 0.0, T = 0.0;
+    bool bad = !live || !(N1 == N1) || N1 > 1e18;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const double m = live ? (double)rops[r].mu[i] : 0.0;
+      if constexpr (MODE == kModeGQ) {
+        const double sg = live ? (double)p.sd[row * DIM + i] : 1.0;
+        const double inv = 1.0 / (sg * sg);
+        cA[i] = 0.5 * (double)p.beta - 0.5 * inv;
+        cB[i] = m * inv;
+        Cr += 0.5 * m * m * inv;
+        R += fabs(live ? (double)rops[r].lsd[i] : 0.0) + c + bb * (0.5 * N2 + c);
+        T += (0.5 * bb + 0.5 * inv) * N2 + fabs(m) * inv * N1;
+        bad = bad || !(sg > 0.0) || !(inv < 1e300);
+      } else {
+        cA[i] = -1.0;
+        cB[i] = 2.0 * m;
+        T += N2 + 2.0 * fabs(m) * N1;
+      }
+    }
+    auto f64_of = [&](int j) {
+      const f32x4 *nj = reinterpret_cast<const f32x4 *>(p.cb + (long)j * DIM);
+      double f = 0.0;
+#pragma unroll
+      for (int q = 0; q < DIM / 4; ++q) {
+        const f32x4 v4 = nj[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double v = (double)v4[k];
+          f = fma(cA[4 * q + k], v * v, f);
+          f = fma(cB[4 * q + k], v, f);
+        }
+      }
+      return f;
+    };
+    // ---- pass 1: fp64 maximum of the row (over this lane's codes, then the half-wave) ----
+    double fmax = -INF;
+    if (live)
+      for (int j = cl; j < p.n; j += 32) {
+        const double f = f64_of(j);
+        fmax = f > fmax ? f : fmax;          // NaN never enters
+      }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const double of = __shfl_xor(fmax, o);
+      fmax = of > fmax ? of : fmax;
+    }
+    double marg;
+    if constexpr (MODE == kModeGQ) {
+      const double cu = (DIM + 16.0) * u;
+      double Q = Cr + 0.5 * bb * DIM * N2 - fmax;
+      Q = Q > 0.0 ? Q : 0.0;
+      marg = 2.5 * cu * (Q + R) / (1.0 - cu) + 1e-12 * T + 1e-30;
+    } else {
+      marg = 1e-11 * T + 1e-30;
+    }
+    bad = bad || !(fmax > -INF) || !(fmax < INF) || !(T < 1e300) || !(marg < 1e300);
+    const double thr = bad ? -INF : fmax - marg;
+    // ---- pass 2: exact reference-order scores inside the window ----------------------------
+    double best_s = 0.0;
+    int best_i = 0x7fffffff;
+    bool have = false;
+    if (live)
+      for (int j = cl; j < p.n; j += 32) {
+        if (bad || f64_of(j) >= thr) {
+          const double s = exact_score_cold<MODE>(p.cb, &rops[r], j, DIM, p.beta);
+          if (!have || better_d(s, j, best_s, best_i)) { best_s = s; best_i = j; have = true; }
+        }
+      }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const double os = __shfl_xor(best_s, o);
+      const int oi = __shfl_xor(best_i, o);
+      const bool oh = __shfl_xor((int)have, o) != 0;
+      if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+    }
+    if (live) {
+      if (cl == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best_i;
+      if (p.zhat) {
+        if (cl < DIM) p.zhat[out_zhat_offset(p.omap, row, cl, DIM)] = p.cb[(long)best_i * DIM + cl];
+        if (cl + 32 < DIM) p.zhat[out_zhat_offset(p.omap, row, cl + 32, DIM)] = p.cb[(long)best_i * DIM + cl + 32];
+      }
+    }
+  }
 }
 
 // Exhaustive exact arg-max: one block per listed row (grid-stride over the

@@ -197,9 +197,20 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
     rc = check_launch();
     if (rc != GQHIP_OK) return rc;
   }
-  if (!pl.mfma && hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
-  const int ex_cap = pl.mfma ? 256 : 4096;
-  const int ex_blocks = (int)(rows < ex_cap ? rows : ex_cap);
+  if (pl.mfma) {
+    // rows the fp32 filter could not decide: fp64 second-stage filter + exact re-rank (usually none)
+    const int64_t groups = (rows + kFallbackRows - 1) / kFallbackRows;
+    const int fb_blocks = (int)(groups < 2048 ? groups : 2048);
+    switch (dim) {
+      case 4: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 4>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
+      case 8: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 8>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
+      case 16: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 16>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
+      default: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 32>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
+    }
+    return check_launch();
+  }
+  if (hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
+  const int ex_blocks = (int)(rows < 4096 ? rows : 4096);
   hipLaunchKernelGGL((gq_exhaustive_kernel<MODE>), dim3((unsigned)ex_blocks), dim3(256), 0, st, rp);
   return check_launch();
 }
