@@ -112,31 +112,87 @@ __global__ __launch_bounds__(256) void dequant_kernel(const DequantParams p) {
 // 1 KiB coalesced runs along n.  The running sum is a float; `iv*iv` is
 // contracted into the subtraction (nvcc's default -fmad), and the beta term is
 // accumulated through double exactly as the CUDA source spells it.
-template <int DIM, int ROWS>
+// Division: iv = (n - mu) / sd is an IEEE fp32 divide in the CUDA source.  A hardware divide costs
+// ~10 VALU instructions per (row, code, dim); instead the correctly rounded reciprocal y = RN(1/sd)
+// is formed once per (row, dim) and each quotient is q = a*y, r = fma(-sd, q, a), q' = fma(r, y, q)
+// (Markstein: with y correctly rounded and no over/underflow, q' = RN(a/sd)).  Rows whose sd (or
+// whose numerators) could leave the safe exponent range take the hardware divide instead.
+// BETA1: beta == 1.0 -- (float)((double)acc + (double)co2) equals the fp32 add acc + co2 exactly
+// (double rounding is innocuous for the sum of two floats), so the fp64 detour is dropped.
+template <int DIM, int ROWS, bool BETA1>
 __global__ __launch_bounds__(256) void gq_scores_kernel(const float *__restrict__ mu,
                                                         const float *__restrict__ sd,
                                                         const float *__restrict__ cb,
                                                         float *__restrict__ out, int rows, int n,
                                                         double beta) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const int jc = j < n ? j : n - 1;
-  float nv[DIM];
-  double nb[DIM];
-#pragma unroll
-  for (int i = 0; i < DIM; ++i) {
-    nv[i] = cb[(long)jc * DIM + i];
-    nb[i] = (double)(nv[i] * nv[i]) * beta;
-  }
+#pragma clang fp contract(off)
+  constexpr int CPT = 1;   // codes per thread (2 measured slower: the kernel is VALU-bound, not LDS-bound)
+  __shared__ float s_mu[ROWS][DIM], s_sd[ROWS][DIM], s_y[ROWS][DIM];
+  __shared__ int s_fast[ROWS];
+  const int j0 = blockIdx.x * (256 * CPT) + threadIdx.x;
   const int r0 = blockIdx.y * ROWS;
-  for (int r = r0; r < r0 + ROWS && r < rows; ++r) {
-    float acc = 0.0f;
+  if (threadIdx.x < ROWS) s_fast[threadIdx.x] = 1;
+  __syncthreads();
+  for (int t = threadIdx.x; t < ROWS * DIM; t += 256) {
+    const int r = t / DIM, i = t % DIM;
+    const int rr = r0 + r < rows ? r0 + r : rows - 1;
+    const float m = mu[(long)rr * DIM + i], s = sd[(long)rr * DIM + i];
+    s_mu[r][i] = m;
+    s_sd[r][i] = s;
+    s_y[r][i] = __fdiv_rn(1.0f, s);
+    const float as = fabsf(s), am = fabsf(m);
+    if (!(as > 1e-18f && as < 1e18f && am < 1e18f)) s_fast[r] = 0;   // also catches NaN
+  }
+  float nv[CPT][DIM], n2[CPT][DIM];
+  float amax = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int j = j0 + 256 * k;
+    const int jc = j < n ? j : n - 1;
 #pragma unroll
     for (int i = 0; i < DIM; ++i) {
-      const float iv = __fdiv_rn(nv[i] - mu[(long)r * DIM + i], sd[(long)r * DIM + i]);
-      acc = __builtin_fmaf(-iv, iv, acc);
-      acc = (float)((double)acc + nb[i]);
+      nv[k][i] = cb[(long)jc * DIM + i];
+      n2[k][i] = nv[k][i] * nv[k][i];
+      amax = __builtin_fmaxf(amax, fabsf(nv[k][i]));
     }
-    if (j < n) out[(long)r * n + j] = acc;
+  }
+  const bool code_ok = amax < 1e18f;   // false for inf / NaN codes too
+  __syncthreads();
+  for (int r = 0; r < ROWS && r0 + r < rows; ++r) {
+    float acc[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) acc[k] = 0.0f;
+    if (s_fast[r] && __all(code_ok)) {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        const float m = s_mu[r][i], sg = s_sd[r][i], y = s_y[r][i];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          const float a = nv[k][i] - m;
+          const float q = a * y;
+          const float rem = __builtin_fmaf(-sg, q, a);
+          const float iv = __builtin_fmaf(rem, y, q);
+          acc[k] = __builtin_fmaf(-iv, iv, acc[k]);
+          if constexpr (BETA1) acc[k] = acc[k] + n2[k][i];
+          else acc[k] = (float)((double)acc[k] + (double)n2[k][i] * beta);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          const float iv = __fdiv_rn(nv[k][i] - s_mu[r][i], s_sd[r][i]);
+          acc[k] = __builtin_fmaf(-iv, iv, acc[k]);
+          acc[k] = (float)((double)acc[k] + (double)n2[k][i] * beta);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int j = j0 + 256 * k;
+      if (j < n) out[(long)(r0 + r) * n + j] = acc[k];
+    }
   }
 }
 

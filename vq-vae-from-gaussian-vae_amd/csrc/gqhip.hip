@@ -256,20 +256,27 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
   if (rows == 0) return GQHIP_OK;
   if (!mu || !sd || !cb || !out) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned gx = (unsigned)((n + 255) / 256);
+  const int cpt = 1;   // codes per thread of gq_scores_kernel (CPT there)
+  const unsigned gx = (unsigned)((n + 256 * cpt - 1) / (256 * cpt));
   constexpr int ROWS = 16;
   const unsigned gy = (unsigned)((rows + ROWS - 1) / ROWS);
   if (gy > 65535u * 32u) return GQHIP_ERR_INVALID_ARG;
-#define GQ_SC(D)                                                                                   \
-  hipLaunchKernelGGL((gq_scores_kernel<D, ROWS>), dim3(gx, gy), dim3(256), 0, st, mu, sd, cb, out, \
-                     (int)rows, (int)n, beta)
+#define GQ_SC(D)                                                                                          \
+  do {                                                                                                    \
+    if (beta == 1.0)                                                                                      \
+      hipLaunchKernelGGL((gq_scores_kernel<D, ROWS, true>), dim3(gx, gy), dim3(256), 0, st, mu, sd, cb, out, \
+                         (int)rows, (int)n, beta);                                                        \
+    else                                                                                                  \
+      hipLaunchKernelGGL((gq_scores_kernel<D, ROWS, false>), dim3(gx, gy), dim3(256), 0, st, mu, sd, cb, out, \
+                         (int)rows, (int)n, beta);                                                        \
+  } while (0)
   switch (dim) {
     case 4: GQ_SC(4); break;
     case 8: GQ_SC(8); break;
     case 16: GQ_SC(16); break;
     case 32: GQ_SC(32); break;
     default:
-      hipLaunchKernelGGL(gq_scores_generic_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, mu, sd, cb,
+      hipLaunchKernelGGL(gq_scores_generic_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, st, mu, sd, cb,
                          out, (int)dim, (int)rows, (int)n, beta);
   }
 #undef GQ_SC
