@@ -63,9 +63,6 @@ __device__ __forceinline__ void lds_read_half(const float *p, float (&a)[HD]) {
 
 // Running maximum over the 16 accumulators of a lane, seeded with t0: 8 v_max3.
 __device__ __forceinline__ float max_chain(float t0, const f32x16 &d) {
-#ifdef GQHIP_ABLATE_EPI   // diagnostic only: price the 7 other v_max3 of the chain
-  return __builtin_fmaxf(__builtin_fmaxf(t0, d[0]), d[15]);
-#endif
   float t = __builtin_fmaxf(__builtin_fmaxf(t0, d[0]), d[1]);
   t = __builtin_fmaxf(__builtin_fmaxf(t, d[2]), d[3]);
   t = __builtin_fmaxf(__builtin_fmaxf(t, d[4]), d[5]);
@@ -104,8 +101,8 @@ __device__ __forceinline__ void tile_mfma(const float (&a)[DIM / 2], const float
 // fp32 MFMA and VALU share the SIMD's fp32 datapath on gfx950 (measured: every VALU
 // instruction next to a v_mfma_f32_32x32x2_f32 stream costs ~4.4 matrix-pipe cycles,
 // tools/mfma_peak.hip), so the epilogue is kept to the minimum instruction count:
-// 8 v_max3 per 16-MFMA chain, and ONE top-3 update per PAIR of tiles (a candidate
-// "half-pair" = the 2 x 16 codes a lane saw in tiles 2p and 2p+1).  The main loop is
+// 8 v_max3 per 16-MFMA chain, and ONE top-3 update per GROUP of GT tiles (a candidate
+// "half-group" = the GT x 16 codes a lane saw in tiles GT*p .. GT*p+GT-1).  The main loop is
 // software pipelined so that nothing but those VALU instructions ever keeps the
 // matrix pipe waiting: the LDS operands of tile t+1 are fetched before the MFMAs of
 // tile t, and the epilogue of tile t-1 runs as ONE cluster right after the first
@@ -189,17 +186,8 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     }
   };
   auto read_ops = [&](const float *val, const float *sq, float (&a)[HD], float (&a2)[HD]) {
-#ifdef GQHIP_ABLATE_LDS   // diagnostic only: operands stay in registers (opaque to the optimiser), no LDS reads
-#pragma unroll
-    for (int s = 0; s < HD; ++s) {
-      a[s] = coefB[0][s];
-      a2[s] = coefA[0][s];
-      asm volatile("" : "+v"(a[s]), "+v"(a2[s]));
-    }
-#else
     lds_read_half<HD>(val, a);
     lds_read_half<HD>(sq, a2);
-#endif
   };
   auto close_pair = [&](int tile) {   // after the last tile of a group of GT tiles (or a lone last tile)
 #pragma unroll
@@ -208,11 +196,11 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
       tpend[rt] = NEG_INF;
     }
   };
-  // epilogue of a finished tile: fold its accumulators into the pending pair maximum
-  auto fold = [&](f32x16 (&d)[RT], int tile, bool odd) {
+  // epilogue of a finished tile: fold its accumulators into the pending group maximum
+  auto fold = [&](f32x16 (&d)[RT], int tile, bool closes) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) tpend[rt] = max_chain(tpend[rt], d[rt]);
-    if (odd) close_pair(tile);
+    if (closes) close_pair(tile);
   };
 
   const int ntiles = t_full_end - t_begin;
@@ -232,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dprev[rt][r] = NEG_INF;   // neutral element
-  int tprev = t_begin - 1;          // odd -> its (no-op) epilogue closes an empty pair
+  int tprev = t_begin - 1;          // its (no-op) epilogue closes an empty group: inserts -inf
   bool have_prev = false;           // dprev holds a real tile whose epilogue is still pending
 
   for (int ch = 0; ch < nchunks; ++ch) {
