@@ -271,23 +271,31 @@ template <int MODE, int DIM>
 __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParams p) {
   constexpr int FR = kFallbackRows;
   __shared__ RowOps rops[FR];
+  __shared__ double sh_d[8];
+  __shared__ int sh_i[8];
   const int tid = threadIdx.x;
-  const int r = tid >> 5, cl = tid & 31;     // row slot, code lane (a half-wave per row)
   const int count = p.hdr->fb_count;
+  // Many listed rows: 8 rows per block (a half-wave each).  Few: the whole block on ONE row, so a
+  // lone fallback row costs ~60 us instead of ~3 ms.
+  const bool wide = count < 4 * (int)gridDim.x;       // block-uniform
+  const int R = wide ? 1 : FR;
+  const int r = wide ? 0 : tid >> 5;                   // row slot
+  const int cl = wide ? tid : tid & 31;                // code lane
+  const int cstride = wide ? 256 : 32;
   const double INF = __builtin_inf();
-  for (int grp = blockIdx.x; grp * FR < count; grp += gridDim.x) {
-    const int nrow = min(FR, count - grp * FR);
+  for (int grp = blockIdx.x; grp * R < count; grp += gridDim.x) {
+    const int nrow = min(R, count - grp * R);
     const bool live = r < nrow;
-    const long row = live ? p.fb_list[grp * FR + r] : 0;
+    const long row = live ? p.fb_list[grp * R + r] : 0;
     __syncthreads();
-    if (live && cl < DIM) load_row_ops(p, row, cl, rops[r]);
-    if (live && cl + 32 < DIM) load_row_ops(p, row, cl + 32, rops[r]);
+    if (live && (tid & 31) < DIM && (wide ? tid < 32 : true)) load_row_ops(p, row, tid & 31, rops[r]);
+    if (live && (tid & 31) + 32 < DIM && (wide ? tid < 32 : true)) load_row_ops(p, row, (tid & 31) + 32, rops[r]);
     __syncthreads();
     // fp64 coefficients + the window constants of this thread's row (redundant per lane, cheap)
     double cA[DIM], cB[DIM];
     const double u = 5.9604644775390625e-08, N1 = (double)p.hdr->absmax, N2 = N1 * N1;
     const double bb = fabs((double)p.beta), c = (double)half_log_2pi();
-    double Cr = 0.0, R = 0.0, T = 0.0;
+    double Cr = 0.0, R0 = 0.0, T = 0.0;
     bool bad = !live || !(N1 == N1) || N1 > 1e18;
 #pragma unroll
     for (int i = 0; i < DIM; ++i) {
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
         cA[i] = 0.5 * (double)p.beta - 0.5 * inv;
         cB[i] = m * inv;
         Cr += 0.5 * m * m * inv;
-        R += fabs(live ? (double)rops[r].lsd[i] : 0.0) + c + bb * (0.5 * N2 + c);
+        R0 += fabs(live ? (double)rops[r].lsd[i] : 0.0) + c + bb * (0.5 * N2 + c);
         T += (0.5 * bb + 0.5 * inv) * N2 + fabs(m) * inv * N1;
         bad = bad || !(sg > 0.0) || !(inv < 1e300);
       } else {
@@ -322,10 +330,10 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
       }
       return f;
     };
-    // ---- pass 1: fp64 maximum of the row (over this lane's codes, then the half-wave) ----
+    // ---- pass 1: fp64 maximum of the row --------------------------------------------------
     double fmax = -INF;
     if (live)
-      for (int j = cl; j < p.n; j += 32) {
+      for (int j = cl; j < p.n; j += cstride) {
         const double f = f64_of(j);
         fmax = f > fmax ? f : fmax;          // NaN never enters
       }
@@ -334,12 +342,19 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
       const double of = __shfl_xor(fmax, o);
       fmax = of > fmax ? of : fmax;
     }
+    if (wide) {                               // combine the block's 8 half-waves
+      if ((tid & 31) == 0) sh_d[tid >> 5] = fmax;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fmax = sh_d[k] > fmax ? sh_d[k] : fmax;
+      __syncthreads();
+    }
     double marg;
     if constexpr (MODE == kModeGQ) {
       const double cu = (DIM + 16.0) * u;
       double Q = Cr + 0.5 * bb * DIM * N2 - fmax;
       Q = Q > 0.0 ? Q : 0.0;
-      marg = 2.5 * cu * (Q + R) / (1.0 - cu) + 1e-12 * T + 1e-30;
+      marg = 2.5 * cu * (Q + R0) / (1.0 - cu) + 1e-12 * T + 1e-30;
     } else {
       marg = 1e-11 * T + 1e-30;
     }
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
     int best_i = 0x7fffffff;
     bool have = false;
     if (live)
-      for (int j = cl; j < p.n; j += 32) {
+      for (int j = cl; j < p.n; j += cstride) {
         if (bad || f64_of(j) >= thr) {
           const double s = exact_score_cold<MODE>(p.cb, &rops[r], j, DIM, p.beta);
           if (!have || better_d(s, j, best_s, best_i)) { best_s = s; best_i = j; have = true; }
@@ -363,12 +378,24 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
       const bool oh = __shfl_xor((int)have, o) != 0;
       if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
     }
-    if (live) {
-      if (cl == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best_i;
-      if (p.zhat) {
-        if (cl < DIM) p.zhat[out_zhat_offset(p.omap, row, cl, DIM)] = p.cb[(long)best_i * DIM + cl];
-        if (cl + 32 < DIM) p.zhat[out_zhat_offset(p.omap, row, cl + 32, DIM)] = p.cb[(long)best_i * DIM + cl + 32];
+    if (wide) {
+      if ((tid & 31) == 0) { sh_d[tid >> 5] = best_s; sh_i[tid >> 5] = have ? best_i : 0x7fffffff; }
+      __syncthreads();
+      have = false;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double os = sh_d[k];
+        const int oi = sh_i[k];
+        if (oi != 0x7fffffff && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
       }
+      __syncthreads();
+    }
+    const int ol = wide ? tid : tid & 31;     // output lane
+    if (live && (wide ? tid < 64 : true)) {
+      if (ol == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best_i;
+      if (p.zhat && ol < DIM) p.zhat[out_zhat_offset(p.omap, row, ol, DIM)] = p.cb[(long)best_i * DIM + ol];
+      if (!wide && p.zhat && ol + 32 < DIM)
+        p.zhat[out_zhat_offset(p.omap, row, ol + 32, DIM)] = p.cb[(long)best_i * DIM + ol + 32];
     }
   }
 }
