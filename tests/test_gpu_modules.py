@@ -381,3 +381,35 @@ def test_unet_channels_last_matches_nchw():
         z2 = enc_cl(x.contiguous(memory_format=torch.channels_last)); r2 = dec_cl(z2[:, :16].contiguous())
     torch.testing.assert_close(z1, z2, atol=2e-4, rtol=2e-4)
     torch.testing.assert_close(r1, r2, atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("z_channels,K", [(16, 1), (32, 2)])
+def test_gq2_shipped_config_and_flagged_k2_variant(z_channels, K):
+    """BASELINE config 4: configs/sd3unet_gq2_0.25.yaml (dim 16, codebook 65536, z_channels 16 -> K = 1
+    as shipped) and the flagged K = 2 variant (z_channels 32); module vs oracle restatement of
+    GaussianQuantRegularizer2.quant_vq (contiguous channel groups) on 2 images, bit-exact operands path."""
+    from pit_hip import _lib
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
+
+    q2 = GaussianQuantRegularizer2(dim=16, codebook_size=65536, backend="cuda").eval().to(DEV)
+    q2.backend = "hip"
+    g = torch.Generator().manual_seed(40 + K)
+    c = z_channels
+    z = torch.cat([0.9 * torch.randn(2, c, 32, 32, generator=g), -1.5 + 0.3 * torch.randn(2, c, 32, 32, generator=g)], 1)
+    zhat, info = q2(z.to(DEV))
+    ind = info["indices"]
+    assert ind.shape == (2, K, 32, 32) and zhat.shape == (2, c, 32, 32)
+    assert torch.equal(q2.dequant(ind), info["zhat_quant"])
+    # operands the kernels derived (position-major rows, contiguous groups) through the oracle
+    zf = z.permute(0, 2, 3, 1).reshape(1, -1, 2 * c).contiguous()
+    idx2, _, mu_r, sd_r = _lib.gq_quantize_z(zf.to(DEV), q2.prior_samples, 16, "blc", _lib.GQHIP_GROUP_CONTIGUOUS,
+                                             return_operands=True)
+    assert torch.equal(idx2.reshape(2, 32, 32, K).permute(0, 3, 1, 2), ind)
+    sdn = sd_r.cpu().numpy()
+    sel = np.arange(0, sdn.shape[0], 4)
+    oi, _ = O.argmax_rows(mu_r.cpu().numpy()[sel], sdn[sel], q2.prior_samples.cpu().numpy(), 1.0,
+                          logstd=np.log(sdn[sel].astype(np.float64)).astype(np.float32))
+    assert np.array_equal(idx2.reshape(-1).cpu().numpy()[sel], oi)
+    # contiguous grouping: sub-codebook k <- channels [k*16, (k+1)*16)
+    mu_ref = z[:, :c].permute(0, 2, 3, 1).reshape(-1, K, 16).reshape(-1, 16)
+    assert torch.equal(mu_r.cpu(), mu_ref)
