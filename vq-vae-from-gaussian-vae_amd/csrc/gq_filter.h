@@ -47,16 +47,31 @@ struct FilterParams {
   void *dbg;            // diagnostic builds only
 };
 
-template <int HD>
-__device__ __forceinline__ void lds_read_half(const float *p, float (&a)[HD]) {
+// LDS image of a chunk: code rows of DIM floats = DIM/4 slots of 16 bytes.  Row-major rows of
+// 32/64/128 bytes make the lanes of a ds_read_b128 group hit the same banks (4-way at DIM 16);
+// slot s of code c is therefore stored at slot  s ^ swz(c)  (an involution, applied by the
+// register-staged writer and by the readers), which spreads a lane group over all 64 banks.
+template <int DIM>
+__device__ __forceinline__ int lds_swz(int code) {
+  if constexpr (DIM == 32) return (code >> 1) & 7;
+  else if constexpr (DIM == 16) return (code >> 2) & 3;
+  else if constexpr (DIM == 8) return (code >> 3) & 1;
+  else return 0;
+}
+
+// the HD floats of lane half h of code row `c` (row base `row` = tile base + c*DIM floats)
+template <int DIM>
+__device__ __forceinline__ void lds_read_half(const float *row, int h, int x, float (&a)[DIM / 2]) {
+  constexpr int HD = DIM / 2;
   if constexpr (HD >= 4) {
 #pragma unroll
     for (int q = 0; q < HD / 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+      const int slot = (h * (HD / 4) + q) ^ x;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 4 * slot);
       a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
     }
   } else {
-    const f32x2 v = *reinterpret_cast<const f32x2 *>(p);
+    const f32x2 v = *reinterpret_cast<const f32x2 *>(row + h * HD);
     a[0] = v.x; a[1] = v.y;
   }
 }
@@ -179,15 +194,20 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     }
   };
   auto store_chunk = [&](int buf) {
+    constexpr int SLOTS = DIM / 4;              // 16-byte slots per code row
 #pragma unroll
     for (int r = 0; r < R4; ++r) {
-      *reinterpret_cast<f32x4 *>(&lds[buf][0][(tid + 256 * r) * 4]) = stage[r];
-      *reinterpret_cast<f32x4 *>(&lds[buf][1][(tid + 256 * r) * 4]) = stage[r] * stage[r];
+      const int q = tid + 256 * r;              // linear slot index within the chunk
+      const int code = q / SLOTS, slot = q % SLOTS;
+      const int dst = (code * SLOTS + (slot ^ lds_swz<DIM>(code))) * 4;
+      *reinterpret_cast<f32x4 *>(&lds[buf][0][dst]) = stage[r];
+      *reinterpret_cast<f32x4 *>(&lds[buf][1][dst]) = stage[r] * stage[r];
     }
   };
+  const int swz = lds_swz<DIM>(c);              // tiles start at multiples of 32 codes: swz(code) = swz(c)
   auto read_ops = [&](const float *val, const float *sq, float (&a)[HD], float (&a2)[HD]) {
-    lds_read_half<HD>(val, a);
-    lds_read_half<HD>(sq, a2);
+    lds_read_half<DIM>(val, h, swz, a);
+    lds_read_half<DIM>(sq, h, swz, a2);
   };
   auto close_pair = [&](int tile) {   // after the last tile of a group of GT tiles (or a lone last tile)
 #pragma unroll
@@ -227,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     const int tile0 = t_begin + ch * CT;
     if (ch + 1 < nchunks) load_chunk(tile0 + CT);
     const int nt = min(CT, t_full_end - tile0);
-    const float *val = lds[ch & 1][0] + c * DIM + h * HD;
-    const float *sq = lds[ch & 1][1] + c * DIM + h * HD;
+    const float *val = lds[ch & 1][0] + c * DIM;   // this lane's code row within a tile
+    const float *sq = lds[ch & 1][1] + c * DIM;
     if (nt == CT) {
       float a[HD], a2[HD];
       read_ops(val, sq, a, a2);
