@@ -209,6 +209,16 @@ def test_engine_end_to_end_full_config():
     mse = float(((rec.cpu() - ref) ** 2).mean())
     assert 10 * np.log10(4.0 / max(mse, 1e-20)) >= 40.0
     assert torch.equal(rec, rec2) and torch.equal(z, z2) and torch.equal(log["indices"], ind)
+    # the bench configuration: channels_last conv stack (NHWC fused kernels) -- same tolerances
+    vae_cl = vae.to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        z_cl, ind_cl = vae_cl.quant(x.contiguous(memory_format=torch.channels_last))
+        rec_cl = vae_cl.dequant(ind_cl)
+    diff_cl = _rows_from_bchw(ind_cl.cpu().numpy()) != _rows_from_bchw(want)
+    assert diff_cl.mean() < 0.02 and np.all(d["gap"][diff_cl] < 1e-2)
+    mse_cl = float(((rec_cl.cpu() - ref) ** 2).mean())
+    assert 10 * np.log10(4.0 / max(mse_cl, 1e-20)) >= 40.0
+    vae = vae_cl.to(memory_format=torch.contiguous_format)
     # golden z_enc fed straight to the GPU quantiser: indices must match the reference (rounding ties aside)
     zhat, info = vae.regularization(torch.from_numpy(d["z_enc"]).to(DEV))
     diff2 = _rows_from_bchw(info["indices"].cpu().numpy()) != _rows_from_bchw(want)
