@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) for real runs; gloo only to exercise the N>1 control flow on one GPU")
     ap.add_argument("--miopen-benchmark", type=int, default=int(os.environ.get("GQ_MIOPEN_BENCHMARK", "0")))
     ap.add_argument("--channels-last", type=int, default=int(os.environ.get("GQ_CHANNELS_LAST", "1")),
                     help="1: conv stack in torch channels_last (NHWC) -- MIOpen's fp32 igemm kernels run without the "
@@ -111,10 +113,10 @@ def main():
     from pit_hip import _lib
     from pit_hip.eval_dist import StepRecord, gather_step, init_from_env, psnr_zero_mean
 
-    env = init_from_env("nccl")
+    env = init_from_env(args.dist_backend)
     rank, world = env["rank"], env["world"]
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    device = torch.device("cuda", env["local_rank"])
+    device = torch.device("cuda", env["local_rank"] % torch.cuda.device_count())
     torch.cuda.set_device(device)
     # 0 = MIOpen immediate mode (measured: same steady-state img/s as find mode, 35 s vs 248 s of warm-up on a
     # fresh box); 1 = find mode like the reference's trainer.benchmark: True
@@ -153,7 +155,7 @@ def main():
     launches, kernel_ms = _lib.profile_collect()
     _lib.profile_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -64,8 +64,8 @@ def init_from_env(backend: Optional[str] = None) -> Dict[str, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -114,6 +114,10 @@ def gather_step(rec: torch.Tensor, world: int) -> torch.Tensor:
     if world == 1:
         return rec[None]
     rec = rec.reshape(-1)
+    if rec.is_cuda and dist.get_backend() == "gloo":   # debug configuration: gloo gathers through the host
+        host = torch.empty(world * rec.numel(), dtype=rec.dtype)
+        dist.all_gather_into_tensor(host, rec.cpu())
+        return host.to(rec.device).reshape(world, -1)
     out = torch.empty(world * rec.numel(), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec)  # concatenated along dim 0 (works on RCCL and gloo)
     return out.reshape(world, -1)
