@@ -423,3 +423,31 @@ def test_gq2_shipped_config_and_flagged_k2_variant(z_channels, K):
     # contiguous grouping: sub-codebook k <- channels [k*16, (k+1)*16)
     mu_ref = z[:, :c].permute(0, 2, 3, 1).reshape(-1, K, 16).reshape(-1, 16)
     assert torch.equal(mu_r.cpu(), mu_ref)
+
+
+def test_quantizer_is_hip_graph_capturable():
+    """The C-ABI entry points never synchronise or allocate, so the fused quantiser (prep -> filter -> re-rank ->
+    fallback) can be captured in a HIP graph and replayed on new data."""
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer
+
+    q = GaussianQuantRegularizer("bchw", 65536, group=16, backend="hip").eval().to(DEV)
+    g = torch.Generator().manual_seed(77)
+    mk = lambda: torch.cat([0.9 * torch.randn(2, 16, 32, 32, generator=g), -1.5 + 0.3 * torch.randn(2, 16, 32, 32, generator=g)], 1)
+    z_static = mk().to(DEV)
+    from pit_hip import _lib
+
+    run = lambda: _lib.gq_quantize_z(z_static, q.prior_samples, 16, "bchw", _lib.GQHIP_GROUP_STRIDED,
+                                     absmax=q._absmax, ws=q._ws)
+    run()  # warm-up: sizes the workspace outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        idx_g, zhat_g = run()
+    for _ in range(3):
+        z_new = mk().to(DEV)
+        z_static.copy_(z_new)
+        graph.replay()
+        torch.cuda.synchronize()
+        idx_e, zhat_e = _lib.gq_quantize_z(z_new, q.prior_samples, 16, "bchw", _lib.GQHIP_GROUP_STRIDED,
+                                           absmax=q._absmax)
+        assert torch.equal(idx_g, idx_e) and torch.equal(zhat_g, zhat_e)
