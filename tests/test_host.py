@@ -202,3 +202,18 @@ def test_simple_dataset_transform_semantics(tmp_path):
     lst = tmp_path / "list.txt"
     lst.write_text(str(tmp_path / "a.png") + "\n")
     assert len(SimpleDataset(str(lst), 32)) == 1
+
+
+def test_unet_autograd_path_on_cpu():
+    """Outside no_grad (training / fine-tuning) the conv stack stays on ATen ops and is differentiable."""
+    from pit_hip.modules.unet import Decoder, Encoder
+
+    torch.manual_seed(0)
+    enc, dec = Encoder(**SMALL), Decoder(**SMALL)
+    x = torch.rand(1, 3, 32, 32) * 2 - 1
+    z = enc(x)
+    rec = dec(z[:, :16])
+    rec.mean().backward()
+    assert enc.conv_in.weight.grad is not None and dec.conv_out.weight.grad is not None
+    with torch.no_grad():
+        torch.testing.assert_close(enc(x), z.detach(), atol=1e-6, rtol=1e-6)  # same function either way
