@@ -170,7 +170,8 @@ def main():
     # compiling the same kernels concurrently on a fresh box serialise on that cache (measured: 186 s vs 33 s).
     def init_pass():
         with torch.no_grad():
-            vae.decode(vae.encode(x))
+            zhat, info = vae.encode(x, return_reg_log=True)
+            layout.pack(info["indices"], psnr_zero_mean(x, vae.decode(zhat))[:, None])
         torch.cuda.synchronize()
 
     if world > 1:
@@ -182,6 +183,8 @@ def main():
         dist.barrier()
     else:
         init_pass()
+    step()   # and one complete step (incl. the gather) so that even --warmup 0 times steady-state steps
+    sync()
     for _ in range(args.warmup):
         step()
     sync()
