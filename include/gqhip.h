@@ -153,6 +153,11 @@ int gn_silu_f32(const float *x, const float *gamma, const float *beta,
 int add_bias_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B,
                  int64_t C, int64_t HW, int layout, void *stream);
 
+/* Nearest-neighbour x2 upsample of an NHWC fp32 tensor: x [B, H, W, C] -> y [B, 2H, 2W, C], C % 4 == 0
+ * (pit/modules/unet.py:69-73, `F.interpolate(scale_factor=2.0, mode="nearest")` in channels_last). */
+int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t W, int64_t C,
+                        void *stream);
+
 /* ---- index wire format / usage histogram ----------------------------------- */
 int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n,
                        int32_t *hist, void *stream);

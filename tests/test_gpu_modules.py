@@ -451,3 +451,13 @@ def test_quantizer_is_hip_graph_capturable():
         idx_e, zhat_e = _lib.gq_quantize_z(z_new, q.prior_samples, 16, "bchw", _lib.GQHIP_GROUP_STRIDED,
                                            absmax=q._absmax)
         assert torch.equal(idx_g, idx_e) and torch.equal(zhat_g, zhat_e)
+
+
+def test_upsample2x_nhwc_matches_interpolate():
+    import torch.nn.functional as F
+    from pit_hip import _lib
+
+    x = torch.randn(2, 64, 5, 7).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _lib.upsample2x_nhwc(x)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y, F.interpolate(x, scale_factor=2.0, mode="nearest"))

@@ -321,6 +321,26 @@ __global__ __launch_bounds__(256) void add_bias_nhwc_kernel(const float *__restr
   }
 }
 
+// Nearest-neighbour x2 upsample, NHWC (unet.py:69-73 `interpolate(scale_factor=2, mode="nearest")`):
+// one thread per (input pixel, channel quad); the 16-byte value is written to the 2x2 output pixels.
+__global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                              int H, int W, int C4, long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q = (int)(t % C4);
+    long p = t / C4;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const long b = p / H;
+    const f32x4 v = reinterpret_cast<const f32x4 *>(x)[t];
+    f32x4 *o = reinterpret_cast<f32x4 *>(y) + ((b * 2 * H + 2 * h) * (2L * W) + 2 * w) * C4 + q;
+    o[0] = v;
+    o[C4] = v;
+    o[2L * W * C4] = v;
+    o[2L * W * C4 + C4] = v;
+  }
+}
+
 // y = a + b (+ bias[c]): the residual add of a ResnetBlock with the pending conv biases folded in.
 __global__ __launch_bounds__(256) void add_bias_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                        const float *__restrict__ bias, float *__restrict__ y, int C,

@@ -438,6 +438,18 @@ int add_bias_f32(const float *a, const float *b, const float *bias_or_null, floa
   return check_launch();
 }
 
+int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
+  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !y) return GQHIP_ERR_INVALID_ARG;
+  const long total = (long)(B * H * W * (C / 4));
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     y, (int)H, (int)W, (int)(C / 4), total);
+  return check_launch();
+}
+
 static int fsq_levels(const int32_t *levels_host, int64_t nlev, FsqLevels *L) {
   if (!levels_host || nlev < 1 || nlev > 16) return GQHIP_ERR_INVALID_ARG;
   L->n = (int)nlev;

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "fsq_dequant_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _i64, _vp]),
     "gn_silu_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int,
                                    ctypes.c_int, _vp, _vp]),
+    "upsample2x_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -332,6 +333,17 @@ def add_bias(a, b, bias=None):
     with torch.cuda.device(a.device):
         _check(lib().add_bias_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, layout, _stream()),
                "add_bias_f32")
+    return y
+
+
+def upsample2x_nhwc(x):
+    """Nearest x2 upsample of a channels_last fp32 HIP tensor [B, C, H, W] -> [B, C, 2H, 2W] (channels_last)."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 4:
+        raise GqHipError("upsample2x_nhwc needs a dense channels_last fp32 HIP tensor with C % 4 == 0")
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        _check(lib().upsample2x_nhwc_f32(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "upsample2x_nhwc_f32")
     return y
 
 

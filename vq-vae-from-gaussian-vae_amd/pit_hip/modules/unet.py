@@ -196,7 +196,13 @@ class Upsample(nn.Module):
 
     def forward(self, x: torch.Tensor):
         """Returns (y, pending_bias) -- see ``_conv``."""
-        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if (FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[1] % 4 == 0
+                and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+            from .. import _lib
+
+            x = _lib.upsample2x_nhwc(x)   # ATen's NHWC nearest kernel runs at ~1.6 TB/s; this one is a plain copy
+        else:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         return _conv(self.conv, x) if self.with_conv else (x, None)
 
 
