@@ -197,6 +197,27 @@ def main():
     launches, kernel_ms = _lib.profile_collect()
     _lib.profile_enable(False)
 
+    # Per-stage split, measured AFTER the timed region on this rank's stream, no collective.
+    def stage_split(reps=5):
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(reps)]
+        with torch.no_grad():
+            for e in ev:
+                e[0].record()
+                z = vae.encoder(x)
+                e[1].record()
+                zhat, info = vae.regularization(z)
+                e[2].record()
+                rec = vae.decode(zhat)
+                e[3].record()
+                layout.pack(info["indices"], psnr_zero_mean(x, rec)[:, None])
+                e[4].record()
+        torch.cuda.synchronize()
+        med = lambda i: sorted(e[i].elapsed_time(e[i + 1]) for e in ev)[reps // 2]
+        return {"encoder": round(med(0), 3), "quantiser": round(med(1), 3), "decoder": round(med(2), 3),
+                "psnr+pack": round(med(3), 3), "note": "median of 5 untimed extra steps, torch events"}
+
+    stages = stage_split()
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -228,6 +249,7 @@ def main():
                          "launches": launches, "avg_launch_us": round(avg_ms * 1e3, 2),
                          "timing": "hipEvents attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream",
                          "algorithmic_flops_per_launch": flops},
+            "stages_ms": stages,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(4)   # ~10 s of host work

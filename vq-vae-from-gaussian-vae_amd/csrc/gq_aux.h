@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void gq_scores_kernel(const float *__restrict_
                                                         float *__restrict__ out, int rows, int n,
                                                         double beta) {
 #pragma clang fp contract(off)
-  constexpr int CPT = 1;   // codes per thread (2 measured slower: the kernel is VALU-bound, not LDS-bound)
+  // codes per thread.  2 was measured slower, and so was 2 held as one f32x2 (v_pk_add/mul/fma_f32): on gfx950 a scalar
+  // fp32 VALU op issues every ~2.7-3.2 cycles per SIMD and a packed one every ~4.7-5 (tools/valu_pk_peak.hip), so packing
+  // buys < 15 % before the splat moves it needs; the kernel is bound by its 6 VALU ops per (row, code, dim).
+  constexpr int CPT = 1;
   __shared__ float s_mu[ROWS][DIM], s_sd[ROWS][DIM], s_y[ROWS][DIM];
   __shared__ int s_fast[ROWS];
   const int j0 = blockIdx.x * (256 * CPT) + threadIdx.x;
