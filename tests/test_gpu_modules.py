@@ -461,3 +461,37 @@ def test_upsample2x_nhwc_matches_interpolate():
     y = _lib.upsample2x_nhwc(x)
     assert y.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(y, F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+def test_rccl_single_rank_gather_of_packed_record():
+    """RCCL (backend "nccl") end to end on this box with world_size 1: process-group init bound to
+    the device, the packed int32 record through all_gather_into_tensor, MAX all-reduce of the
+    step time and a barrier -- the exact calls bench.py / evaluate_sharded make at N > 1."""
+    import socket
+    import torch.distributed as dist
+    from pit_hip.eval_dist import StepRecord, gather_step
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        bs, tokens = 4, 1024
+        layout = StepRecord(bs, tokens, n_metrics=1)
+        g = torch.Generator().manual_seed(5)
+        idx = torch.randint(0, 65536, (bs, 1, 32, 32), generator=g).to(DEV)
+        psnr = torch.rand(bs, 1, generator=g).to(DEV)
+        rec = layout.pack(idx, psnr)
+        out = gather_step(rec, 1, always_collective=True)
+        assert out.shape == (1, layout.words) and out.is_cuda
+        i2, m2 = layout.unpack(out[:, None])
+        assert torch.equal(i2.reshape(-1), idx.reshape(-1)) and torch.equal(m2.reshape(-1), psnr.reshape(-1))
+        t = torch.tensor([1.25], dtype=torch.float64, device=DEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        assert float(t.item()) == 1.25
+    finally:
+        dist.destroy_process_group()

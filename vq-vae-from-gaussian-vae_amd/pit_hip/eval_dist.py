@@ -109,9 +109,10 @@ class StepRecord:
         return flat.reshape(*lead, self.bs, self.tokens), metrics
 
 
-def gather_step(rec: torch.Tensor, world: int) -> torch.Tensor:
-    """ONE collective per step: [words] -> [world, words]."""
-    if world == 1:
+def gather_step(rec: torch.Tensor, world: int, always_collective: bool = False) -> torch.Tensor:
+    """ONE collective per step: [words] -> [world, words].  ``always_collective`` issues the
+    all-gather even for a single rank (tests use it to drive RCCL on a one-GPU box)."""
+    if world == 1 and not always_collective:
         return rec[None]
     rec = rec.reshape(-1)
     if rec.is_cuda and dist.get_backend() == "gloo":   # debug configuration: gloo gathers through the host
