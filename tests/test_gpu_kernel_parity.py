@@ -11,6 +11,16 @@ from oracle import gq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "fp32"])
+def filter_kind(request):
+    """Every test of this module runs with both filter kernels (split-bf16 and fp32 MFMA); same indices."""
+    from pit_hip import _lib
+
+    _lib.set_filter(request.param)
+    yield request.param
+    _lib.set_filter("auto")
+
+
 def _inputs(rows, dim, seed, realistic=True):
     g = torch.Generator().manual_seed(seed)
     if realistic:
@@ -177,7 +187,7 @@ def test_config4_group_sweep_full_batch(cfg, c, group, rows_expected):
     assert torch.equal(_lib.gq_dequant(idx, cb, group, "bchw", _lib.GQHIP_GROUP_STRIDED), zhat)
 
 
-def test_reference_smoke_loop_shape_max_size():
+def test_reference_smoke_loop_shape_max_size(filter_kind):
     """The shape of the reference's own test loop (gq_cuda_extension/test/test_extension.py:10-14:
     b = 1024*4*8*8 = 262 144 rows, dim 16, 65 536 codes -- a 64 GiB score matrix there, never
     materialised here) plus the compat op on a slice of it; oracle on a strided sample."""
@@ -199,10 +209,54 @@ def test_reference_smoke_loop_shape_max_size():
     lsd = np.log(sd.numpy()[sel].astype(np.float64)).astype(np.float32)
     oi, _ = O.argmax_rows(mu.numpy()[sel], sd.numpy()[sel], noise.numpy(), 1.0, logstd=lsd)
     assert np.array_equal(idx.cpu().numpy()[sel], oi)
-    assert fb < rows // 10, f"fallback rows {fb}"   # abs(randn) sigmas: ~3 % of the rows need the fp64 second stage
+    # abs(randn) sigmas (tiny ones included): ~3 % of the rows need the fp64 second stage behind the fp32 filter;
+    # the split-bf16 filter's wider margin sends more of these ill-conditioned rows there (still exact)
+    assert fb < (rows // 10 if filter_kind == "fp32" else rows // 2), f"fallback rows {fb}"
     # compat op on the first 64 rows: same arg-max wherever the top-2 gap is not a rounding tie
     out = torch.zeros(64, n, device=dev)
     _lib.gq_scores(mu[:64].to(dev), sd[:64].to(dev), noise.to(dev), out, 1.0)
     ri, _, best, second = O.argmax_rows(mu.numpy()[:64], sd.numpy()[:64], noise.numpy(), 1.0, with_gap=True)
     clear = (best - second) > 1e-3 * np.maximum(1.0, np.abs(best))
     assert np.array_equal(out.argmax(1).cpu().numpy()[clear], ri[clear])
+
+
+@pytest.mark.parametrize("dim,rows,n", [(16, 4096, 65536), (8, 2048, 8192), (32, 1024, 4096)])
+def test_filter_value_error_within_the_bound_the_rerank_assumes(dim, rows, n, filter_kind):
+    """The re-rank trusts |f_filter - f| <= ef_coeff * 2^-24 * T (gq_rerank.h).  Measure it: the filter's
+    best record value m1 of every (row, split) against the fp64 value of the same expansion, maximised over
+    the codes of that candidate group.  Must sit well inside the bound (the margin is 2.5x the bound)."""
+    from pit_hip import _lib
+
+    dev = torch.device("cuda:0")
+    mu, sd = _inputs(rows, dim, 31)
+    cb = O.codebook(n, dim, 42)
+    ws = _lib.Workspace()
+    _lib.gq_argmax(mu.to(dev), sd.to(dev), torch.from_numpy(cb).to(dev), 1.0, ws=ws)
+    torch.cuda.synchronize()
+    pl = _lib.debug_plan(rows, n, dim)
+    assert pl["bf16"] == (1 if filter_kind == "auto" else 0)
+    m, ids = _lib.debug_records(ws, rows, n, dim)
+    m1 = m[..., 0].cpu().numpy().astype(np.float64)            # [nsplit, rows]
+    id1 = ids[..., 0].cpu().numpy()
+    # fp64 expansion with the kernel's fp32 coefficients' real-valued targets
+    mu64, sd64, cb64 = mu.numpy().astype(np.float64), sd.numpy().astype(np.float64), cb.astype(np.float64)
+    inv = 1.0 / (sd64 * sd64)
+    A, B = 0.5 - 0.5 * inv, mu64 * inv                           # beta = 1
+    N1 = np.abs(cb64).max()
+    T = ((0.5 + 0.5 * inv) * N1 * N1 + np.abs(mu64) * inv * N1).sum(axis=1)   # the bound's T (gq_rerank.h)
+    gt = pl["gt"]
+    r = np.arange(16 * gt)
+    worst = 0.0
+    sel = np.arange(0, rows, 7)
+    for s in range(pl["nsplit"]):
+        gid = id1[s, sel]
+        tile = (gid >> 1)[:, None] * gt + (r >> 4)[None, :]
+        code = tile * 32 + (r & 3)[None, :] + 8 * ((r & 15) >> 2)[None, :] + 4 * (gid & 1)[:, None]
+        ok = code < n
+        cc = np.minimum(code, n - 1)
+        f = (A[sel][:, None, :] * cb64[cc] ** 2 + B[sel][:, None, :] * cb64[cc]).sum(axis=2)
+        f = np.where(ok, f, -np.inf).max(axis=1)
+        err = np.abs(m1[s, sel] - f) / (2.0 ** -24 * T[sel])
+        worst = max(worst, float(err.max()))
+    print(f"filter={filter_kind} dim={dim}: max |f_filter - f| = {worst:.1f} x 2^-24 T (bound coefficient {pl['ef_coeff']})")
+    assert worst <= pl["ef_coeff"] / 4.0

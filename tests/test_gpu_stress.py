@@ -12,6 +12,16 @@ from oracle import gq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "fp32"])
+def filter_kind(request):
+    """Every test of this module runs with both filter kernels (split-bf16 and fp32 MFMA); same indices."""
+    from pit_hip import _lib
+
+    _lib.set_filter(request.param)
+    yield request.param
+    _lib.set_filter("auto")
+
+
 def _case(seed):
     rng = np.random.default_rng(seed)
     dim = int(rng.choice([4, 8, 16, 32]))

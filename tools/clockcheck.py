@@ -18,7 +18,7 @@ torch.cuda.synchronize()
 L = _lib.lib()
 nblk = 512
 # workspace layout: hdr(512) | rec (nsplit*rows*32) | fb (rows*4) | mu ...
-off = 512 + 8 * rows * 32 + ((rows * 4 + 255) // 256) * 256
+off = 512 + 8 * rows * 32 + ((rows * 4 + 255) // 256) * 256 + 33792   # hdr | rec | fb | spread slots
 raw = ws.buf[off:off + nblk * 32].cpu().numpy().view(np.uint64).reshape(nblk, 4)
 t0 = raw[:, 0].min()
 start = (raw[:, 0] - t0) / 100.0   # us

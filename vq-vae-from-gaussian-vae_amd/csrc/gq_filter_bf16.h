@@ -1,0 +1,360 @@
+// gq_filter_bf16.h -- the filter on the bf16 matrix cores (split-precision variant of gq_filter.h).
+//
+// Same contract as gq_filter_kernel: for every row r and code j it evaluates
+//     f(r, j) = sum_i  A[r,i] * c[j,i]^2  +  B[r,i] * c[j,i]
+// and keeps, per (row, code split), the three largest half-group maxima + the ids of the best two; the
+// re-rank kernel then decides exactly.  The products are formed on v_mfma_f32_32x32x16_bf16 (16x the fp32
+// MFMA rate) from two-term bf16 splits of every fp32 operand q = q_h + q_l (+ residual <= 2^-18 |q|):
+//     A * s  ~  A_h s_h  +  A_h s_l  +  A_l s_h          (each bf16 x bf16 product is exact in fp32)
+// so a fp32 MAC costs three bf16 MACs and the filter value carries a relative error of ~3 * 2^-18 per
+// product instead of ~2^-24 -- which only widens the re-rank margin (gq_rerank.h: `ef_coeff`): the indices
+// stay bit-identical to the reference because the decision is still taken by the exact re-rank.
+//
+// K layout.  Per "type" (hh, lh, hl) there are 2*DIM slots [ squares of dims 0..DIM-1 | values of dims
+// 0..DIM-1 ]; MFMA m of a type covers slots 16m .. 16m+15, lane half h supplies slots 16m+8h .. 16m+8h+7.
+// NV = DIM/8 MFMAs per type.  Code side: vectors 0..NV-1 hold the h parts, NV..2NV-1 the l parts; row side
+// likewise with the coefficients [A | B].  MFMA (type, m):  hh -> (code m, row m), lh -> (code NV+m, row m),
+// hl -> (code m, row NV+m).  Both images are produced once per call by bf16_split_kernel (below), the
+// codebook image already in the LDS tile order, so staging is a linear 16-byte copy.
+//
+// Tile image: [tile][code vector cv][half h][code c] x 16 bytes  ->  a wave's ds_read_b128 of one vector is
+// 1 KiB contiguous (conflict-free).  D layout as in gq_filter.h (lane = one row, 16 codes).
+#pragma once
+#include <type_traits>
+
+#include "gq_filter.h"
+
+namespace gqhip {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct FilterBfParams {
+  const u32x4 *cbimg;   // [tiles_total + CT][2*NV][2][32]
+  const u32x4 *rowimg;  // [rows][2*NV][2]
+  Rec *rec;             // [nsplit, rows]
+  int rows, n;
+  int nsplit, tiles_total, tiles_per_split;
+  WsHeader *hdr;
+  float absmax;
+};
+
+struct SplitParams {
+  const float *mu, *sd, *cb;
+  u32x4 *cbimg, *rowimg;
+  int rows, n, tiles_total;
+  float beta;
+};
+
+// round-to-nearest-even fp32 -> bf16 (as the upper 16 bits); finite inputs (non-finite rows / codebooks never
+// reach a decision through the filter: the re-rank routes them to the second stage by their bound).
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+  const unsigned x = __float_as_uint(f);
+  return (x + 0x7fffu + ((x >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bf16_split(float q, unsigned &hi, unsigned &lo) {
+  hi = bf16_rne(q);
+  const float r = q - __uint_as_float(hi << 16);   // exact in fp32
+  lo = bf16_rne(r);
+}
+
+// One thread per (code, half) and per (row, half): builds both operand images.
+template <int MODE, int DIM>
+__global__ __launch_bounds__(256) void bf16_split_kernel(const SplitParams p) {
+  constexpr int NV = DIM / 8;
+  static_assert(DIM == 8 || DIM == 16 || DIM == 32, "split-bf16 filter: dims 8, 16, 32");
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long ncode_threads = (long)p.tiles_total * 64;
+  float q[NV][8];   // this half's 8 slots of each of the NV MFMAs of a type
+  u32x4 *dst;
+  long stride;      // in u32x4 between consecutive vectors
+  if (t < ncode_threads) {
+    const int tile = (int)(t >> 6), h = (int)(t >> 5) & 1, c = (int)t & 31;
+    const long code = (long)tile * 32 + c;
+#pragma unroll
+    for (int m = 0; m < NV; ++m)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int g = 16 * m + 8 * h + k;
+        float v = 0.0f;
+        if (code < p.n) {
+          v = p.cb[code * DIM + (g < DIM ? g : g - DIM)];
+          if (g < DIM) v = v * v;
+        }
+        q[m][k] = v;
+      }
+    dst = p.cbimg + (long)tile * (2 * NV * 64) + h * 32 + c;
+    stride = 64;
+  } else {
+    const long u = t - ncode_threads;
+    const long row = u >> 1;
+    const int h = (int)u & 1;
+    if (row >= p.rows) return;
+#pragma unroll
+    for (int m = 0; m < NV; ++m)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int g = 16 * m + 8 * h + k;
+        const int i = g < DIM ? g : g - DIM;
+        float v;
+        if constexpr (MODE == kModeGQ) {
+          const double sg = (double)p.sd[row * DIM + i];
+          const double inv = 1.0 / (sg * sg);
+          v = g < DIM ? (float)(0.5 * (double)p.beta - 0.5 * inv) : (float)((double)p.mu[row * DIM + i] * inv);
+        } else {
+          v = g < DIM ? -1.0f : 2.0f * p.mu[row * DIM + i];
+        }
+        q[m][k] = v;
+      }
+    dst = p.rowimg + row * (2 * NV * 2) + h;
+    stride = 2;
+  }
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    unsigned hi[8], lo[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bf16_split(q[m][k], hi[k], lo[k]);
+    u32x4 vh, vl;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      vh[w] = hi[2 * w] | (hi[2 * w + 1] << 16);
+      vl[w] = lo[2 * w] | (lo[2 * w + 1] << 16);
+    }
+    dst[(long)m * stride] = vh;
+    dst[(long)(NV + m) * stride] = vl;
+  }
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// MFMAs [S0, S1) of the 3*NV of one tile, for the wave's RT row tiles (chains alternate in program order).
+template <int NV, int RT, int S0, int S1>
+__device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[2 * NV], const u32x4 (&rv)[RT][2 * NV],
+                                               f32x16 (&d)[RT]) {
+  if constexpr (S0 == 0) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      d[rt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int s = S0; s < S1; ++s) {
+    const int type = s / NV, m = s % NV;           // 0 hh, 1 lh, 2 hl
+    const int ci = type == 1 ? NV + m : m;
+    const int ri = type == 2 ? NV + m : m;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      d[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(cv[ci]), as_bf16x8(rv[rt][ri]), d[rt], 0, 0, 0);
+  }
+}
+
+template <int NV, int RT, int CT, int GT>
+__global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
+  constexpr int NCV = 2 * NV;                 // code (and row) vectors per tile
+  constexpr int TILE_Q = NCV * 64;            // 16-byte slots per tile
+  constexpr int CHUNK_Q = CT * TILE_Q;
+  constexpr int R4 = CHUNK_Q / 256;           // 16-byte loads per thread per chunk
+  constexpr int NM = 3 * NV;                  // MFMAs per tile and row tile
+  static_assert(R4 >= 1 && CHUNK_Q % 256 == 0 && CT % GT == 0, "chunk: whole tile groups, whole thread passes");
+  __shared__ u32x4 lds[2][CHUNK_Q];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int split = blockIdx.x % p.nsplit;
+  const int rowblk = blockIdx.x / p.nsplit;
+  const int t_begin = split * p.tiles_per_split;          // multiple of GT
+  const int t_end = min(t_begin + p.tiles_per_split, p.tiles_total);
+  const int t_full_end = min(t_end, p.n / kTileCodes);    // complete tiles only
+
+  if (blockIdx.x == 0 && tid == 0) {  // workspace header for the kernels that follow on the stream
+    p.hdr->fb_count = 0;
+    p.hdr->reranked = 0ull;
+    if (p.absmax > 0.f) p.hdr->absmax = p.absmax;
+  }
+
+  // ---- row operands (B side of the MFMA), fixed for the whole kernel ----
+  u32x4 rv[RT][NCV];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int row = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
+    row = min(row, p.rows - 1);
+#pragma unroll
+    for (int v = 0; v < NCV; ++v) rv[rt][v] = p.rowimg[((long)row * NCV + v) * 2 + h];
+  }
+
+  const float NEG_INF = -__builtin_inff();
+  float m1[RT], m2[RT], m3[RT], tpend[RT];
+  int i1[RT], i2[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    m1[rt] = m2[rt] = m3[rt] = tpend[rt] = NEG_INF;
+    i1[rt] = i2[rt] = 0;
+  }
+
+  // ---- chunk staging: global image -> registers -> LDS (a linear copy) ----
+  u32x4 stage[R4];
+  auto load_chunk = [&](int tile0) {
+    const u32x4 *src = p.cbimg + (long)tile0 * TILE_Q + tid;
+#pragma unroll
+    for (int r = 0; r < R4; ++r) stage[r] = src[256 * r];   // the image is padded by CT tiles
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < R4; ++r) lds[buf][tid + 256 * r] = stage[r];
+  };
+  auto read_ops = [&](const u32x4 *tile, u32x4 (&cv)[NCV]) {
+#pragma unroll
+    for (int v = 0; v < NCV; ++v) cv[v] = tile[v * 64];
+  };
+  auto close_group = [&](int tile) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      top3_insert(tpend[rt], tile / GT, m1[rt], m2[rt], m3[rt], i1[rt], i2[rt]);
+      tpend[rt] = NEG_INF;
+    }
+  };
+  auto fold = [&](f32x16 (&d)[RT], int tile, bool closes) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) tpend[rt] = max_chain(tpend[rt], d[rt]);
+    if (closes) close_group(tile);
+  };
+
+  const int ntiles = t_full_end - t_begin;
+  const int nchunks = ntiles > 0 ? (ntiles + CT - 1) / CT : 0;
+  if (nchunks > 0) {
+    load_chunk(t_begin);
+    store_chunk(0);
+  }
+  // Touch the row operands here: the compiler then waits for their loads BEFORE the loop.  Otherwise its
+  // wait-count bookkeeping carries "row operands may still be in flight" into the loop, and since loads retire
+  // in order the first tile of every chunk would wait for that chunk's prefetch (vmcnt(0) in the hot loop).
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int v = 0; v < NCV; ++v) asm volatile("" ::"v"(rv[rt][v]));
+  __syncthreads();
+
+  constexpr int S0 = NM >= 6 ? 2 : 1;   // MFMA steps issued before the previous tile's epilogue
+  f32x16 dprev[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dprev[rt][r] = NEG_INF;
+  int tprev = t_begin - 1;
+  bool have_prev = false;
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int tile0 = t_begin + ch * CT;
+    if (ch + 1 < nchunks) load_chunk(tile0 + CT);
+    const int nt = min(CT, t_full_end - tile0);
+    const u32x4 *base = lds[ch & 1] + h * 32 + c;   // this lane's slot within a vector
+    if (nt == CT) {
+      u32x4 cv[NCV];
+      read_ops(base, cv);
+      auto step = [&](int tt, auto prev_closes, auto last) {
+        constexpr bool PREV_CLOSES = decltype(prev_closes)::value, LAST = decltype(last)::value;
+        u32x4 cvn[NCV];
+        if constexpr (!LAST) read_ops(base + (tt + 1) * TILE_Q, cvn);
+        f32x16 d[RT];
+        tile_mfma_bf16<NV, RT, 0, S0>(cv, rv, d);
+        fold(dprev, tprev, PREV_CLOSES);
+        tile_mfma_bf16<NV, RT, S0, NM>(cv, rv, d);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) dprev[rt] = d[rt];
+        tprev = tile0 + tt;
+        if constexpr (!LAST) {
+#pragma unroll
+          for (int v = 0; v < NCV; ++v) cv[v] = cvn[v];
+          __builtin_amdgcn_sched_group_barrier(0x100, NCV, 0);
+        }
+        // pin the order: next tile's LDS reads | then every MFMA of this tile followed by a slice of the
+        // PREVIOUS tile's epilogue (its accumulators are long complete; bf16 MFMAs and VALU overlap)
+        // (VALU budget slightly under the real count, none after the last MFMA: a slot left over would pull the
+        // NEXT step's epilogue -- the accumulators just written -- forward and stall on the MFMA latency)
+        constexpr int BUDGET = (PREV_CLOSES ? 16 : 8) * RT, K = NM * RT - 1;
+        constexpr int PER = BUDGET / K, EXTRA = BUDGET % K;   // the first EXTRA MFMAs carry PER+1 VALU slots
+#pragma unroll
+        for (int k = 0; k < EXTRA; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, PER + 1, 0);
+        }
+#pragma unroll
+        for (int k = EXTRA; k < K; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if constexpr (PER > 0) __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      };
+      auto run_all = [&](auto... is) {
+        (step(decltype(is)::value, std::bool_constant<(decltype(is)::value % GT) == 0>{},
+              std::bool_constant<decltype(is)::value == CT - 1>{}), ...);
+      };
+      using std::integral_constant;
+      if constexpr (CT == 8)
+        run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
+                integral_constant<int, 3>{}, integral_constant<int, 4>{}, integral_constant<int, 5>{},
+                integral_constant<int, 6>{}, integral_constant<int, 7>{});
+      else
+        run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
+                integral_constant<int, 3>{});
+      static_assert(CT == 8 || CT == 4, "unrolled tile loop is written for 4 or 8 tiles per chunk");
+      have_prev = true;
+    } else {
+      if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);
+      have_prev = false;
+      for (int tt = 0; tt < nt; ++tt) {
+        u32x4 cv[NCV];
+        read_ops(base + tt * TILE_Q, cv);
+        f32x16 d[RT];
+        tile_mfma_bf16<NV, RT, 0, NM>(cv, rv, d);
+        fold(d, tile0 + tt, ((tile0 + tt) % GT) == GT - 1);
+      }
+    }
+    if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+    __syncthreads();
+  }
+  if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);
+
+  // ---- leftovers: the one partial tile (n % 32 != 0; zero-padded in the image) / an open group ----
+  const bool pending = ntiles > 0 && (ntiles % GT) != 0;
+  if (t_end > t_full_end) {
+    const int tile = t_full_end;
+    u32x4 cv[NCV];
+    read_ops(p.cbimg + (long)tile * TILE_Q + h * 32 + c, cv);
+    f32x16 d[RT];
+    tile_mfma_bf16<NV, RT, 0, NM>(cv, rv, d);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = tile * kTileCodes + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (cc >= p.n) d[rt][r] = NEG_INF;
+      }
+      tpend[rt] = max_chain(tpend[rt], d[rt]);
+    }
+    close_group(tile);
+  } else if (pending) {
+    close_group(t_full_end - 1);
+  }
+
+  // ---- merge the two lane halves of each row, write one record ----
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt];
+    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h;
+    const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32);
+    const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32);
+    top3_insert(b1, k1, a1, a2v, a3, j1, j2);
+    top3_insert(b2, k2, a1, a2v, a3, j1, j2);
+    top3_insert_value(b3, a2v, a3);
+    const int row = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
+    if (h == 0 && row < p.rows) {
+      Rec r;
+      r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.id1 = j1; r.id2 = j2;
+      r.pad[0] = r.pad[1] = r.pad[2] = 0;
+      p.rec[(long)split * p.rows + row] = r;
+    }
+  }
+}
+
+}  // namespace gqhip

@@ -46,6 +46,21 @@ __device__ __forceinline__ long out_zhat_offset(const OutMap &m, long row, int g
   return pos * m.c + ch;
 }
 
+// Scratch of the "spread" second stage (few listed rows, each spread over kSpreadSlices blocks).
+constexpr int kSpreadRows = 64;     // listed rows handled by the spread kernels (more: gq_fallback64_kernel)
+constexpr int kSpreadSlices = 32;   // blocks per listed row
+struct SpreadPartial {
+  double s;
+  int i;      // 0x7fffffff: empty
+  int pad;
+};
+struct SpreadSlot {
+  unsigned long long fmax_enc;   // order-preserving encoding of the fp64 row maximum (0 = none yet)
+  int done;                      // slices finished in pass 2
+  int pad;
+  SpreadPartial part[kSpreadSlices];
+};
+
 struct RerankParams {
   const float *mu;    // [rows, dim] (VQ: z)
   const float *sd;    // [rows, dim]
@@ -56,10 +71,12 @@ struct RerankParams {
   float *zhat;        // may be NULL
   WsHeader *hdr;
   int *fb_list;       // [rows]
+  SpreadSlot *spread; // [kSpreadRows]
   int rows, n, dim;
   float beta;
   int nsplit;
   int gt;             // tiles per candidate group (2 or 4) -- must match the filter's GT
+  float ef_coeff;     // filter error bound E_f = ef_coeff * 2^-24 * T  (fp32 filter: 2 dim + 4; split-bf16: 220 + 24 dim)
   int all_rows;       // exhaustive kernel: process every row (no filter ran)
   int stats;          // count re-ranked half-pairs (debug)
   OutMap omap;
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   }
   T = wave_sum(T);
   G = wave_sum(G);
-  const double Ef = (2.0 * p.dim + 4.0) * u * T;
+  const double Ef = (double)p.ef_coeff * u * T;
   const double Er = MODE == kModeGQ ? (p.dim + 16.0) * u * G : 1e-12 * T;
   const double margin = 2.5 * (Ef + Er) + 1e-30;
   bad = __any(bad) || !(margin < 1e30);
@@ -203,6 +220,10 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
     if (lane == 0) {
       const int pos = atomicAdd(&p.hdr->fb_count, 1);
       p.fb_list[pos] = (int)row;
+      if (pos < kSpreadRows) {
+        p.spread[pos].fmax_enc = 0ull;
+        p.spread[pos].done = 0;
+      }
     }
     return;
   }
@@ -275,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
   __shared__ int sh_i[8];
   const int tid = threadIdx.x;
   const int count = p.hdr->fb_count;
+  if (count <= kSpreadRows) return;                    // gq_fallback64_spread_kernel handles short lists
   // Many listed rows: 8 rows per block (a half-wave each).  Few: the whole block on ONE row, so a
   // lone fallback row costs ~60 us instead of ~3 ms.
   const bool wide = count < 4 * (int)gridDim.x;       // block-uniform
@@ -396,6 +418,156 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
       if (p.zhat && ol < DIM) p.zhat[out_zhat_offset(p.omap, row, ol, DIM)] = p.cb[(long)best_i * DIM + ol];
       if (!wide && p.zhat && ol + 32 < DIM)
         p.zhat[out_zhat_offset(p.omap, row, ol + 32, DIM)] = p.cb[(long)best_i * DIM + ol + 32];
+    }
+  }
+}
+
+// ---- short lists: every listed row is spread over kSpreadSlices blocks ------------------------------
+// Same two passes as gq_fallback64_kernel, as two launches (PASS 1: fp64 row maximum through an atomic max;
+// PASS 2: exact scores inside the window, per-slice partial results, the last slice to finish combines them),
+// so that a lone undecided row costs a few microseconds instead of one block walking all 65 536 codes.
+__device__ __forceinline__ unsigned long long enc_f64(double d) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dec_f64(unsigned long long e) {
+  const unsigned long long b = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+  return __longlong_as_double((long long)b);
+}
+
+template <int MODE, int DIM, int PASS>
+__global__ __launch_bounds__(256) void gq_fallback64_spread_kernel(const RerankParams p) {
+  __shared__ RowOps rops;
+  __shared__ double sh_d[4];
+  __shared__ int sh_i[4];
+  __shared__ int sh_last;
+  const int count = p.hdr->fb_count;
+  const int e = blockIdx.x / kSpreadSlices, sl = blockIdx.x % kSpreadSlices;
+  if (count > kSpreadRows || e >= count) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row = p.fb_list[e];
+  if (tid < DIM) load_row_ops(p, row, tid, rops);
+  __syncthreads();
+  double cA[DIM], cB[DIM];
+  const double u = 5.9604644775390625e-08, N1 = (double)p.hdr->absmax, N2 = N1 * N1;
+  const double bb = fabs((double)p.beta), c = (double)half_log_2pi();
+  const double INF = __builtin_inf();
+  double Cr = 0.0, R0 = 0.0, T = 0.0;
+  bool bad = !(N1 == N1) || N1 > 1e18;
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    const double m = (double)rops.mu[i];
+    if constexpr (MODE == kModeGQ) {
+      const double sg = (double)p.sd[row * DIM + i];
+      const double inv = 1.0 / (sg * sg);
+      cA[i] = 0.5 * (double)p.beta - 0.5 * inv;
+      cB[i] = m * inv;
+      Cr += 0.5 * m * m * inv;
+      R0 += fabs((double)rops.lsd[i]) + c + bb * (0.5 * N2 + c);
+      T += (0.5 * bb + 0.5 * inv) * N2 + fabs(m) * inv * N1;
+      bad = bad || !(sg > 0.0) || !(inv < 1e300);
+    } else {
+      cA[i] = -1.0;
+      cB[i] = 2.0 * m;
+      T += N2 + 2.0 * fabs(m) * N1;
+    }
+  }
+  auto f64_of = [&](int j) {
+    const f32x4 *nj = reinterpret_cast<const f32x4 *>(p.cb + (long)j * DIM);
+    double f = 0.0;
+#pragma unroll
+    for (int q = 0; q < DIM / 4; ++q) {
+      const f32x4 v4 = nj[q];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double v = (double)v4[k];
+        f = fma(cA[4 * q + k], v * v, f);
+        f = fma(cB[4 * q + k], v, f);
+      }
+    }
+    return f;
+  };
+  const int per = (p.n + kSpreadSlices - 1) / kSpreadSlices;
+  const int j0 = sl * per, j1 = min(p.n, j0 + per);
+  SpreadSlot &slot = p.spread[e];
+  if constexpr (PASS == 1) {
+    double fmax = -INF;
+    for (int j = j0 + tid; j < j1; j += 256) {
+      const double f = f64_of(j);
+      fmax = f > fmax ? f : fmax;            // NaN never enters
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double of = __shfl_xor(fmax, o);
+      fmax = of > fmax ? of : fmax;
+    }
+    if (lane == 0 && fmax > -INF) atomicMax(&slot.fmax_enc, enc_f64(fmax));
+  } else {
+    const unsigned long long fe = slot.fmax_enc;
+    const double fmax = fe ? dec_f64(fe) : -INF;
+    double marg;
+    if constexpr (MODE == kModeGQ) {
+      const double cu = (DIM + 16.0) * u;
+      double Q = Cr + 0.5 * bb * DIM * N2 - fmax;
+      Q = Q > 0.0 ? Q : 0.0;
+      marg = 2.5 * cu * (Q + R0) / (1.0 - cu) + 1e-12 * T + 1e-30;
+    } else {
+      marg = 1e-11 * T + 1e-30;
+    }
+    bad = bad || !(fmax > -INF) || !(fmax < INF) || !(T < 1e300) || !(marg < 1e300);
+    const double thr = bad ? -INF : fmax - marg;
+    double best_s = 0.0;
+    int best_i = 0x7fffffff;
+    bool have = false;
+    for (int j = j0 + tid; j < j1; j += 256) {
+      if (bad || f64_of(j) >= thr) {
+        const double s = exact_score_cold<MODE>(p.cb, &rops, j, DIM, p.beta);
+        if (!have || better_d(s, j, best_s, best_i)) { best_s = s; best_i = j; have = true; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double os = __shfl_xor(best_s, o);
+      const int oi = __shfl_xor(best_i, o);
+      const bool oh = __shfl_xor((int)have, o) != 0;
+      if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+    }
+    if (lane == 0) { sh_d[wave] = best_s; sh_i[wave] = have ? best_i : 0x7fffffff; }
+    __syncthreads();
+    if (tid == 0) {
+      have = false;
+      for (int k = 0; k < 4; ++k) {
+        const double os = sh_d[k];
+        const int oi = sh_i[k];
+        if (oi != 0x7fffffff && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+      }
+      slot.part[sl].s = best_s;
+      slot.part[sl].i = have ? best_i : 0x7fffffff;
+      __threadfence();
+      sh_last = atomicAdd(&slot.done, 1) == kSpreadSlices - 1;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    __threadfence();
+    // last slice of this row: combine the partial results (one wave) and write the answer
+    if (wave == 0) {
+      have = false;
+      best_s = 0.0;
+      best_i = 0x7fffffff;
+      if (lane < kSpreadSlices) {
+        const volatile SpreadPartial *pp = &slot.part[lane];
+        best_s = pp->s;
+        best_i = pp->i;
+        have = best_i != 0x7fffffff;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(best_s, o);
+        const int oi = __shfl_xor(best_i, o);
+        const bool oh = __shfl_xor((int)have, o) != 0;
+        if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+      }
+      write_result(p, row, best_i, lane);
     }
   }
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <utility>
@@ -13,6 +14,7 @@
 #include "gq_aux.h"
 #include "gq_common.h"
 #include "gq_filter.h"
+#include "gq_filter_bf16.h"
 #include "gq_rerank.h"
 
 using namespace gqhip;
@@ -39,8 +41,19 @@ struct Plan {
   int nsplit;           // code splits
   int tiles_total;
   int tiles_per_split;
-  int gt;               // tiles per candidate group: 4 for dim <= 8, else 2
+  int gt;               // tiles per candidate group: 4 for dim <= 8 and for the split-bf16 filter, else 2
+  bool bf16;            // split-bf16 filter (gq_filter_bf16.h) instead of the fp32 MFMA one
+  int ct;               // tiles per LDS chunk of the split-bf16 filter
 };
+
+// Filter selection: 0 = auto (split-bf16 where it applies: dims 8/16/32), 1 = always the fp32 MFMA filter.
+// Initial value from GQHIP_FILTER=fp32|bf16, changed at run time by gqhip_set_filter().  Both filters feed the
+// same exact re-rank, so the choice never changes an index.
+std::atomic<int> g_filter_kind{[] {
+  const char *e = getenv("GQHIP_FILTER");
+  return (e && (e[0] == 'f' || e[0] == 'F')) ? 1 : 0;
+}()};
+bool want_bf16_filter() { return g_filter_kind.load(std::memory_order_relaxed) == 0; }
 
 Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   Plan pl{};
@@ -63,7 +76,12 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   if (s > pl.tiles_total) s = pl.tiles_total;
   if (s < 1) s = 1;
   pl.tiles_per_split = (pl.tiles_total + s - 1) / s;
-  pl.gt = dim <= 8 ? 4 : 2;
+  pl.bf16 = pl.mfma && (dim == 8 || dim == 16 || dim == 32) && want_bf16_filter();
+  pl.ct = dim == 32 ? 4 : 8;
+  static const int env_bgt = getenv("GQHIP_BF16_GT") ? atoi(getenv("GQHIP_BF16_GT")) : 0;
+  // split-bf16: the tracker's VALU work overlaps the bf16 MFMAs, so the finest candidate (one tile half =
+  // 16 codes) is free in the filter and halves / quarters the exact re-rank work
+  pl.gt = pl.bf16 ? ((env_bgt == 1 || env_bgt == 2 || env_bgt == 4) ? env_bgt : 1) : (dim <= 8 ? 4 : 2);
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   return pl;
@@ -72,7 +90,7 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WsLayout {
-  int64_t hdr, rec, fb, mu, sd, lsd, total;
+  int64_t hdr, rec, fb, spread, mu, sd, lsd, cbimg, rowimg, total;
 };
 
 WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
@@ -82,9 +100,13 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.hdr = off; off += (int64_t)sizeof(WsHeader);
   w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit : 0));
   w.fb = off;  off += align256(4 * rows);
+  w.spread = off; off += align256((int64_t)sizeof(SpreadSlot) * kSpreadRows);
   w.mu = off;  off += align256(4 * rows * dim);
   w.sd = off;  off += align256(4 * rows * dim);
   w.lsd = off; off += align256(4 * rows * dim);
+  // split-bf16 operand images: 2*NV vectors of 16 B per (code, half) / (row, half), NV = dim / 8
+  w.cbimg = off;  off += pl.bf16 ? align256((int64_t)(pl.tiles_total + pl.ct) * (dim / 4) * 64 * 16) : 0;
+  w.rowimg = off; off += pl.bf16 ? align256(rows * (dim / 4) * 2 * 16) : 0;
   w.total = off;
   return w;
 }
@@ -149,6 +171,50 @@ int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t s
   return check_launch();
 }
 
+template <int MODE>
+int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitParams &sp, int dim, hipStream_t st) {
+  const long split_threads = (long)pl.tiles_total * 64 + (long)sp.rows * 2;
+  const dim3 sgrid((unsigned)((split_threads + 255) / 256)), grid((unsigned)(pl.row_blocks * pl.nsplit)), block(256);
+  switch (dim) {
+    case 8: hipLaunchKernelGGL((bf16_split_kernel<MODE, 8>), sgrid, block, 0, st, sp); break;
+    case 16: hipLaunchKernelGGL((bf16_split_kernel<MODE, 16>), sgrid, block, 0, st, sp); break;
+    case 32: hipLaunchKernelGGL((bf16_split_kernel<MODE, 32>), sgrid, block, 0, st, sp); break;
+    default: return GQHIP_ERR_INVALID_ARG;
+  }
+  int rc = check_launch();
+  if (rc != GQHIP_OK) return rc;
+  ProfScope prof;
+#define GQ_LAUNCH_BF1(NV, R, C, G)                                                                        \
+  do {                                                                                                    \
+    if (prof.on)                                                                                          \
+      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, G>), grid, block, 0, st, prof.a, prof.b, 0, fp); \
+    else                                                                                                  \
+      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, G>), grid, block, 0, st, fp);                      \
+  } while (0)
+#define GQ_LAUNCH_BF(NV, R, C)                                                                            \
+  do {                                                                                                    \
+    if (pl.gt == 1) GQ_LAUNCH_BF1(NV, R, C, 1);                                                           \
+    else if (pl.gt == 2) GQ_LAUNCH_BF1(NV, R, C, 2);                                                      \
+    else GQ_LAUNCH_BF1(NV, R, C, 4);                                                                      \
+  } while (0)
+  if (pl.rt == 2) {
+    switch (dim) {
+      case 8: GQ_LAUNCH_BF(1, 2, 8); break;
+      case 16: GQ_LAUNCH_BF(2, 2, 8); break;
+      default: GQ_LAUNCH_BF(4, 2, 4); break;
+    }
+  } else {
+    switch (dim) {
+      case 8: GQ_LAUNCH_BF(1, 1, 8); break;
+      case 16: GQ_LAUNCH_BF(2, 1, 8); break;
+      default: GQ_LAUNCH_BF(4, 1, 4); break;
+    }
+  }
+#undef GQ_LAUNCH_BF
+#undef GQ_LAUNCH_BF1
+  return check_launch();
+}
+
 // filter -> re-rank -> exhaustive, shared by GQ and VQ.
 template <int MODE>
 int run_argmax(const float *mu, const float *sd, const float *lsd, const float *cb, int64_t *idx,
@@ -177,11 +243,31 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
   rp.rec = reinterpret_cast<const Rec *>(ws + w.rec);
   rp.idx = idx; rp.zhat = zhat; rp.hdr = hdr;
   rp.fb_list = reinterpret_cast<int *>(ws + w.fb);
+  rp.spread = reinterpret_cast<SpreadSlot *>(ws + w.spread);
   rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
+  rp.ef_coeff = pl.bf16 ? (float)(220 + 24 * dim) : (float)(2 * dim + 4);
   rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
 
-  if (pl.mfma) {
+  if (pl.bf16) {
+    SplitParams sp{};
+    sp.mu = mu; sp.sd = sd; sp.cb = cb;
+    sp.cbimg = reinterpret_cast<u32x4 *>(ws + w.cbimg); sp.rowimg = reinterpret_cast<u32x4 *>(ws + w.rowimg);
+    sp.rows = (int)rows; sp.n = (int)n; sp.tiles_total = pl.tiles_total; sp.beta = (float)beta;
+    FilterBfParams fp{};
+    fp.cbimg = sp.cbimg; fp.rowimg = sp.rowimg;
+    fp.rec = reinterpret_cast<Rec *>(ws + w.rec);
+    fp.rows = (int)rows; fp.n = (int)n;
+    fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
+    fp.hdr = hdr; fp.absmax = cb_absmax;
+    if (need_absmax && hipMemsetAsync(&hdr->absmax, 0, sizeof(float), st) != hipSuccess) return check_launch();
+    int rc = launch_filter_bf16<MODE>(pl, fp, sp, (int)dim, st);
+    if (rc != GQHIP_OK) return rc;
+    if (need_absmax) launch_absmax();
+    hipLaunchKernelGGL((gq_rerank_kernel<MODE>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rp);
+    rc = check_launch();
+    if (rc != GQHIP_OK) return rc;
+  } else if (pl.mfma) {
     FilterParams fp{};
     fp.mu = mu; fp.sd = sd; fp.cb = cb;
     fp.rec = reinterpret_cast<Rec *>(ws + w.rec);
@@ -198,15 +284,27 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
     if (rc != GQHIP_OK) return rc;
   }
   if (pl.mfma) {
-    // rows the fp32 filter could not decide: fp64 second-stage filter + exact re-rank (usually none)
+    // rows the filter could not decide: fp64 second-stage filter + exact re-rank (usually none or a handful).
+    // Short lists (<= kSpreadRows) are spread over kSpreadSlices blocks per row by the two spread launches;
+    // longer ones go to gq_fallback64_kernel.  Each kernel reads the list length and returns if it is not its turn.
     const int64_t groups = (rows + kFallbackRows - 1) / kFallbackRows;
     const int fb_blocks = (int)(groups < 2048 ? groups : 2048);
+    const int64_t sp_rows = rows < kSpreadRows ? rows : kSpreadRows;
+    const dim3 sp_grid((unsigned)(sp_rows * kSpreadSlices));
+#define GQ_FB(D)                                                                                              \
+  do {                                                                                                        \
+    hipLaunchKernelGGL((gq_fallback64_spread_kernel<MODE, D, 1>), sp_grid, dim3(256), 0, st, rp);             \
+    hipLaunchKernelGGL((gq_fallback64_spread_kernel<MODE, D, 2>), sp_grid, dim3(256), 0, st, rp);             \
+    if (rows > kSpreadRows)                                                                                   \
+      hipLaunchKernelGGL((gq_fallback64_kernel<MODE, D>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp);   \
+  } while (0)
     switch (dim) {
-      case 4: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 4>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
-      case 8: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 8>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
-      case 16: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 16>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
-      default: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 32>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
+      case 4: GQ_FB(4); break;
+      case 8: GQ_FB(8); break;
+      case 16: GQ_FB(16); break;
+      default: GQ_FB(32); break;
     }
+#undef GQ_FB
     return check_launch();
   }
   if (hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
@@ -233,6 +331,23 @@ const char *gqhip_status_string(int s) {
 }
 
 int gqhip_last_hip_error(void) { return g_last_hip_error; }
+
+int gqhip_set_filter(int kind) {
+  if (kind != GQHIP_FILTER_AUTO && kind != GQHIP_FILTER_FP32) return GQHIP_ERR_INVALID_ARG;
+  g_filter_kind.store(kind, std::memory_order_relaxed);
+  return GQHIP_OK;
+}
+
+int gqhip_get_filter(void) { return g_filter_kind.load(std::memory_order_relaxed); }
+
+int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
+  if (!out8 || rows < 1 || n < 1 || dim < 1 || dim > kMaxDim) return GQHIP_ERR_INVALID_ARG;
+  const Plan pl = make_plan(rows, n, dim);
+  const WsLayout w = ws_layout(rows, n, dim);
+  out8[0] = w.rec; out8[1] = pl.mfma ? pl.nsplit : 0; out8[2] = pl.gt; out8[3] = pl.tiles_per_split;
+  out8[4] = pl.bf16 ? 1 : 0; out8[5] = pl.bf16 ? 220 + 24 * dim : 2 * dim + 4; out8[6] = pl.rt; out8[7] = w.total;
+  return GQHIP_OK;
+}
 
 int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim) {
   if (rows < 0 || n < 1 || dim < 1 || dim > kMaxDim) return -1;

@@ -31,6 +31,9 @@ _SIGNATURES = {
     "gqhip_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "gqhip_last_hip_error": (ctypes.c_int, []),
     "gqhip_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gqhip_set_filter": (ctypes.c_int, [ctypes.c_int]),
+    "gqhip_get_filter": (ctypes.c_int, []),
+    "gqhip_debug_plan": (ctypes.c_int, [_i64, _i64, _i64, ctypes.POINTER(_i64)]),
     "gqhip_codebook_absmax": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_scores_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double, _vp]),
     "gq_argmax_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double,
@@ -388,6 +391,36 @@ def profile_collect() -> Tuple[int, float]:
 
 def debug_enable(on: bool) -> None:
     lib().gqhip_debug_enable(1 if on else 0)
+
+
+FILTER_KINDS = {"auto": 0, "fp32": 1}
+
+
+def set_filter(kind: str) -> None:
+    """"auto": split-bf16 MFMA filter where it applies (dims 8/16/32), fp32 MFMA filter elsewhere; "fp32": always
+    the fp32 MFMA filter.  Process-wide; indices are identical either way (the exact re-rank decides)."""
+    if kind not in FILTER_KINDS:
+        raise GqHipError(f"unknown filter {kind!r} (expected one of {sorted(FILTER_KINDS)})")
+    _check(lib().gqhip_set_filter(FILTER_KINDS[kind]), "gqhip_set_filter")
+
+
+def get_filter() -> str:
+    k = lib().gqhip_get_filter()
+    return next(name for name, v in FILTER_KINDS.items() if v == k)
+
+
+def debug_plan(rows: int, n: int, dim: int) -> dict:
+    out = (_i64 * 8)()
+    _check(lib().gqhip_debug_plan(rows, n, dim, out), "gqhip_debug_plan")
+    keys = ("rec_offset", "nsplit", "gt", "tiles_per_split", "bf16", "ef_coeff", "rt", "ws_bytes")
+    return dict(zip(keys, (int(v) for v in out)))
+
+
+def debug_records(ws: Workspace, rows: int, n: int, dim: int):
+    """Candidate records the filter left in the workspace: (m [nsplit, rows, 3] fp32, ids [nsplit, rows, 2] int32)."""
+    pl = debug_plan(rows, n, dim)
+    raw = ws.buf[pl["rec_offset"]: pl["rec_offset"] + pl["nsplit"] * rows * 32].view(torch.int32).reshape(pl["nsplit"], rows, 8)
+    return raw[..., :3].contiguous().view(torch.float32), raw[..., 3:5].contiguous()
 
 
 def debug_counters(ws: Workspace) -> Tuple[int, int]:
