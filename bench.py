@@ -50,6 +50,7 @@ UNET = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=256, i
             ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[32], dropout=0.0)
 N_CODES, DIM = 65536, 16
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.5 PFLOP/s)
 
 
 def build_model(device):
@@ -65,7 +66,7 @@ def build_model(device):
     return vae.eval().to(device)
 
 
-def pmc_traffic_bytes():
+def pmc_traffic_bytes(kernel="gq_filter_bf16_kernel"):
     """HBM bytes per filter launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_*.csv,
     separate FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py at this shape).  Units are KiB; gfx950
     reports half of a wide coalesced read stream, so FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM)."""
@@ -77,7 +78,7 @@ def pmc_traffic_bytes():
         if not os.path.exists(path):
             return None
         rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if "gq_filter_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+                if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
         if not rows:
             return None
         vals[name] = sum(rows) / len(rows)
@@ -218,6 +219,26 @@ def main():
 
     stages = stage_split()
 
+    # The fp32 MFMA filter on the same rows, for comparison (same indices; untimed extra quantiser calls).
+    def fp32_filter_us(reps=5):
+        with torch.no_grad():
+            z = vae.encoder(x)
+            _lib.set_filter("fp32")
+            try:
+                vae.regularization(z)
+                torch.cuda.synchronize()
+                _lib.profile_enable(True)
+                for _ in range(reps):
+                    vae.regularization(z)
+                torch.cuda.synchronize()
+                n_l, ms = _lib.profile_collect()
+                _lib.profile_enable(False)
+            finally:
+                _lib.set_filter("auto")
+        return ms / max(n_l, 1) * 1e3
+
+    fp32_us = fp32_filter_us() if _lib.get_filter() == "auto" else None
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -228,6 +249,35 @@ def main():
         flops = 4.0 * DIM * N_CODES * rows  # 4*dim*N flops per row
         avg_ms = kernel_ms / max(launches, 1)
         achieved = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
+        bf16 = _lib.debug_plan(rows, N_CODES, DIM)["bf16"] == 1
+        if bf16:
+            # split-bf16 filter: every algorithmic fp32 MAC is executed as 3 bf16 MACs (A_h s_h + A_h s_l + A_l s_h)
+            roofline = {"kernel": "gq_filter_bf16_kernel<2,2,8,1> (split-bf16 MFMA filter of the fused quantiser)",
+                        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                        "executed": round(3 * achieved, 2), "executed_frac": round(3 * achieved / PEAK_BF16_TFLOPS, 4),
+                        "vs_fp32_mfma_peak": round(achieved / PEAK_F32_TFLOPS, 3),
+                        "note": "achieved = algorithmic fp32-equivalent flops (SURVEY 8d: 4*dim*N per row) / launch time; "
+                                "the kernel executes 3 bf16 MACs per algorithmic MAC (two-term bf16 splits, exact re-rank "
+                                "keeps the indices bit-identical), so executed = 3 x achieved is what the dense bf16 MFMA "
+                                "peak bounds; the algorithmic rate is vs_fp32_mfma_peak x the fp32 MFMA peak (157.3)",
+                        "traffic": pmc_traffic_bytes("gq_filter_bf16_kernel"),
+                        "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01 PMC passes; "
+                                        "algorithmic bytes 3.3e6 + 4.2e6 (+8.4e6 bf16 codebook image, +4.2e6 candidate records)"}
+            if fp32_us:
+                roofline["fp32_filter"] = {"kernel": "gq_filter_kernel<16,2,8,GQ,2> (GQHIP_FILTER=fp32)",
+                                           "avg_launch_us": round(fp32_us, 2),
+                                           "achieved": round(flops / (fp32_us * 1e-6) / 1e12, 2), "peak": PEAK_F32_TFLOPS,
+                                           "frac": round(flops / (fp32_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS, 4)}
+        else:
+            roofline = {"kernel": "gq_filter_kernel<16,2,8,GQ,2> (fp32 MFMA filter of the fused quantiser)",
+                        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": pmc_traffic_bytes("gq_filter_kernel"),
+                        "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01 PMC passes; "
+                                        "algorithmic bytes 7.5e6 (+4.2e6 candidate records)"}
+        roofline.update({"launches": launches, "avg_launch_us": round(avg_ms * 1e3, 2),
+                         "timing": "hipEvents attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream",
+                         "algorithmic_flops_per_launch": flops})
         line = {
             "metric": "images/sec encode+quantize+decode, 256x256, codebook 2^16",
             "value": round(args.batch * world * args.steps / elapsed, 3),
@@ -241,14 +291,7 @@ def main():
                        "global_batch": args.batch * world, "rows_per_step_per_gpu": rows,
                        "weights": "seeded random init (seed 1234), no checkpoint offline",
                        "parallelism": f"dp{world} image-sharded, one packed all_gather/step"},
-            "roofline": {"kernel": "gq_filter_kernel<16,2,8,GQ> (fp32 MFMA filter of the fused quantiser)",
-                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
-                         "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01 PMC passes; "
-                                         "algorithmic bytes 7.5e6 (+4.2e6 candidate records)",
-                         "launches": launches, "avg_launch_us": round(avg_ms * 1e3, 2),
-                         "timing": "hipEvents attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream",
-                         "algorithmic_flops_per_launch": flops},
+            "roofline": roofline,
             "stages_ms": stages,
         }
         if world == 1 and not args.no_cpu_baseline:

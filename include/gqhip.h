@@ -65,7 +65,7 @@ int gqhip_get_filter(void);
 
 /* Diagnostics: launch plan and workspace layout of the fused arg-max for a shape.  out8 = { byte offset of the
  * candidate records, code splits, tiles per candidate group, tiles per split, 1 if split-bf16, coefficient of the
- * filter error bound (E_f = coeff * 2^-24 * T), row tiles per wave, workspace bytes }. */
+ * filter error bound (E_f = coeff * 2^-24 * T), row tiles per wave, waves per filter block }. */
 int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8);
 
 

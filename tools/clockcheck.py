@@ -16,9 +16,12 @@ for _ in range(100):
     _lib.gq_argmax(mu, sd, cb, 1.0, absmax=4.6, ws=ws)
 torch.cuda.synchronize()
 L = _lib.lib()
-nblk = 512
+pl = _lib.debug_plan(rows, n, dim)
+rpb = 32 * pl['waves'] * pl['rt']
+nblk = ((rows + rpb - 1) // rpb) * pl['nsplit']
+print('plan:', pl, 'blocks:', nblk)
 # workspace layout: hdr(512) | rec (nsplit*rows*32) | fb (rows*4) | mu ...
-off = 512 + 8 * rows * 32 + ((rows * 4 + 255) // 256) * 256 + 33792   # hdr | rec | fb | spread slots
+off = 512 + pl['nsplit'] * rows * 32 + ((rows * 4 + 255) // 256) * 256 + 33792   # hdr | rec | fb | spread slots
 raw = ws.buf[off:off + nblk * 32].cpu().numpy().view(np.uint64).reshape(nblk, 4)
 t0 = raw[:, 0].min()
 start = (raw[:, 0] - t0) / 100.0   # us

@@ -19,7 +19,10 @@ def main():
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--filter", default=None, choices=["auto", "fp32"], help="filter kernel (default: library default)")
     a = ap.parse_args()
+    if a.filter:
+        _lib.set_filter(a.filter)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     mu = (0.9 * torch.randn(a.rows, a.dim, generator=g)).to(dev)
@@ -45,8 +48,12 @@ def main():
     torch.cuda.synchronize()
     fb, rr = _lib.debug_counters(ws)
     _lib.debug_enable(False)
-    print(f"rows={a.rows} dim={a.dim} n={a.n}: filter kernel {kms*1e3:.1f} us avg over {launches} launches "
-          f"-> {flops/kms/1e9:.1f} TFLOP/s ({flops/kms/1e9/157.3*100:.1f}% of 157.3); "
+    bf16 = _lib.debug_plan(a.rows, a.n, a.dim)["bf16"] == 1
+    tf = flops / kms / 1e9
+    rate = (f"{tf:.1f} algorithmic TFLOP/s = {tf/157.3:.2f}x the fp32 MFMA peak; executed 3x = {3*tf:.0f} TFLOP/s bf16 "
+            f"({3*tf/2500*100:.1f}% of 2500)") if bf16 else f"{tf:.1f} TFLOP/s ({tf/157.3*100:.1f}% of 157.3)"
+    print(f"rows={a.rows} dim={a.dim} n={a.n}: {'split-bf16' if bf16 else 'fp32'} filter kernel {kms*1e3:.1f} us avg over "
+          f"{launches} launches -> {rate}; "
           f"whole call wall {wall*1e6:.1f} us; fallback rows {fb}, re-ranked half-tiles/row {rr/a.rows:.3f}")
 
 

@@ -1,5 +1,5 @@
 """Steady-state per-step kernel breakdown from a rocprofv3 --kernel-trace csv of bench.py:
-steps are delimited by the gq_filter_kernel launches; only the last K steps are summed."""
+steps are delimited by the filter kernel launches (gq_filter_bf16_kernel or gq_filter_kernel); only the last K steps are summed."""
 import csv
 import glob
 import sys
@@ -9,7 +9,7 @@ d, last = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "gq_filter_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if ("gq_filter_kernel" in r["Kernel_Name"] or "gq_filter_bf16_kernel" in r["Kernel_Name"])]
 lo, hi = marks[-last - 1], marks[-1]
 acc, cnt = defaultdict(float), defaultdict(int)
 for r in rows[lo:hi]:

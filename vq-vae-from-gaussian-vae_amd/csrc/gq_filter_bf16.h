@@ -37,6 +37,7 @@ struct FilterBfParams {
   int nsplit, tiles_total, tiles_per_split;
   WsHeader *hdr;
   float absmax;
+  void *dbg;            // diagnostic builds only
 };
 
 struct SplitParams {
@@ -147,14 +148,20 @@ __device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[2 * NV], const 
   }
 }
 
-template <int NV, int RT, int CT, int GT>
-__global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
+// WAVES = 8: one 512-thread block per CU, so the two waves that share a SIMD belong to the SAME block and meet at
+// every chunk barrier.  With two independent 4-wave blocks per CU the SIMD's arbiter favours one of them: it
+// finishes at ~70 % of the kernel time and the other runs the rest alone, without a partner to hide its LDS
+// waits and epilogues behind (measured per block with GQHIP_CLOCK_STAMPS: 104 / 149 us).  One block per CU also
+// halves the L2 -> LDS staging traffic (one chunk copy serves 8 waves).
+template <int NV, int RT, int CT, int GT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
   constexpr int NCV = 2 * NV;                 // code (and row) vectors per tile
   constexpr int TILE_Q = NCV * 64;            // 16-byte slots per tile
   constexpr int CHUNK_Q = CT * TILE_Q;
-  constexpr int R4 = CHUNK_Q / 256;           // 16-byte loads per thread per chunk
+  constexpr int NT = 64 * WAVES;              // threads per block
+  constexpr int R4 = CHUNK_Q / NT;            // 16-byte loads per thread per chunk
   constexpr int NM = 3 * NV;                  // MFMAs per tile and row tile
-  static_assert(R4 >= 1 && CHUNK_Q % 256 == 0 && CT % GT == 0, "chunk: whole tile groups, whole thread passes");
+  static_assert(R4 >= 1 && CHUNK_Q % NT == 0 && CT % GT == 0, "chunk: whole tile groups, whole thread passes");
   __shared__ u32x4 lds[2][CHUNK_Q];
 
   const int tid = threadIdx.x;
@@ -166,6 +173,9 @@ __global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfPa
   const int t_end = min(t_begin + p.tiles_per_split, p.tiles_total);
   const int t_full_end = min(t_end, p.n / kTileCodes);    // complete tiles only
 
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_b0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (blockIdx.x == 0 && tid == 0) {  // workspace header for the kernels that follow on the stream
     p.hdr->fb_count = 0;
     p.hdr->reranked = 0ull;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfPa
   u32x4 rv[RT][NCV];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    int row = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
+    int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;
     row = min(row, p.rows - 1);
 #pragma unroll
     for (int v = 0; v < NCV; ++v) rv[rt][v] = p.rowimg[((long)row * NCV + v) * 2 + h];
@@ -196,11 +206,11 @@ __global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfPa
   auto load_chunk = [&](int tile0) {
     const u32x4 *src = p.cbimg + (long)tile0 * TILE_Q + tid;
 #pragma unroll
-    for (int r = 0; r < R4; ++r) stage[r] = src[256 * r];   // the image is padded by CT tiles
+    for (int r = 0; r < R4; ++r) stage[r] = src[NT * r];    // the image is padded by CT tiles
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < R4; ++r) lds[buf][tid + 256 * r] = stage[r];
+    for (int r = 0; r < R4; ++r) lds[buf][tid + NT * r] = stage[r];
   };
   auto read_ops = [&](const u32x4 *tile, u32x4 (&cv)[NCV]) {
 #pragma unroll
@@ -234,6 +244,9 @@ __global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfPa
     for (int v = 0; v < NCV; ++v) asm volatile("" ::"v"(rv[rt][v]));
   __syncthreads();
 
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int S0 = NM >= 6 ? 2 : 1;   // MFMA steps issued before the previous tile's epilogue
   f32x16 dprev[RT];
 #pragma unroll
@@ -314,6 +327,13 @@ __global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfPa
     __syncthreads();
   }
   if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_r2 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0 && blockIdx.x < 24) {   // diagnostic build only: shader clocks and 100 MHz ticks spent in the main loop
+    p.hdr->stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+    p.hdr->stamps[2 * blockIdx.x + 1] = st_r2 - st_r0;
+  }
+#endif
 
   // ---- leftovers: the one partial tile (n % 32 != 0; zero-padded in the image) / an open group ----
   const bool pending = ntiles > 0 && (ntiles % GT) != 0;
@@ -347,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfPa
     top3_insert(b1, k1, a1, a2v, a3, j1, j2);
     top3_insert(b2, k2, a1, a2v, a3, j1, j2);
     top3_insert_value(b3, a2v, a3);
-    const int row = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
+    const int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;
     if (h == 0 && row < p.rows) {
       Rec r;
       r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.id1 = j1; r.id2 = j2;
@@ -355,6 +375,16 @@ __global__ __launch_bounds__(256, 2) void gq_filter_bf16_kernel(const FilterBfPa
       p.rec[(long)split * p.rows + row] = r;
     }
   }
+#ifdef GQHIP_CLOCK_STAMPS
+  if (tid == 0 && blockIdx.x < 2048) {   // per-block timeline + placement, same record as gq_filter_kernel's
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + 4 * blockIdx.x;
+    o[0] = st_b0;
+    o[1] = __builtin_amdgcn_s_memrealtime();
+    o[2] = ((st_r0 - st_b0) << 32) | (st_r2 - st_b0);
+    o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+           (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
 }
 
 }  // namespace gqhip

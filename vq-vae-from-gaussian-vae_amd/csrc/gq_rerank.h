@@ -55,8 +55,8 @@ struct SpreadPartial {
   int pad;
 };
 struct SpreadSlot {
-  unsigned long long fmax_enc;   // order-preserving encoding of the fp64 row maximum (0 = none yet)
-  int done;                      // slices finished in pass 2
+  unsigned long long pad0;
+  int done;                      // slices finished
   int pad;
   SpreadPartial part[kSpreadSlices];
 };
@@ -164,94 +164,117 @@ __device__ __forceinline__ void write_result(const RerankParams &p, long row, in
     p.zhat[out_zhat_offset(p.omap, row, lane, p.dim)] = p.cb[(long)best * p.dim + lane];
 }
 
-// One wave per row.
-template <int MODE>
+// GROUP lanes per row, GROUP = codes per candidate (16 * gt): a wave handles 64 / GROUP rows, each lane group
+// walks its row's candidate list one candidate (= GROUP codes, one per lane) at a time.  The kernel is a chain of
+// dependent memory round trips (records -> row operands / code rows -> result), so rows per wave is what sets
+// its duration: 4 rows per wave with the split-bf16 filter's 16-code candidates.
+template <int MODE, int GROUP>
 __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
-  __shared__ int cand[4][2 * kMaxSplit];
-  __shared__ RowOps rops[4];
+  constexpr int RPW = 64 / GROUP;            // rows per wave
+  constexpr int RPB = 4 * RPW;               // rows per block
+  constexpr int NSI = kMaxSplit / GROUP;     // record passes per lane (code splits <= kMaxSplit)
+  __shared__ int cand[RPB][2 * kMaxSplit];
+  __shared__ RowOps rops[RPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long row = (long)blockIdx.x * 4 + wave;
-  if (row >= p.rows) return;
+  const int sub = lane % GROUP, grp = lane / GROUP;
+  const int slot = wave * RPW + grp;
+  const long row_raw = (long)blockIdx.x * RPB + slot;
+  if ((long)blockIdx.x * RPB + wave * RPW >= p.rows) return;        // whole wave past the end
+  const bool live = row_raw < p.rows;
+  const long row = live ? row_raw : p.rows - 1;                     // dead groups mirror the last row, write nothing
+  const int gshift = grp * GROUP;
+  const unsigned long long glow = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+  auto group_bits = [&](bool c) { return (__ballot(c) >> gshift) & glow; };
 
   // ---- rounding bound E(r) -> margin --------------------------------------
   const double u = 5.9604644775390625e-08;  // 2^-24
   const double N1 = (double)p.hdr->absmax, N2 = N1 * N1;
   double T = 0.0, G = 0.0;
   bool bad = !(N1 == N1) || N1 > 1e18;
-  if (lane < p.dim) {
-    const double m = fabs((double)p.mu[row * p.dim + lane]);
+  for (int i = sub; i < p.dim; i += GROUP) {
+    const double m = fabs((double)p.mu[row * p.dim + i]);
     if constexpr (MODE == kModeGQ) {
-      const double s = (double)p.sd[row * p.dim + lane];
-      const double l = p.lsd ? (double)p.lsd[row * p.dim + lane] : log(s);
+      const double s = (double)p.sd[row * p.dim + i];
+      const double l = p.lsd ? (double)p.lsd[row * p.dim + i] : log(s);
       const double inv = 1.0 / (s * s);
       const double b = fabs((double)p.beta);
-      T = (0.5 * b + 0.5 * inv) * N2 + m * inv * N1;
-      G = (N1 + m) * (N1 + m) * 0.5 * inv + fabs(l) + (double)half_log_2pi() +
-          b * (0.5 * N2 + (double)half_log_2pi());
-      bad = bad || !(s > 0.0) || !(T < 1e30) || !(G < 1e30);
+      const double t = (0.5 * b + 0.5 * inv) * N2 + m * inv * N1;
+      const double g = (N1 + m) * (N1 + m) * 0.5 * inv + fabs(l) + (double)half_log_2pi() +
+                       b * (0.5 * N2 + (double)half_log_2pi());
+      T += t;
+      G += g;
+      bad = bad || !(s > 0.0) || !(t < 1e30) || !(g < 1e30);
     } else {
-      T = N2 + 2.0 * m * N1;
-      G = 0.0;
-      bad = bad || !(T < 1e30);
+      const double t = N2 + 2.0 * m * N1;
+      T += t;
+      bad = bad || !(t < 1e30);
     }
   }
-  T = wave_sum(T);
-  G = wave_sum(G);
+#pragma unroll
+  for (int o = GROUP / 2; o > 0; o >>= 1) {
+    T += __shfl_xor(T, o);
+    G += __shfl_xor(G, o);
+  }
   const double Ef = (double)p.ef_coeff * u * T;
   const double Er = MODE == kModeGQ ? (p.dim + 16.0) * u * G : 1e-12 * T;
   const double margin = 2.5 * (Ef + Er) + 1e-30;
-  bad = __any(bad) || !(margin < 1e30);
+  bad = group_bits(bad) != 0ull || !(margin < 1e30);
 
   // ---- gather the per-split records ----------------------------------------
   const float NEG_INF = -__builtin_inff();
-  Rec r;
-  r.m1 = r.m2 = r.m3 = NEG_INF;
-  r.id1 = r.id2 = 0;
-  if (lane < p.nsplit) r = p.rec[(long)lane * p.rows + row];
-  float fmax = r.m1;
+  Rec r[NSI];
+  float fmax = NEG_INF;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, o));
+  for (int k = 0; k < NSI; ++k) {
+    r[k].m1 = r[k].m2 = r[k].m3 = NEG_INF;
+    r[k].id1 = r[k].id2 = 0;
+    const int s = k * GROUP + sub;
+    if (s < p.nsplit) r[k] = p.rec[(long)s * p.rows + row];
+    fmax = __builtin_fmaxf(fmax, r[k].m1);
+  }
+#pragma unroll
+  for (int o = GROUP / 2; o > 0; o >>= 1) fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, o));
   bad = bad || !(fmax == fmax) || !(fmax > NEG_INF) || !(fmax < __builtin_inff());
 
   const double thr = (double)fmax - margin;
-  const bool c1 = (double)r.m1 >= thr, c2 = (double)r.m2 >= thr, c3 = (double)r.m3 >= thr;
-  const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
-  if (bad || b3 != 0ull) {
-    if (lane == 0) {
+  const unsigned long long lt = (1ull << sub) - 1ull;
+  int total = 0;
+  bool third = false;
+#pragma unroll
+  for (int k = 0; k < NSI; ++k) {
+    const bool c1 = (double)r[k].m1 >= thr, c2 = (double)r[k].m2 >= thr, c3 = (double)r[k].m3 >= thr;
+    const unsigned long long b1 = group_bits(c1), b2 = group_bits(c2), b3 = group_bits(c3);
+    third = third || b3 != 0ull;
+    const int n1 = __popcll(b1);
+    if (c1) cand[slot][total + __popcll(b1 & lt)] = r[k].id1;
+    if (c2) cand[slot][total + n1 + __popcll(b2 & lt)] = r[k].id2;
+    total += n1 + __popcll(b2);
+  }
+  const bool undecided = bad || third;       // group-uniform
+  if (undecided) {
+    if (live && sub == 0) {
       const int pos = atomicAdd(&p.hdr->fb_count, 1);
       p.fb_list[pos] = (int)row;
-      if (pos < kSpreadRows) {
-        p.spread[pos].fmax_enc = 0ull;
-        p.spread[pos].done = 0;
-      }
+      if (pos < kSpreadRows) p.spread[pos].done = 0;
     }
-    return;
+    total = 0;
   }
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const int n1 = __popcll(b1);
-  const int total = n1 + __popcll(b2);
-  if (c1) cand[wave][__popcll(b1 & lt)] = r.id1;
-  if (c2) cand[wave][n1 + __popcll(b2 & lt)] = r.id2;
-  if (lane < p.dim) load_row_ops(p, row, lane, rops[wave]);
+  for (int i = sub; i < p.dim; i += GROUP) load_row_ops(p, row, i, rops[slot]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- exact scores of every code in the flagged half-groups (16*gt codes each) ----
+  // ---- exact scores of every code in the flagged groups (GROUP = 16*gt codes each, one per lane) ----
   double best_s = 0.0;
   int best_i = 0x7fffffff;
   bool have = false;
-  const int per = 16 * p.gt;          // codes per candidate: 32 or 64
-  const int cpp = 64 / per;           // candidates per wave pass
-  for (int g = 0; g * cpp < total; ++g) {
-    const int e = g * cpp + lane / per;
+  for (int e = 0; __any(e < total); ++e) {
     if (e < total) {
-      const int id = cand[wave][e];
-      const int rr = lane % per;
-      const int tile = (id >> 1) * p.gt + (rr >> 4);
-      const int code = tile * kTileCodes + (rr & 3) + 8 * ((rr & 15) >> 2) + 4 * (id & 1);
+      const int id = cand[slot][e];
+      const int tile = (id >> 1) * p.gt + (sub >> 4);
+      const int code = tile * kTileCodes + (sub & 3) + 8 * ((sub & 15) >> 2) + 4 * (id & 1);
       if (code < p.n) {
-        const double s = exact_score<MODE>(p, rops[wave], code);
+        const double s = exact_score<MODE>(p, rops[slot], code);
         if (!have || better_d(s, code, best_s, best_i)) {
           best_s = s;
           best_i = code;
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = GROUP / 2; o > 0; o >>= 1) {
     const double os = __shfl_xor(best_s, o);
     const int oi = __shfl_xor(best_i, o);
     const bool oh = __shfl_xor((int)have, o) != 0;
@@ -271,8 +294,12 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
       have = true;
     }
   }
-  if (p.stats && lane == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)total);
-  write_result(p, row, best_i, lane);
+  if (!live || undecided) return;
+  if (p.stats && sub == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)total);
+  if (sub == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best_i;
+  if (p.zhat)
+    for (int i = sub; i < p.dim; i += GROUP)
+      p.zhat[out_zhat_offset(p.omap, row, i, p.dim)] = p.cb[(long)best_i * p.dim + i];
 }
 
 // Second-stage filter for the rows the fp32 filter could not decide (fallback list).
@@ -423,19 +450,16 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
 }
 
 // ---- short lists: every listed row is spread over kSpreadSlices blocks ------------------------------
-// Same two passes as gq_fallback64_kernel, as two launches (PASS 1: fp64 row maximum through an atomic max;
-// PASS 2: exact scores inside the window, per-slice partial results, the last slice to finish combines them),
-// so that a lone undecided row costs a few microseconds instead of one block walking all 65 536 codes.
-__device__ __forceinline__ unsigned long long enc_f64(double d) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double dec_f64(unsigned long long e) {
-  const unsigned long long b = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
-  return __longlong_as_double((long long)b);
-}
+// One launch.  A block owns a slice of the codes: fp64 values of the expansion for its codes (kept in
+// registers), the slice maximum, then the exact reference-order score of every code inside the window taken
+// around the SLICE maximum.  That window contains the window around the row maximum (slice max <= row max, and
+// the margin grows as the maximum drops), so the union over the slices is a superset of the codes the row-wide
+// rule would re-evaluate -- and the reference arg-max is the exact maximum over any set that contains it.
+// Per-slice partial results go to the workspace; the last slice to finish combines them.  A lone undecided row
+// costs a few microseconds instead of one block walking all 65 536 codes twice.
+constexpr int kSpreadCodes = 16;    // codes per thread held in registers (slice <= 256 * kSpreadCodes codes)
 
-template <int MODE, int DIM, int PASS>
+template <int MODE, int DIM>
 __global__ __launch_bounds__(256) void gq_fallback64_spread_kernel(const RerankParams p) {
   __shared__ RowOps rops;
   __shared__ double sh_d[4];
@@ -489,41 +513,102 @@ __global__ __launch_bounds__(256) void gq_fallback64_spread_kernel(const RerankP
   };
   const int per = (p.n + kSpreadSlices - 1) / kSpreadSlices;
   const int j0 = sl * per, j1 = min(p.n, j0 + per);
-  SpreadSlot &slot = p.spread[e];
-  if constexpr (PASS == 1) {
-    double fmax = -INF;
+  const bool in_regs = per <= 256 * kSpreadCodes;      // block-uniform; otherwise the values are recomputed
+  double fv[kSpreadCodes];
+  double fmax = -INF;
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kSpreadCodes; ++k) {
+      const int j = j0 + tid + 256 * k;
+      fv[k] = j < j1 ? f64_of(j) : -INF;
+      fmax = fv[k] > fmax ? fv[k] : fmax;              // NaN never enters
+    }
+  } else {
     for (int j = j0 + tid; j < j1; j += 256) {
       const double f = f64_of(j);
-      fmax = f > fmax ? f : fmax;            // NaN never enters
+      fmax = f > fmax ? f : fmax;
     }
+  }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double of = __shfl_xor(fmax, o);
-      fmax = of > fmax ? of : fmax;
-    }
-    if (lane == 0 && fmax > -INF) atomicMax(&slot.fmax_enc, enc_f64(fmax));
+  for (int o = 32; o > 0; o >>= 1) {
+    const double of = __shfl_xor(fmax, o);
+    fmax = of > fmax ? of : fmax;
+  }
+  if (lane == 0) sh_d[wave] = fmax;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) fmax = sh_d[k] > fmax ? sh_d[k] : fmax;
+  __syncthreads();
+  double marg;
+  if constexpr (MODE == kModeGQ) {
+    const double cu = (DIM + 16.0) * u;
+    double Q = Cr + 0.5 * bb * DIM * N2 - fmax;
+    Q = Q > 0.0 ? Q : 0.0;
+    marg = 2.5 * cu * (Q + R0) / (1.0 - cu) + 1e-12 * T + 1e-30;
   } else {
-    const unsigned long long fe = slot.fmax_enc;
-    const double fmax = fe ? dec_f64(fe) : -INF;
-    double marg;
-    if constexpr (MODE == kModeGQ) {
-      const double cu = (DIM + 16.0) * u;
-      double Q = Cr + 0.5 * bb * DIM * N2 - fmax;
-      Q = Q > 0.0 ? Q : 0.0;
-      marg = 2.5 * cu * (Q + R0) / (1.0 - cu) + 1e-12 * T + 1e-30;
-    } else {
-      marg = 1e-11 * T + 1e-30;
-    }
-    bad = bad || !(fmax > -INF) || !(fmax < INF) || !(T < 1e300) || !(marg < 1e300);
-    const double thr = bad ? -INF : fmax - marg;
-    double best_s = 0.0;
-    int best_i = 0x7fffffff;
-    bool have = false;
-    for (int j = j0 + tid; j < j1; j += 256) {
-      if (bad || f64_of(j) >= thr) {
-        const double s = exact_score_cold<MODE>(p.cb, &rops, j, DIM, p.beta);
-        if (!have || better_d(s, j, best_s, best_i)) { best_s = s; best_i = j; have = true; }
+    marg = 1e-11 * T + 1e-30;
+  }
+  // a slice without a finite value contributes nothing unless the row itself is degenerate (then: exhaustive)
+  bad = bad || !(fmax < INF) || !(T < 1e300) || !(marg < 1e300) || (fmax != fmax);
+  const bool empty = !bad && !(fmax > -INF);
+  const double thr = bad ? -INF : fmax - marg;
+  double best_s = 0.0;
+  int best_i = 0x7fffffff;
+  bool have = false;
+  if (!empty) {
+    if (in_regs) {
+#pragma unroll
+      for (int k = 0; k < kSpreadCodes; ++k) {
+        const int j = j0 + tid + 256 * k;
+        if (j < j1 && (bad || fv[k] >= thr)) {
+          const double s = exact_score_cold<MODE>(p.cb, &rops, j, DIM, p.beta);
+          if (!have || better_d(s, j, best_s, best_i)) { best_s = s; best_i = j; have = true; }
+        }
       }
+    } else {
+      for (int j = j0 + tid; j < j1; j += 256) {
+        if (bad || f64_of(j) >= thr) {
+          const double s = exact_score_cold<MODE>(p.cb, &rops, j, DIM, p.beta);
+          if (!have || better_d(s, j, best_s, best_i)) { best_s = s; best_i = j; have = true; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double os = __shfl_xor(best_s, o);
+    const int oi = __shfl_xor(best_i, o);
+    const bool oh = __shfl_xor((int)have, o) != 0;
+    if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+  }
+  if (lane == 0) { sh_d[wave] = best_s; sh_i[wave] = have ? best_i : 0x7fffffff; }
+  __syncthreads();
+  SpreadSlot &slot = p.spread[e];
+  if (tid == 0) {
+    have = false;
+    for (int k = 0; k < 4; ++k) {
+      const double os = sh_d[k];
+      const int oi = sh_i[k];
+      if (oi != 0x7fffffff && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+    }
+    slot.part[sl].s = best_s;
+    slot.part[sl].i = have ? best_i : 0x7fffffff;
+    __threadfence();
+    sh_last = atomicAdd(&slot.done, 1) == kSpreadSlices - 1;
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  __threadfence();
+  // last slice of this row: combine the partial results (one wave) and write the answer
+  if (wave == 0) {
+    have = false;
+    best_s = 0.0;
+    best_i = 0x7fffffff;
+    if (lane < kSpreadSlices) {
+      const volatile SpreadPartial *pp = &slot.part[lane];
+      best_s = pp->s;
+      best_i = pp->i;
+      have = best_i != 0x7fffffff;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -532,43 +617,7 @@ __global__ __launch_bounds__(256) void gq_fallback64_spread_kernel(const RerankP
       const bool oh = __shfl_xor((int)have, o) != 0;
       if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
     }
-    if (lane == 0) { sh_d[wave] = best_s; sh_i[wave] = have ? best_i : 0x7fffffff; }
-    __syncthreads();
-    if (tid == 0) {
-      have = false;
-      for (int k = 0; k < 4; ++k) {
-        const double os = sh_d[k];
-        const int oi = sh_i[k];
-        if (oi != 0x7fffffff && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
-      }
-      slot.part[sl].s = best_s;
-      slot.part[sl].i = have ? best_i : 0x7fffffff;
-      __threadfence();
-      sh_last = atomicAdd(&slot.done, 1) == kSpreadSlices - 1;
-    }
-    __syncthreads();
-    if (!sh_last) return;
-    __threadfence();
-    // last slice of this row: combine the partial results (one wave) and write the answer
-    if (wave == 0) {
-      have = false;
-      best_s = 0.0;
-      best_i = 0x7fffffff;
-      if (lane < kSpreadSlices) {
-        const volatile SpreadPartial *pp = &slot.part[lane];
-        best_s = pp->s;
-        best_i = pp->i;
-        have = best_i != 0x7fffffff;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double os = __shfl_xor(best_s, o);
-        const int oi = __shfl_xor(best_i, o);
-        const bool oh = __shfl_xor((int)have, o) != 0;
-        if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
-      }
-      write_result(p, row, best_i, lane);
-    }
+    write_result(p, row, best_i, lane);
   }
 }
 

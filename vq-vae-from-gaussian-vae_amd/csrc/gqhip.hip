@@ -44,6 +44,7 @@ struct Plan {
   int gt;               // tiles per candidate group: 4 for dim <= 8 and for the split-bf16 filter, else 2
   bool bf16;            // split-bf16 filter (gq_filter_bf16.h) instead of the fp32 MFMA one
   int ct;               // tiles per LDS chunk of the split-bf16 filter
+  int waves;            // waves per block: 8 (one block per CU) for the split-bf16 filter, else 4
 };
 
 // Filter selection: 0 = auto (split-bf16 where it applies: dims 8/16/32), 1 = always the fp32 MFMA filter.
@@ -63,11 +64,14 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   static const int env_blocks = getenv("GQHIP_TARGET_BLOCKS") ? atoi(getenv("GQHIP_TARGET_BLOCKS")) : 0;
   pl.rt = rows >= 8192 ? 2 : 1;
   if (env_rt == 1 || env_rt == 2) pl.rt = env_rt;
-  pl.rows_per_block = 128 * pl.rt;
+  pl.bf16 = pl.mfma && (dim == 8 || dim == 16 || dim == 32) && want_bf16_filter();
+  static const int env_waves = getenv("GQHIP_BF16_WAVES") ? atoi(getenv("GQHIP_BF16_WAVES")) : 0;
+  pl.waves = pl.bf16 ? (env_waves == 4 ? 4 : 8) : 4;
+  pl.rows_per_block = 32 * pl.waves * pl.rt;
   pl.row_blocks = (int)((rows + pl.rows_per_block - 1) / pl.rows_per_block);
-  // ~2 blocks per CU on 256 CUs; splits in multiples of 8 so that
+  // 4-wave blocks: ~2 blocks per CU on 256 CUs; 8-wave blocks: one per CU.  Splits in multiples of 8 so that
   // blockIdx % 8 (XCD) == split % 8.
-  const int target = env_blocks > 0 ? env_blocks : 512;
+  const int target = env_blocks > 0 ? env_blocks : (pl.waves == 8 ? 256 : 512);
   int s = (target + pl.row_blocks - 1) / (pl.row_blocks > 0 ? pl.row_blocks : 1);
   s = ((s + 7) / 8) * 8;
   static const int env_nsplit = getenv("GQHIP_NSPLIT") ? atoi(getenv("GQHIP_NSPLIT")) : 0;
@@ -76,12 +80,11 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   if (s > pl.tiles_total) s = pl.tiles_total;
   if (s < 1) s = 1;
   pl.tiles_per_split = (pl.tiles_total + s - 1) / s;
-  pl.bf16 = pl.mfma && (dim == 8 || dim == 16 || dim == 32) && want_bf16_filter();
   pl.ct = dim == 32 ? 4 : 8;
   static const int env_bgt = getenv("GQHIP_BF16_GT") ? atoi(getenv("GQHIP_BF16_GT")) : 0;
   // split-bf16: the tracker's VALU work overlaps the bf16 MFMAs, so the finest candidate (one tile half =
   // 16 codes) is free in the filter and halves / quarters the exact re-rank work
-  pl.gt = pl.bf16 ? ((env_bgt == 1 || env_bgt == 2 || env_bgt == 4) ? env_bgt : 1) : (dim <= 8 ? 4 : 2);
+  pl.gt = pl.bf16 ? ((pl.waves == 4 && (env_bgt == 2 || env_bgt == 4)) ? env_bgt : 1) : (dim <= 8 ? 4 : 2);
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   return pl;
@@ -171,10 +174,22 @@ int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t s
   return check_launch();
 }
 
+// re-rank: GROUP = codes per candidate = lanes per row
+template <int MODE>
+void launch_rerank(const RerankParams &rp, int64_t rows, hipStream_t st) {
+  if (rp.gt == 1)
+    hipLaunchKernelGGL((gq_rerank_kernel<MODE, 16>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, rp);
+  else if (rp.gt == 2)
+    hipLaunchKernelGGL((gq_rerank_kernel<MODE, 32>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, rp);
+  else
+    hipLaunchKernelGGL((gq_rerank_kernel<MODE, 64>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rp);
+}
+
 template <int MODE>
 int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitParams &sp, int dim, hipStream_t st) {
   const long split_threads = (long)pl.tiles_total * 64 + (long)sp.rows * 2;
   const dim3 sgrid((unsigned)((split_threads + 255) / 256)), grid((unsigned)(pl.row_blocks * pl.nsplit)), block(256);
+  const dim3 fblock((unsigned)(64 * pl.waves));
   switch (dim) {
     case 8: hipLaunchKernelGGL((bf16_split_kernel<MODE, 8>), sgrid, block, 0, st, sp); break;
     case 16: hipLaunchKernelGGL((bf16_split_kernel<MODE, 16>), sgrid, block, 0, st, sp); break;
@@ -184,18 +199,19 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitPara
   int rc = check_launch();
   if (rc != GQHIP_OK) return rc;
   ProfScope prof;
-#define GQ_LAUNCH_BF1(NV, R, C, G)                                                                        \
+#define GQ_LAUNCH_BF1(NV, R, C, G, W)                                                                       \
   do {                                                                                                    \
     if (prof.on)                                                                                          \
-      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, G>), grid, block, 0, st, prof.a, prof.b, 0, fp); \
+      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, G, W>), grid, fblock, 0, st, prof.a, prof.b, 0, fp); \
     else                                                                                                  \
-      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, G>), grid, block, 0, st, fp);                      \
+      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, G, W>), grid, fblock, 0, st, fp);                  \
   } while (0)
 #define GQ_LAUNCH_BF(NV, R, C)                                                                            \
   do {                                                                                                    \
-    if (pl.gt == 1) GQ_LAUNCH_BF1(NV, R, C, 1);                                                           \
-    else if (pl.gt == 2) GQ_LAUNCH_BF1(NV, R, C, 2);                                                      \
-    else GQ_LAUNCH_BF1(NV, R, C, 4);                                                                      \
+    if (pl.waves == 8) GQ_LAUNCH_BF1(NV, R, C, 1, 8);                                                     \
+    else if (pl.gt == 1) GQ_LAUNCH_BF1(NV, R, C, 1, 4);                                                   \
+    else if (pl.gt == 2) GQ_LAUNCH_BF1(NV, R, C, 2, 4);                                                   \
+    else GQ_LAUNCH_BF1(NV, R, C, 4, 4);                                                                   \
   } while (0)
   if (pl.rt == 2) {
     switch (dim) {
@@ -260,11 +276,12 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
     fp.rows = (int)rows; fp.n = (int)n;
     fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
     fp.hdr = hdr; fp.absmax = cb_absmax;
+    fp.dbg = ws + w.mu;   // scratch rows area (unused by gq_argmax_f32); read by diagnostic builds only
     if (need_absmax && hipMemsetAsync(&hdr->absmax, 0, sizeof(float), st) != hipSuccess) return check_launch();
     int rc = launch_filter_bf16<MODE>(pl, fp, sp, (int)dim, st);
     if (rc != GQHIP_OK) return rc;
     if (need_absmax) launch_absmax();
-    hipLaunchKernelGGL((gq_rerank_kernel<MODE>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rp);
+    launch_rerank<MODE>(rp, rows, st);
     rc = check_launch();
     if (rc != GQHIP_OK) return rc;
   } else if (pl.mfma) {
@@ -279,13 +296,13 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
     int rc = launch_filter<MODE>(pl, fp, (int)dim, st);
     if (rc != GQHIP_OK) return rc;
     if (need_absmax) launch_absmax();   // after the filter (it owns the header init), before the re-rank
-    hipLaunchKernelGGL((gq_rerank_kernel<MODE>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rp);
+    launch_rerank<MODE>(rp, rows, st);
     rc = check_launch();
     if (rc != GQHIP_OK) return rc;
   }
   if (pl.mfma) {
     // rows the filter could not decide: fp64 second-stage filter + exact re-rank (usually none or a handful).
-    // Short lists (<= kSpreadRows) are spread over kSpreadSlices blocks per row by the two spread launches;
+    // Short lists (<= kSpreadRows) are spread over kSpreadSlices blocks per row by the spread kernel;
     // longer ones go to gq_fallback64_kernel.  Each kernel reads the list length and returns if it is not its turn.
     const int64_t groups = (rows + kFallbackRows - 1) / kFallbackRows;
     const int fb_blocks = (int)(groups < 2048 ? groups : 2048);
@@ -293,8 +310,7 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
     const dim3 sp_grid((unsigned)(sp_rows * kSpreadSlices));
 #define GQ_FB(D)                                                                                              \
   do {                                                                                                        \
-    hipLaunchKernelGGL((gq_fallback64_spread_kernel<MODE, D, 1>), sp_grid, dim3(256), 0, st, rp);             \
-    hipLaunchKernelGGL((gq_fallback64_spread_kernel<MODE, D, 2>), sp_grid, dim3(256), 0, st, rp);             \
+    hipLaunchKernelGGL((gq_fallback64_spread_kernel<MODE, D>), sp_grid, dim3(256), 0, st, rp);                \
     if (rows > kSpreadRows)                                                                                   \
       hipLaunchKernelGGL((gq_fallback64_kernel<MODE, D>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp);   \
   } while (0)
@@ -345,7 +361,7 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
   const Plan pl = make_plan(rows, n, dim);
   const WsLayout w = ws_layout(rows, n, dim);
   out8[0] = w.rec; out8[1] = pl.mfma ? pl.nsplit : 0; out8[2] = pl.gt; out8[3] = pl.tiles_per_split;
-  out8[4] = pl.bf16 ? 1 : 0; out8[5] = pl.bf16 ? 220 + 24 * dim : 2 * dim + 4; out8[6] = pl.rt; out8[7] = w.total;
+  out8[4] = pl.bf16 ? 1 : 0; out8[5] = pl.bf16 ? 220 + 24 * dim : 2 * dim + 4; out8[6] = pl.rt; out8[7] = pl.waves;
   return GQHIP_OK;
 }
 

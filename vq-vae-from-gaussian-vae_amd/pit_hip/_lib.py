@@ -412,7 +412,7 @@ def get_filter() -> str:
 def debug_plan(rows: int, n: int, dim: int) -> dict:
     out = (_i64 * 8)()
     _check(lib().gqhip_debug_plan(rows, n, dim, out), "gqhip_debug_plan")
-    keys = ("rec_offset", "nsplit", "gt", "tiles_per_split", "bf16", "ef_coeff", "rt", "ws_bytes")
+    keys = ("rec_offset", "nsplit", "gt", "tiles_per_split", "bf16", "ef_coeff", "rt", "waves")
     return dict(zip(keys, (int(v) for v in out)))
 
 
