@@ -495,3 +495,27 @@ def test_rccl_single_rank_gather_of_packed_record():
         assert float(t.item()) == 1.25
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("filt", ["auto", "fp32"])
+@pytest.mark.parametrize("rows,n,dim", [(256, 1024, 8), (1000, 4096, 16), (3000, 65536, 16), (500, 5000, 32)])
+def test_vq_multi_candidate(rows, n, dim, filt):
+    """VQ arg-min on random data, where the split-bf16 filter's margin leaves several candidate groups per row
+    for the exact fp64 arbiter: indices must equal the brute-force fp64 arg-min wherever it is not a rounding tie."""
+    from pit_hip import _lib
+
+    g = torch.Generator().manual_seed(7 + rows)
+    emb = torch.randn(n, dim, generator=g)
+    z = torch.randn(rows, dim, generator=g)
+    zz, ee = (z.double() ** 2).sum(1, keepdim=True), (emb.double() ** 2).sum(1)[None]
+    d = zz + ee - 2 * z.double() @ emb.double().T
+    ref = d.argmin(1)
+    _lib.set_filter(filt)
+    try:
+        idx, zq = _lib.vq_argmin(z.to(DEV), emb.to(DEV))
+    finally:
+        _lib.set_filter("auto")
+    idx = idx.cpu()
+    gap = d.gather(1, idx[:, None])[:, 0] - d.gather(1, ref[:, None])[:, 0]
+    assert float(gap.max()) <= 1e-9, f"{int((gap > 1e-9).sum())} rows picked a farther codeword (max gap {float(gap.max()):.3g})"
+    assert torch.equal(zq.cpu(), emb[idx])

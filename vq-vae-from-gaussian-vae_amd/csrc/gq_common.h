@@ -136,7 +136,12 @@ __device__ inline double vq_neg_dist(const float *__restrict__ e, const float *_
     ee += b * b;
     ze += a * b;
   }
-  return -(zz + ee - 2.0 * ze);
+  double r = -(zz + ee - 2.0 * ze);
+  // Opaque to the optimiser: with the negation visible, hipcc (ROCm 7.2, -O3) folds it into the fp64 compares of
+  // the callers' (score, index) selection as source modifiers and the multi-candidate re-rank then keeps the lower
+  // index instead of the larger score (reproduced on gfx950; tests/test_gpu_modules.py::test_vq_multi_candidate).
+  asm volatile("" : "+v"(r));
+  return r;
 }
 
 }  // namespace gqhip

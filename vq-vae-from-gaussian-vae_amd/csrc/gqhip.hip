@@ -262,6 +262,8 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
   rp.spread = reinterpret_cast<SpreadSlot *>(ws + w.spread);
   rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
   rp.ef_coeff = pl.bf16 ? (float)(220 + 24 * dim) : (float)(2 * dim + 4);
+  static const double env_ef = getenv("GQHIP_EF_COEFF") ? atof(getenv("GQHIP_EF_COEFF")) : 0.0;   // diagnostics
+  if (env_ef > 0.0) rp.ef_coeff = (float)env_ef;
   rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
 
