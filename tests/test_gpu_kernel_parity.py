@@ -220,7 +220,7 @@ def test_reference_smoke_loop_shape_max_size(filter_kind):
     assert np.array_equal(out.argmax(1).cpu().numpy()[clear], ri[clear])
 
 
-@pytest.mark.parametrize("dim,rows,n", [(16, 4096, 65536), (8, 2048, 8192), (32, 1024, 4096)])
+@pytest.mark.parametrize("dim,rows,n", [(16, 4096, 65536), (8, 2048, 8192), (32, 1024, 4096), (4, 2048, 8192)])
 def test_filter_value_error_within_the_bound_the_rerank_assumes(dim, rows, n, filter_kind):
     """The re-rank trusts |f_filter - f| <= ef_coeff * 2^-24 * T (gq_rerank.h).  Measure it: the filter's
     best record value m1 of every (row, split) against the fp64 value of the same expansion, maximised over

@@ -12,7 +12,7 @@
 //
 // K layout.  Per "type" (hh, lh, hl) there are 2*DIM slots [ squares of dims 0..DIM-1 | values of dims
 // 0..DIM-1 ]; MFMA m of a type covers slots 16m .. 16m+15, lane half h supplies slots 16m+8h .. 16m+8h+7.
-// NV = DIM/8 MFMAs per type.  Code side: vectors 0..NV-1 hold the h parts, NV..2NV-1 the l parts; row side
+// NV = DIM/8 MFMAs per type (DIM = 4 packs its three 8-slot types into two MFMAs, see bf16_split_kernel).  Code side: vectors 0..NV-1 hold the h parts, NV..2NV-1 the l parts; row side
 // likewise with the coefficients [A | B].  MFMA (type, m):  hh -> (code m, row m), lh -> (code NV+m, row m),
 // hl -> (code m, row NV+m).  Both images are produced once per call by bf16_split_kernel (below), the
 // codebook image already in the LDS tile order, so staging is a linear 16-byte copy.
@@ -60,23 +60,32 @@ __device__ __forceinline__ void bf16_split(float q, unsigned &hi, unsigned &lo) 
 }
 
 // One thread per (code, half) and per (row, half): builds both operand images.
+// DIM == 4 ("packed", NV = 0 in the filter): a type has only 8 slots, so two MFMAs carry the three types:
+//   MFMA 0: half 0 = hh (code h parts x row h parts), half 1 = lh (code l parts x row h parts)
+//   MFMA 1: half 0 = hl (code h parts x row l parts), half 1 = zero padding
 template <int MODE, int DIM>
 __global__ __launch_bounds__(256) void bf16_split_kernel(const SplitParams p) {
-  constexpr int NV = DIM / 8;
-  static_assert(DIM == 8 || DIM == 16 || DIM == 32, "split-bf16 filter: dims 8, 16, 32");
+  static_assert(DIM == 4 || DIM == 8 || DIM == 16 || DIM == 32, "split-bf16 filter: dims 4, 8, 16, 32");
+  constexpr bool PACKED = DIM == 4;
+  constexpr int NV = PACKED ? 1 : DIM / 8;     // 8-slot groups this thread splits
+  constexpr int NVEC = PACKED ? 2 : 2 * NV;    // vectors per (code | row, half) in the image
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const long ncode_threads = (long)p.tiles_total * 64;
-  float q[NV][8];   // this half's 8 slots of each of the NV MFMAs of a type
+  float q[NV][8];
   u32x4 *dst;
   long stride;      // in u32x4 between consecutive vectors
+  int h;
+  bool is_code;
   if (t < ncode_threads) {
-    const int tile = (int)(t >> 6), h = (int)(t >> 5) & 1, c = (int)t & 31;
+    is_code = true;
+    const int tile = (int)(t >> 6), c = (int)t & 31;
+    h = (int)(t >> 5) & 1;
     const long code = (long)tile * 32 + c;
 #pragma unroll
     for (int m = 0; m < NV; ++m)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int g = 16 * m + 8 * h + k;
+        const int g = PACKED ? k : 16 * m + 8 * h + k;     // slot: [ squares | values ]
         float v = 0.0f;
         if (code < p.n) {
           v = p.cb[code * DIM + (g < DIM ? g : g - DIM)];
@@ -84,18 +93,19 @@ __global__ __launch_bounds__(256) void bf16_split_kernel(const SplitParams p) {
         }
         q[m][k] = v;
       }
-    dst = p.cbimg + (long)tile * (2 * NV * 64) + h * 32 + c;
+    dst = p.cbimg + (long)tile * (NVEC * 64) + h * 32 + c;
     stride = 64;
   } else {
+    is_code = false;
     const long u = t - ncode_threads;
     const long row = u >> 1;
-    const int h = (int)u & 1;
+    h = (int)u & 1;
     if (row >= p.rows) return;
 #pragma unroll
     for (int m = 0; m < NV; ++m)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int g = 16 * m + 8 * h + k;
+        const int g = PACKED ? k : 16 * m + 8 * h + k;
         const int i = g < DIM ? g : g - DIM;
         float v;
         if constexpr (MODE == kModeGQ) {
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256) void bf16_split_kernel(const SplitParams p) {
         }
         q[m][k] = v;
       }
-    dst = p.rowimg + row * (2 * NV * 2) + h;
+    dst = p.rowimg + row * (NVEC * 2) + h;
     stride = 2;
   }
 #pragma unroll
@@ -121,17 +131,34 @@ __global__ __launch_bounds__(256) void bf16_split_kernel(const SplitParams p) {
       vh[w] = hi[2 * w] | (hi[2 * w + 1] << 16);
       vl[w] = lo[2 * w] | (lo[2 * w + 1] << 16);
     }
-    dst[(long)m * stride] = vh;
-    dst[(long)(NV + m) * stride] = vl;
+    if constexpr (PACKED) {
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      if (is_code) {   // vector 0: (h, l) parts by half; vector 1: (h parts, padding)
+        dst[0] = h == 0 ? vh : vl;
+        dst[stride] = h == 0 ? vh : zero;
+      } else {         // vector 0: h parts in both halves; vector 1: (l parts, padding)
+        dst[0] = vh;
+        dst[stride] = h == 0 ? vl : zero;
+      }
+    } else {
+      dst[(long)m * stride] = vh;
+      dst[(long)(NV + m) * stride] = vl;
+    }
   }
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// MFMAs [S0, S1) of the 3*NV of one tile, for the wave's RT row tiles (chains alternate in program order).
+// Layout constants: NV = DIM / 8 MFMAs per type (NV = 0: the packed DIM = 4 layout, two MFMAs, two vectors).
+template <int NV> struct BfLayout {
+  static constexpr int NCV = NV ? 2 * NV : 2;   // code (and row) vectors per tile
+  static constexpr int NM = NV ? 3 * NV : 2;    // MFMAs per tile and row tile
+};
+
+// MFMAs [S0, S1) of one tile, for the wave's RT row tiles (chains alternate in program order).
 template <int NV, int RT, int S0, int S1>
-__device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[2 * NV], const u32x4 (&rv)[RT][2 * NV],
-                                               f32x16 (&d)[RT]) {
+__device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[BfLayout<NV>::NCV],
+                                               const u32x4 (&rv)[RT][BfLayout<NV>::NCV], f32x16 (&d)[RT]) {
   if constexpr (S0 == 0) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -139,9 +166,12 @@ __device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[2 * NV], const 
   }
 #pragma unroll
   for (int s = S0; s < S1; ++s) {
-    const int type = s / NV, m = s % NV;           // 0 hh, 1 lh, 2 hl
-    const int ci = type == 1 ? NV + m : m;
-    const int ri = type == 2 ? NV + m : m;
+    int ci = s, ri = s;                              // packed: MFMA s uses (code vector s, row vector s)
+    if constexpr (NV > 0) {
+      const int type = s / NV, m = s % NV;           // 0 hh, 1 lh, 2 hl
+      ci = type == 1 ? NV + m : m;
+      ri = type == 2 ? NV + m : m;
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
       d[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(cv[ci]), as_bf16x8(rv[rt][ri]), d[rt], 0, 0, 0);
@@ -155,12 +185,12 @@ __device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[2 * NV], const 
 // halves the L2 -> LDS staging traffic (one chunk copy serves 8 waves).
 template <int NV, int RT, int CT, int GT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
-  constexpr int NCV = 2 * NV;                 // code (and row) vectors per tile
+  constexpr int NCV = BfLayout<NV>::NCV;      // code (and row) vectors per tile
   constexpr int TILE_Q = NCV * 64;            // 16-byte slots per tile
   constexpr int CHUNK_Q = CT * TILE_Q;
   constexpr int NT = 64 * WAVES;              // threads per block
   constexpr int R4 = CHUNK_Q / NT;            // 16-byte loads per thread per chunk
-  constexpr int NM = 3 * NV;                  // MFMAs per tile and row tile
+  constexpr int NM = BfLayout<NV>::NM;        // MFMAs per tile and row tile
   static_assert(R4 >= 1 && CHUNK_Q % NT == 0 && CT % GT == 0, "chunk: whole tile groups, whole thread passes");
   __shared__ u32x4 lds[2][CHUNK_Q];
 

@@ -316,14 +316,13 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
 constexpr int kFallbackRows = 8;
 
 template <int MODE, int DIM>
-__global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParams p) {
+__device__ __forceinline__ void fallback64_long_list(const RerankParams &p) {
   constexpr int FR = kFallbackRows;
   __shared__ RowOps rops[FR];
   __shared__ double sh_d[8];
   __shared__ int sh_i[8];
   const int tid = threadIdx.x;
   const int count = p.hdr->fb_count;
-  if (count <= kSpreadRows) return;                    // gq_fallback64_spread_kernel handles short lists
   // Many listed rows: 8 rows per block (a half-wave each).  Few: the whole block on ONE row, so a
   // lone fallback row costs ~60 us instead of ~3 ms.
   const bool wide = count < 4 * (int)gridDim.x;       // block-uniform
@@ -460,14 +459,14 @@ __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParam
 constexpr int kSpreadCodes = 16;    // codes per thread held in registers (slice <= 256 * kSpreadCodes codes)
 
 template <int MODE, int DIM>
-__global__ __launch_bounds__(256) void gq_fallback64_spread_kernel(const RerankParams p) {
+__device__ __forceinline__ void fallback64_spread(const RerankParams &p) {
   __shared__ RowOps rops;
   __shared__ double sh_d[4];
   __shared__ int sh_i[4];
   __shared__ int sh_last;
   const int count = p.hdr->fb_count;
   const int e = blockIdx.x / kSpreadSlices, sl = blockIdx.x % kSpreadSlices;
-  if (count > kSpreadRows || e >= count) return;
+  if (e >= count) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long row = p.fb_list[e];
   if (tid < DIM) load_row_ops(p, row, tid, rops);
@@ -619,6 +618,18 @@ __global__ __launch_bounds__(256) void gq_fallback64_spread_kernel(const RerankP
     }
     write_result(p, row, best_i, lane);
   }
+}
+
+// The second stage as ONE launch: the list length (known only on the device) picks the variant.
+// Grid: max(listed-row capacity of the spread variant x slices, row groups of the long-list variant), <= 2048 blocks.
+template <int MODE, int DIM>
+__global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParams p) {
+  const int count = p.hdr->fb_count;
+  if (count == 0) return;
+  if (count <= kSpreadRows && count * kSpreadSlices <= (int)gridDim.x)
+    fallback64_spread<MODE, DIM>(p);
+  else
+    fallback64_long_list<MODE, DIM>(p);
 }
 
 // Exhaustive exact arg-max: one block per listed row (grid-stride over the

@@ -64,7 +64,7 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   static const int env_blocks = getenv("GQHIP_TARGET_BLOCKS") ? atoi(getenv("GQHIP_TARGET_BLOCKS")) : 0;
   pl.rt = rows >= 8192 ? 2 : 1;
   if (env_rt == 1 || env_rt == 2) pl.rt = env_rt;
-  pl.bf16 = pl.mfma && (dim == 8 || dim == 16 || dim == 32) && want_bf16_filter();
+  pl.bf16 = pl.mfma && want_bf16_filter();
   static const int env_waves = getenv("GQHIP_BF16_WAVES") ? atoi(getenv("GQHIP_BF16_WAVES")) : 0;
   pl.waves = pl.bf16 ? (env_waves == 4 ? 4 : 8) : 4;
   pl.rows_per_block = 32 * pl.waves * pl.rt;
@@ -84,7 +84,8 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   static const int env_bgt = getenv("GQHIP_BF16_GT") ? atoi(getenv("GQHIP_BF16_GT")) : 0;
   // split-bf16: the tracker's VALU work overlaps the bf16 MFMAs, so the finest candidate (one tile half =
   // 16 codes) is free in the filter and halves / quarters the exact re-rank work
-  pl.gt = pl.bf16 ? ((pl.waves == 4 && (env_bgt == 2 || env_bgt == 4)) ? env_bgt : 1) : (dim <= 8 ? 4 : 2);
+  // (dim 4: two MFMAs per tile, the epilogue dominates -> the coarse 64-code candidate keeps the tracker cheap)
+  pl.gt = pl.bf16 ? (dim == 4 ? 4 : ((pl.waves == 4 && (env_bgt == 2 || env_bgt == 4)) ? env_bgt : 1)) : (dim <= 8 ? 4 : 2);
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   return pl;
@@ -108,8 +109,9 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.sd = off;  off += align256(4 * rows * dim);
   w.lsd = off; off += align256(4 * rows * dim);
   // split-bf16 operand images: 2*NV vectors of 16 B per (code, half) / (row, half), NV = dim / 8
-  w.cbimg = off;  off += pl.bf16 ? align256((int64_t)(pl.tiles_total + pl.ct) * (dim / 4) * 64 * 16) : 0;
-  w.rowimg = off; off += pl.bf16 ? align256(rows * (dim / 4) * 2 * 16) : 0;
+  const int64_t nvec = dim == 4 ? 2 : dim / 4;
+  w.cbimg = off;  off += pl.bf16 ? align256((int64_t)(pl.tiles_total + pl.ct) * nvec * 64 * 16) : 0;
+  w.rowimg = off; off += pl.bf16 ? align256(rows * nvec * 2 * 16) : 0;
   w.total = off;
   return w;
 }
@@ -191,6 +193,7 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitPara
   const dim3 sgrid((unsigned)((split_threads + 255) / 256)), grid((unsigned)(pl.row_blocks * pl.nsplit)), block(256);
   const dim3 fblock((unsigned)(64 * pl.waves));
   switch (dim) {
+    case 4: hipLaunchKernelGGL((bf16_split_kernel<MODE, 4>), sgrid, block, 0, st, sp); break;
     case 8: hipLaunchKernelGGL((bf16_split_kernel<MODE, 8>), sgrid, block, 0, st, sp); break;
     case 16: hipLaunchKernelGGL((bf16_split_kernel<MODE, 16>), sgrid, block, 0, st, sp); break;
     case 32: hipLaunchKernelGGL((bf16_split_kernel<MODE, 32>), sgrid, block, 0, st, sp); break;
@@ -208,19 +211,22 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitPara
   } while (0)
 #define GQ_LAUNCH_BF(NV, R, C)                                                                            \
   do {                                                                                                    \
-    if (pl.waves == 8) GQ_LAUNCH_BF1(NV, R, C, 1, 8);                                                     \
+    if (pl.waves == 8 && pl.gt == 4) GQ_LAUNCH_BF1(NV, R, C, 4, 8);                                       \
+    else if (pl.waves == 8) GQ_LAUNCH_BF1(NV, R, C, 1, 8);                                                \
     else if (pl.gt == 1) GQ_LAUNCH_BF1(NV, R, C, 1, 4);                                                   \
     else if (pl.gt == 2) GQ_LAUNCH_BF1(NV, R, C, 2, 4);                                                   \
     else GQ_LAUNCH_BF1(NV, R, C, 4, 4);                                                                   \
   } while (0)
   if (pl.rt == 2) {
     switch (dim) {
+      case 4: GQ_LAUNCH_BF(0, 2, 8); break;
       case 8: GQ_LAUNCH_BF(1, 2, 8); break;
       case 16: GQ_LAUNCH_BF(2, 2, 8); break;
       default: GQ_LAUNCH_BF(4, 2, 4); break;
     }
   } else {
     switch (dim) {
+      case 4: GQ_LAUNCH_BF(0, 1, 8); break;
       case 8: GQ_LAUNCH_BF(1, 1, 8); break;
       case 16: GQ_LAUNCH_BF(2, 1, 8); break;
       default: GQ_LAUNCH_BF(4, 1, 4); break;
@@ -261,7 +267,7 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
   rp.fb_list = reinterpret_cast<int *>(ws + w.fb);
   rp.spread = reinterpret_cast<SpreadSlot *>(ws + w.spread);
   rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
-  rp.ef_coeff = pl.bf16 ? (float)(220 + 24 * dim) : (float)(2 * dim + 4);
+  rp.ef_coeff = pl.bf16 ? (float)(dim == 4 ? 332 : 220 + 24 * dim) : (float)(2 * dim + 4);
   static const double env_ef = getenv("GQHIP_EF_COEFF") ? atof(getenv("GQHIP_EF_COEFF")) : 0.0;   // diagnostics
   if (env_ef > 0.0) rp.ef_coeff = (float)env_ef;
   rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
@@ -304,25 +310,18 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
   }
   if (pl.mfma) {
     // rows the filter could not decide: fp64 second-stage filter + exact re-rank (usually none or a handful).
-    // Short lists (<= kSpreadRows) are spread over kSpreadSlices blocks per row by the spread kernel;
-    // longer ones go to gq_fallback64_kernel.  Each kernel reads the list length and returns if it is not its turn.
+    // One launch; on the device the list length picks the variant: short lists are spread over kSpreadSlices blocks
+    // per row, long ones take 8 rows per block.
     const int64_t groups = (rows + kFallbackRows - 1) / kFallbackRows;
-    const int fb_blocks = (int)(groups < 2048 ? groups : 2048);
     const int64_t sp_rows = rows < kSpreadRows ? rows : kSpreadRows;
-    const dim3 sp_grid((unsigned)(sp_rows * kSpreadSlices));
-#define GQ_FB(D)                                                                                              \
-  do {                                                                                                        \
-    hipLaunchKernelGGL((gq_fallback64_spread_kernel<MODE, D>), sp_grid, dim3(256), 0, st, rp);                \
-    if (rows > kSpreadRows)                                                                                   \
-      hipLaunchKernelGGL((gq_fallback64_kernel<MODE, D>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp);   \
-  } while (0)
+    int64_t fb_blocks = groups > sp_rows * kSpreadSlices ? groups : sp_rows * kSpreadSlices;
+    if (fb_blocks > 2048) fb_blocks = 2048;
     switch (dim) {
-      case 4: GQ_FB(4); break;
-      case 8: GQ_FB(8); break;
-      case 16: GQ_FB(16); break;
-      default: GQ_FB(32); break;
+      case 4: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 4>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
+      case 8: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 8>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
+      case 16: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 16>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
+      default: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 32>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
     }
-#undef GQ_FB
     return check_launch();
   }
   if (hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
@@ -363,7 +362,7 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
   const Plan pl = make_plan(rows, n, dim);
   const WsLayout w = ws_layout(rows, n, dim);
   out8[0] = w.rec; out8[1] = pl.mfma ? pl.nsplit : 0; out8[2] = pl.gt; out8[3] = pl.tiles_per_split;
-  out8[4] = pl.bf16 ? 1 : 0; out8[5] = pl.bf16 ? 220 + 24 * dim : 2 * dim + 4; out8[6] = pl.rt; out8[7] = pl.waves;
+  out8[4] = pl.bf16 ? 1 : 0; out8[5] = pl.bf16 ? (dim == 4 ? 332 : 220 + 24 * dim) : 2 * dim + 4; out8[6] = pl.rt; out8[7] = pl.waves;
   return GQHIP_OK;
 }
 
