@@ -29,8 +29,8 @@ struct __attribute__((aligned(32))) Rec {
 
 // Workspace header (first 256 bytes of the caller's workspace).
 struct WsHeader {
-  int fb_count;                       // rows routed to the exhaustive kernel
-  int pad0;
+  int fb_count;                       // rows the first filter + re-rank could not decide (list A)
+  int fb2_count;                      // rows still undecided after the fp32 second-level filter (list B)
   unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly
   float absmax;                       // max |cb| (device-computed when needed)
   int pad1[27];

@@ -45,6 +45,11 @@ struct FilterParams {
   WsHeader *hdr;        // block 0 initialises the workspace header
   float absmax;         // caller-provided max|cb| (<= 0: a later kernel computes it)
   void *dbg;            // diagnostic builds only
+  // second-level use (behind the split-bf16 filter): only the rows listed in row_list[0 .. *row_count) are
+  // processed, and only if there are more than min_count of them; records are still indexed by row id
+  const int *row_list;
+  const int *row_count;
+  int min_count;
 };
 
 // LDS image of a chunk: code rows of DIM floats = DIM/4 slots of 16 bytes.  Row-major rows of
@@ -146,8 +151,13 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
 #ifdef GQHIP_CLOCK_STAMPS
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (blockIdx.x == 0 && tid == 0) {  // workspace header for the kernels that follow on the stream
+  int nrows = p.rows;
+  if (p.row_list) {
+    nrows = *p.row_count;
+    if (nrows <= p.min_count || rowblk * (128 * RT) >= nrows) return;   // block-uniform
+  } else if (blockIdx.x == 0 && tid == 0) {  // workspace header for the kernels that follow on the stream
     p.hdr->fb_count = 0;
+    p.hdr->fb2_count = 0;
     p.hdr->reranked = 0ull;
     if (p.absmax > 0.f) p.hdr->absmax = p.absmax;
   }
@@ -157,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     int row = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
-    row = min(row, p.rows - 1);
+    row = min(row, nrows - 1);
+    if (p.row_list) row = p.row_list[row];
     const float *pm = p.mu + (long)row * DIM + h * HD;
 #pragma unroll
     for (int s = 0; s < HD; ++s) {
@@ -355,8 +366,9 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
     top3_insert(b1, k1, a1, a2v, a3, j1, j2);
     top3_insert(b2, k2, a1, a2v, a3, j1, j2);
     top3_insert_value(b3, a2v, a3);
-    const int row = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
-    if (h == 0 && row < p.rows) {
+    const int pos = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
+    if (h == 0 && pos < nrows) {
+      const int row = p.row_list ? p.row_list[pos] : pos;
       Rec r;
       r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.id1 = j1; r.id2 = j2;
       r.pad[0] = r.pad[1] = r.pad[2] = 0;

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
 #endif
   if (blockIdx.x == 0 && tid == 0) {  // workspace header for the kernels that follow on the stream
     p.hdr->fb_count = 0;
+    p.hdr->fb2_count = 0;
     p.hdr->reranked = 0ull;
     if (p.absmax > 0.f) p.hdr->absmax = p.absmax;
   }

@@ -47,6 +47,7 @@ __device__ __forceinline__ long out_zhat_offset(const OutMap &m, long row, int g
 }
 
 // Scratch of the "spread" second stage (few listed rows, each spread over kSpreadSlices blocks).
+constexpr int kCascadeMin = 64;     // list A longer than this goes through the fp32 second-level filter first
 constexpr int kSpreadRows = 64;     // listed rows handled by the spread kernels (more: gq_fallback64_kernel)
 constexpr int kSpreadSlices = 32;   // blocks per listed row
 struct SpreadPartial {
@@ -70,7 +71,10 @@ struct RerankParams {
   int64_t *idx;
   float *zhat;        // may be NULL
   WsHeader *hdr;
-  int *fb_list;       // [rows]
+  int *fb_list;       // [rows]  list A: rows the first filter + re-rank could not decide
+  int *fb2_list;      // [rows]  list B: rows still undecided after the fp32 second level (cascade only)
+  int cascade;        // 1: a second-level fp32 filter runs when list A has more than kCascadeMin rows
+  int level;          // re-rank: 1 = all rows -> list A, 2 = list A -> list B (cascade only)
   SpreadSlot *spread; // [kSpreadRows]
   int rows, n, dim;
   float beta;
@@ -81,6 +85,16 @@ struct RerankParams {
   int stats;          // count re-ranked half-pairs (debug)
   OutMap omap;
 };
+
+// the list the fp64 second stage works on: list B when the cascade's second level ran, else list A
+__device__ __forceinline__ void second_stage_list(const RerankParams &p, const int *&list, int &count) {
+  list = p.fb_list;
+  count = p.hdr->fb_count;
+  if (p.cascade && count > kCascadeMin) {
+    list = p.fb2_list;
+    count = p.hdr->fb2_count;
+  }
+}
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -178,10 +192,17 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % GROUP, grp = lane / GROUP;
   const int slot = wave * RPW + grp;
-  const long row_raw = (long)blockIdx.x * RPB + slot;
-  if ((long)blockIdx.x * RPB + wave * RPW >= p.rows) return;        // whole wave past the end
-  const bool live = row_raw < p.rows;
-  const long row = live ? row_raw : p.rows - 1;                     // dead groups mirror the last row, write nothing
+  // level 1: every row; level 2 (cascade): the rows of list A, if there are more than kCascadeMin of them
+  int nrows = p.rows;
+  if (p.level == 2) {
+    nrows = p.hdr->fb_count;
+    if (nrows <= kCascadeMin) return;
+  }
+  const long pos_raw = (long)blockIdx.x * RPB + slot;
+  if ((long)blockIdx.x * RPB + wave * RPW >= nrows) return;          // whole wave past the end
+  const bool live = pos_raw < nrows;
+  const long pos_c = live ? pos_raw : nrows - 1;                     // dead groups mirror the last row, write nothing
+  const long row = p.level == 2 ? (long)p.fb_list[pos_c] : pos_c;
   const int gshift = grp * GROUP;
   const unsigned long long glow = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
   auto group_bits = [&](bool c) { return (__ballot(c) >> gshift) & glow; };
@@ -253,8 +274,8 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   const bool undecided = bad || third;       // group-uniform
   if (undecided) {
     if (live && sub == 0) {
-      const int pos = atomicAdd(&p.hdr->fb_count, 1);
-      p.fb_list[pos] = (int)row;
+      const int pos = atomicAdd(p.level == 2 ? &p.hdr->fb2_count : &p.hdr->fb_count, 1);
+      (p.level == 2 ? p.fb2_list : p.fb_list)[pos] = (int)row;
       if (pos < kSpreadRows) p.spread[pos].done = 0;
     }
     total = 0;
@@ -322,7 +343,9 @@ __device__ __forceinline__ void fallback64_long_list(const RerankParams &p) {
   __shared__ double sh_d[8];
   __shared__ int sh_i[8];
   const int tid = threadIdx.x;
-  const int count = p.hdr->fb_count;
+  const int *list;
+  int count;
+  second_stage_list(p, list, count);
   // Many listed rows: 8 rows per block (a half-wave each).  Few: the whole block on ONE row, so a
   // lone fallback row costs ~60 us instead of ~3 ms.
   const bool wide = count < 4 * (int)gridDim.x;       // block-uniform
@@ -334,7 +357,7 @@ __device__ __forceinline__ void fallback64_long_list(const RerankParams &p) {
   for (int grp = blockIdx.x; grp * R < count; grp += gridDim.x) {
     const int nrow = min(R, count - grp * R);
     const bool live = r < nrow;
-    const long row = live ? p.fb_list[grp * R + r] : 0;
+    const long row = live ? list[grp * R + r] : 0;
     __syncthreads();
     if (live && (tid & 31) < DIM && (wide ? tid < 32 : true)) load_row_ops(p, row, tid & 31, rops[r]);
     if (live && (tid & 31) + 32 < DIM && (wide ? tid < 32 : true)) load_row_ops(p, row, (tid & 31) + 32, rops[r]);
@@ -464,11 +487,13 @@ __device__ __forceinline__ void fallback64_spread(const RerankParams &p) {
   __shared__ double sh_d[4];
   __shared__ int sh_i[4];
   __shared__ int sh_last;
-  const int count = p.hdr->fb_count;
+  const int *list;
+  int count;
+  second_stage_list(p, list, count);
   const int e = blockIdx.x / kSpreadSlices, sl = blockIdx.x % kSpreadSlices;
   if (e >= count) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long row = p.fb_list[e];
+  const long row = list[e];
   if (tid < DIM) load_row_ops(p, row, tid, rops);
   __syncthreads();
   double cA[DIM], cB[DIM];
@@ -624,7 +649,9 @@ __device__ __forceinline__ void fallback64_spread(const RerankParams &p) {
 // Grid: max(listed-row capacity of the spread variant x slices, row groups of the long-list variant), <= 2048 blocks.
 template <int MODE, int DIM>
 __global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParams p) {
-  const int count = p.hdr->fb_count;
+  const int *list;
+  int count;
+  second_stage_list(p, list, count);
   if (count == 0) return;
   if (count <= kSpreadRows && count * kSpreadSlices <= (int)gridDim.x)
     fallback64_spread<MODE, DIM>(p);

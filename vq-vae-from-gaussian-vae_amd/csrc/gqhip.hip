@@ -45,6 +45,8 @@ struct Plan {
   bool bf16;            // split-bf16 filter (gq_filter_bf16.h) instead of the fp32 MFMA one
   int ct;               // tiles per LDS chunk of the split-bf16 filter
   int waves;            // waves per block: 8 (one block per CU) for the split-bf16 filter, else 4
+  // second level of the cascade behind the split-bf16 filter: the fp32 MFMA filter (RT 1) on the undecided rows
+  int nsplit2, tiles_per_split2, gt2;
 };
 
 // Filter selection: 0 = auto (split-bf16 where it applies: dims 8/16/32), 1 = always the fp32 MFMA filter.
@@ -88,13 +90,17 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   pl.gt = pl.bf16 ? (dim == 4 ? 4 : ((pl.waves == 4 && (env_bgt == 2 || env_bgt == 4)) ? env_bgt : 1)) : (dim <= 8 ? 4 : 2);
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
+  pl.gt2 = dim <= 8 ? 4 : 2;
+  int s2 = pl.tiles_total < 16 ? pl.tiles_total : 16;          // 16 splits: 4096 codes per block at N = 65 536
+  pl.tiles_per_split2 = ((pl.tiles_total + s2 - 1) / s2 + pl.gt2 - 1) / pl.gt2 * pl.gt2;
+  pl.nsplit2 = (pl.tiles_total + pl.tiles_per_split2 - 1) / pl.tiles_per_split2;
   return pl;
 }
 
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WsLayout {
-  int64_t hdr, rec, fb, spread, mu, sd, lsd, cbimg, rowimg, total;
+  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, cbimg, rowimg, total;
 };
 
 WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
@@ -104,6 +110,9 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.hdr = off; off += (int64_t)sizeof(WsHeader);
   w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit : 0));
   w.fb = off;  off += align256(4 * rows);
+  // cascade behind the split-bf16 filter: list B + the second-level fp32 filter's records (kCascadeSplit splits)
+  w.fb2 = off;  off += pl.bf16 ? align256(4 * rows) : 0;
+  w.rec2 = off; off += pl.bf16 ? align256((int64_t)sizeof(Rec) * rows * pl.nsplit2) : 0;
   w.spread = off; off += align256((int64_t)sizeof(SpreadSlot) * kSpreadRows);
   w.mu = off;  off += align256(4 * rows * dim);
   w.sd = off;  off += align256(4 * rows * dim);
@@ -128,9 +137,9 @@ std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 struct ProfScope {
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
-  ProfScope() {
+  explicit ProfScope(bool enable = true) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    on = g_prof_on;
+    on = g_prof_on && enable;
     if (on) {
       (void)hipEventCreate(&a);
       (void)hipEventCreate(&b);
@@ -145,9 +154,9 @@ struct ProfScope {
 };
 
 template <int MODE>
-int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t st) {
+int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t st, bool profile = true) {
   const dim3 grid((unsigned)(pl.row_blocks * pl.nsplit)), block(256);
-  ProfScope prof;
+  ProfScope prof(profile);
 #define GQ_LAUNCH(D, R, C, G)                                                                           \
   do {                                                                                                \
     if (prof.on)                                                                                      \
@@ -265,6 +274,9 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
   rp.rec = reinterpret_cast<const Rec *>(ws + w.rec);
   rp.idx = idx; rp.zhat = zhat; rp.hdr = hdr;
   rp.fb_list = reinterpret_cast<int *>(ws + w.fb);
+  rp.fb2_list = reinterpret_cast<int *>(ws + w.fb2);
+  rp.cascade = pl.bf16 ? 1 : 0;
+  rp.level = 1;
   rp.spread = reinterpret_cast<SpreadSlot *>(ws + w.spread);
   rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
   rp.ef_coeff = pl.bf16 ? (float)(dim == 4 ? 332 : 220 + 24 * dim) : (float)(2 * dim + 4);
@@ -290,6 +302,26 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
     if (rc != GQHIP_OK) return rc;
     if (need_absmax) launch_absmax();
     launch_rerank<MODE>(rp, rows, st);
+    rc = check_launch();
+    if (rc != GQHIP_OK) return rc;
+    // Cascade: when more than kCascadeMin rows are undecided (ill-conditioned inputs: the split-bf16 margin is ~16x
+    // the fp32 one), they go through the fp32 MFMA filter + re-rank before the fp64 second stage.  Both launches
+    // read the list length on the device and return at once when it is short.
+    FilterParams f2{};
+    f2.mu = mu; f2.sd = sd; f2.cb = cb;
+    f2.rec = reinterpret_cast<Rec *>(ws + w.rec2);
+    f2.rows = (int)rows; f2.n = (int)n; f2.beta = (float)beta;
+    f2.nsplit = pl.nsplit2; f2.tiles_total = pl.tiles_total; f2.tiles_per_split = pl.tiles_per_split2;
+    f2.hdr = hdr; f2.absmax = 0.f; f2.dbg = nullptr;
+    f2.row_list = rp.fb_list; f2.row_count = &hdr->fb_count; f2.min_count = kCascadeMin;
+    Plan p2 = pl;
+    p2.rt = 1; p2.rows_per_block = 128; p2.row_blocks = (int)((rows + 127) / 128); p2.nsplit = pl.nsplit2;
+    rc = launch_filter<MODE>(p2, f2, (int)dim, st, /*profile=*/false);
+    if (rc != GQHIP_OK) return rc;
+    RerankParams r2 = rp;
+    r2.rec = reinterpret_cast<const Rec *>(ws + w.rec2);
+    r2.nsplit = pl.nsplit2; r2.gt = pl.gt2; r2.ef_coeff = (float)(2 * dim + 4); r2.level = 2;
+    launch_rerank<MODE>(r2, rows, st);
     rc = check_launch();
     if (rc != GQHIP_OK) return rc;
   } else if (pl.mfma) {
