@@ -15,6 +15,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   (head -1 "$f"; grep "gqhip::" "$f") > "$DST/pmc_$C.csv"
 done
 grep -h '^{' "$SRC/bench_stdout.txt" | tail -1 > "$DST/bench_line_under_rocprof.json"
-tail -1 "$SRC/kbench_stdout.txt" > "$DST/kbench_line.txt"
-tail -1 "$SRC/kbench_fp32_stdout.txt" > "$DST/kbench_fp32_line.txt"
+grep -h "filter kernel" "$SRC/kbench_stdout.txt" | tail -1 > "$DST/kbench_line.txt"
+grep -h "filter kernel" "$SRC/kbench_fp32_stdout.txt" | tail -1 > "$DST/kbench_fp32_line.txt"
 ls -la "$DST"
