@@ -252,7 +252,7 @@ def main():
         bf16 = _lib.debug_plan(rows, N_CODES, DIM)["bf16"] == 1
         if bf16:
             # split-bf16 filter: every algorithmic fp32 MAC is executed as 3 bf16 MACs (A_h s_h + A_h s_l + A_l s_h)
-            roofline = {"kernel": "gq_filter_bf16_kernel<2,2,8,1> (split-bf16 MFMA filter of the fused quantiser)",
+            roofline = {"kernel": "gq_filter_bf16_kernel<NV=2,RT=2,CT=16,GT=1,WAVES=8> (split-bf16 MFMA filter of the fused quantiser)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                         "executed": round(3 * achieved, 2), "executed_frac": round(3 * achieved / PEAK_BF16_TFLOPS, 4),

@@ -21,6 +21,7 @@
 // 1 KiB contiguous (conflict-free).  D layout as in gq_filter.h (lane = one row, 16 codes).
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "gq_filter.h"
 
@@ -145,6 +146,12 @@ __global__ __launch_bounds__(256) void bf16_split_kernel(const SplitParams p) {
       dst[(long)(NV + m) * stride] = vl;
     }
   }
+}
+
+// f(integral_constant<int, 0>{}, ..., integral_constant<int, N-1>{})
+template <class F, int... I>
+__device__ __forceinline__ void call_with_indices(F &&f, std::integer_sequence<int, I...>) {
+  f(std::integral_constant<int, I>{}...);
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -329,19 +336,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       };
+      // one step per tile of the chunk, fully unrolled (the tags are compile-time constants)
       auto run_all = [&](auto... is) {
         (step(decltype(is)::value, std::bool_constant<(decltype(is)::value % GT) == 0>{},
               std::bool_constant<decltype(is)::value == CT - 1>{}), ...);
       };
-      using std::integral_constant;
-      if constexpr (CT == 8)
-        run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
-                integral_constant<int, 3>{}, integral_constant<int, 4>{}, integral_constant<int, 5>{},
-                integral_constant<int, 6>{}, integral_constant<int, 7>{});
-      else
-        run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
-                integral_constant<int, 3>{});
-      static_assert(CT == 8 || CT == 4, "unrolled tile loop is written for 4 or 8 tiles per chunk");
+      call_with_indices(run_all, std::make_integer_sequence<int, CT>{});
       have_prev = true;
     } else {
       if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);

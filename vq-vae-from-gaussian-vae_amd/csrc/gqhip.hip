@@ -82,7 +82,9 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   if (s > pl.tiles_total) s = pl.tiles_total;
   if (s < 1) s = 1;
   pl.tiles_per_split = (pl.tiles_total + s - 1) / s;
-  pl.ct = dim == 32 ? 4 : 8;
+  // tiles per LDS chunk: 16 at dim 16 with one block per CU (2 x 64 KiB of LDS, half the chunk barriers: +1-2 %)
+  static const int env_ct = getenv("GQHIP_BF16_CT") ? atoi(getenv("GQHIP_BF16_CT")) : 0;
+  pl.ct = dim == 32 ? 4 : ((dim == 16 && pl.waves == 8 && env_ct != 8) ? 16 : 8);
   static const int env_bgt = getenv("GQHIP_BF16_GT") ? atoi(getenv("GQHIP_BF16_GT")) : 0;
   // split-bf16: the tracker's VALU work overlaps the bf16 MFMAs, so the finest candidate (one tile half =
   // 16 codes) is free in the filter and halves / quarters the exact re-rank work
@@ -230,7 +232,7 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitPara
     switch (dim) {
       case 4: GQ_LAUNCH_BF(0, 2, 8); break;
       case 8: GQ_LAUNCH_BF(1, 2, 8); break;
-      case 16: GQ_LAUNCH_BF(2, 2, 8); break;
+      case 16: if (pl.ct == 16) GQ_LAUNCH_BF1(2, 2, 16, 1, 8); else GQ_LAUNCH_BF(2, 2, 8); break;
       default: GQ_LAUNCH_BF(4, 2, 4); break;
     }
   } else {
