@@ -217,3 +217,10 @@ def test_unet_autograd_path_on_cpu():
     assert enc.conv_in.weight.grad is not None and dec.conv_out.weight.grad is not None
     with torch.no_grad():
         torch.testing.assert_close(enc(x), z.detach(), atol=1e-6, rtol=1e-6)  # same function either way
+
+
+def test_graft_entry_build_runs():
+    """`__graft_entry__.build()` is the driver's "does it build" check: it must compile (incrementally) and import."""
+    import __graft_entry__ as ge
+
+    ge.build()
