@@ -169,6 +169,17 @@ int gn_silu_f32(const float *x, const float *gamma, const float *beta,
 int add_bias_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B,
                  int64_t C, int64_t HW, int layout, void *stream);
 
+/* NHWC only.  y = a + b (+ bias[c]) AND the GroupNorm statistics of y: stats_out[2*(b*groups+g)] = sum, [+1] = sum of
+ * squares over the group (fp64; zeroed here).  The residual add of a ResnetBlock / AttnBlock (unet.py:160, :205) is
+ * always followed by a GroupNorm over the same tensor (unet.py:140, :190, :581): gn_apply_f32 then normalises from
+ * these statistics without its own statistics pass.  Needs (C/groups) % 4 == 0, 256 % (C/4) == 0, groups <= 64. */
+int add_bias_stats_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B,
+                       int64_t C, int64_t HW, int64_t groups, double *stats_out, void *stream);
+
+/* NHWC only.  The apply pass of gn_silu_f32 with statistics computed earlier (by add_bias_stats_f32). */
+int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B, int64_t C,
+                 int64_t HW, int64_t groups, double eps, int apply_silu, const double *stats, void *stream);
+
 /* Nearest-neighbour x2 upsample of an NHWC fp32 tensor: x [B, H, W, C] -> y [B, 2H, 2W, C], C % 4 == 0
  * (pit/modules/unet.py:69-73, `F.interpolate(scale_factor=2.0, mode="nearest")` in channels_last). */
 int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t W, int64_t C,

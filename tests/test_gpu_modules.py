@@ -519,3 +519,47 @@ def test_vq_multi_candidate(rows, n, dim, filt):
     gap = d.gather(1, idx[:, None])[:, 0] - d.gather(1, ref[:, None])[:, 0]
     assert float(gap.max()) <= 1e-9, f"{int((gap > 1e-9).sum())} rows picked a farther codeword (max gap {float(gap.max()):.3g})"
     assert torch.equal(zq.cpu(), emb[idx])
+
+
+def test_add_bias_stats_and_gn_apply_match_the_unfused_pair():
+    """Residual add that leaves the next GroupNorm's statistics behind + apply-only GroupNorm == add, then GN."""
+    import torch.nn.functional as F
+    from pit_hip import _lib
+
+    g = torch.Generator().manual_seed(3)
+    for C, H in ((128, 24), (256, 10), (512, 7)):
+        a = torch.randn(3, C, H, H + 1, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(3, C, H, H + 1, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        bias = torch.randn(C, generator=g).to(DEV)
+        gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+        y, stats = _lib.add_bias_stats(a, b, bias, 32)
+        ref = a + b + bias[None, :, None, None]
+        assert torch.equal(y, ref) and y.is_contiguous(memory_format=torch.channels_last)
+        for silu in (True, False):
+            out = _lib.gn_apply(y, gamma, beta, 32, 1e-6, silu, stats)
+            exp = F.group_norm(ref, 32, gamma, beta, 1e-6)
+            exp = F.silu(exp) if silu else exp
+            assert torch.allclose(out, exp, atol=2e-5, rtol=1e-5)
+            assert torch.allclose(out, _lib.gn_silu(y, gamma, beta, 32, 1e-6, silu=silu), atol=1e-6, rtol=1e-6)
+
+
+def test_unet_with_and_without_fused_add_stats_agree():
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(0)
+    cfg = dict(ch=128, out_ch=3, in_channels=3, resolution=64, z_channels=16, double_z=True, ch_mult=[1, 2, 4, 4],
+               num_res_blocks=2, attn_resolutions=[8], dropout=0.0)
+    enc = U.Encoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
+    dec = U.Decoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
+    x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    outs = []
+    with torch.no_grad():
+        for flag in (True, False):
+            U.FUSED_ADD_STATS = flag
+            z = enc(x)
+            outs.append((z, dec(z[:, :16])))
+    U.FUSED_ADD_STATS = True
+    # same arithmetic up to the summation order of the statistics (fp32 partial sums per thread, fp64 across blocks)
+    dz = float((outs[0][0] - outs[1][0]).abs().max())
+    dx = float((outs[0][1] - outs[1][1]).abs().max())
+    assert dz <= 1e-4 and dx <= 5e-4, (dz, dx)

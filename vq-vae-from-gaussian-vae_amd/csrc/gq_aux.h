@@ -324,6 +324,39 @@ __global__ __launch_bounds__(256) void add_bias_nhwc_kernel(const float *__restr
   }
 }
 
+// Residual add that also leaves the GroupNorm statistics of its OUTPUT behind (the next op of the UNet is a
+// GroupNorm over exactly this tensor: unet.py:160 -> :140): same block/thread mapping as gn_stats_nhwc_kernel, so
+// the consumer's statistics pass (one full read of the tensor) disappears.
+__global__ __launch_bounds__(256) void add_bias_stats_nhwc_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                  const float *__restrict__ bias, float *__restrict__ y,
+                                                                  double *__restrict__ stats, int C, long HW, int cpg,
+                                                                  int slabs) {
+  __shared__ double red[2 * 64];   // per-group (sum, sumsq), groups <= 64
+  const int groups = C / cpg, quads = C / 4, lanes = 256 / quads;
+  const long bi = blockIdx.x / slabs;
+  const int slab = blockIdx.x % slabs;
+  const long per = (HW + slabs - 1) / slabs;
+  const long lo = slab * per, hi = lo + per < HW ? lo + per : HW;
+  const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
+  if (threadIdx.x < 2 * groups) red[threadIdx.x] = 0.0;
+  __syncthreads();
+  f32x4 pb = {0.f, 0.f, 0.f, 0.f};
+  if (bias) pb = *reinterpret_cast<const f32x4 *>(bias + 4 * q);
+  const long off = (bi * HW) * C + 4 * q;
+  float s = 0.f, ss = 0.f;
+  for (long p = lo + pl; p < hi; p += lanes) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(a + off + p * C) + *reinterpret_cast<const f32x4 *>(b + off + p * C) + pb;
+    *reinterpret_cast<f32x4 *>(y + off + p * C) = v;
+    s += (v.x + v.y) + (v.z + v.w);
+    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  const int g = (4 * q) / cpg;
+  atomicAdd(&red[2 * g], (double)s);
+  atomicAdd(&red[2 * g + 1], (double)ss);
+  __syncthreads();
+  if (threadIdx.x < 2 * groups) atomicAdd(&stats[2 * (bi * groups) + threadIdx.x], red[threadIdx.x]);
+}
+
 // Nearest-neighbour x2 upsample, NHWC (unet.py:69-73 `interpolate(scale_factor=2, mode="nearest")`):
 // one thread per (input pixel, channel quad); the 16-byte value is written to the 2x2 output pixels.
 __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y,

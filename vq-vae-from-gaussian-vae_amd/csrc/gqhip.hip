@@ -604,6 +604,47 @@ int add_bias_f32(const float *a, const float *b, const float *bias_or_null, floa
   return check_launch();
 }
 
+// slabs of ~16 pixels per thread, as gn_silu_f32's NHWC path
+static int nhwc_slabs(int64_t C, int64_t HW) {
+  const int lanes = (int)(256 / (C / 4));
+  int slabs = (int)((HW + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16));
+  if (slabs > 1024) slabs = 1024;
+  return slabs < 1 ? 1 : slabs;
+}
+
+int add_bias_stats_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B, int64_t C,
+                       int64_t HW, int64_t groups, double *stats_out, void *stream) {
+  if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!a || !b || !y || !stats_out) return GQHIP_ERR_INVALID_ARG;
+  const int64_t cpg = C / groups;
+  if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(stats_out, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) return check_launch();
+  const int slabs = nhwc_slabs(C, HW);
+  hipLaunchKernelGGL(add_bias_stats_nhwc_kernel, dim3((unsigned)(B * slabs)), dim3(256), 0, st, a, b, bias_or_null, y,
+                     stats_out, (int)C, (long)HW, (int)cpg, slabs);
+  return check_launch();
+}
+
+int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B, int64_t C, int64_t HW,
+                 int64_t groups, double eps, int apply_silu, const double *stats, void *stream) {
+  if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !gamma || !beta || !y || !stats) return GQHIP_ERR_INVALID_ARG;
+  const int64_t cpg = C / groups;
+  if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int slabs = nhwc_slabs(C, HW);
+  if (apply_silu)
+    hipLaunchKernelGGL((gn_apply_nhwc_kernel<1>), dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, gamma, beta, y, stats,
+                       (const float *)nullptr, (int)C, (long)HW, (int)cpg, eps, slabs);
+  else
+    hipLaunchKernelGGL((gn_apply_nhwc_kernel<0>), dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, gamma, beta, y, stats,
+                       (const float *)nullptr, (int)C, (long)HW, (int)cpg, eps, slabs);
+  return check_launch();
+}
+
 int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
   if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;

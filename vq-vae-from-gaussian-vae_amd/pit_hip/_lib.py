@@ -50,6 +50,8 @@ _SIGNATURES = {
     "fsq_dequant_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _i64, _vp]),
     "gn_silu_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int,
                                    ctypes.c_int, _vp, _vp]),
+    "add_bias_stats_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "gn_apply_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp]),
     "upsample2x_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
@@ -304,7 +306,7 @@ def image_layout(x: torch.Tensor):
 
 def gn_nhwc_ok(C: int, groups: int) -> bool:
     cpg = C // groups
-    return cpg % 4 == 0 and 256 % (C // 4) == 0 and groups <= 64
+    return C % groups == 0 and cpg % 4 == 0 and C % 4 == 0 and 256 % (C // 4) == 0 and groups <= 64
 
 
 def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True, pre_bias=None):
@@ -336,6 +338,33 @@ def add_bias(a, b, bias=None):
     with torch.cuda.device(a.device):
         _check(lib().add_bias_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, layout, _stream()),
                "add_bias_f32")
+    return y
+
+
+def add_bias_stats(a, b, bias, groups: int):
+    """channels_last only: (a + b (+ bias[c]), GroupNorm statistics of that sum [2 * B * groups] fp64)."""
+    if image_layout(a) != 1 or image_layout(b) != 1 or not a.is_cuda or a.dtype != torch.float32 or not gn_nhwc_ok(a.shape[1], groups):
+        raise GqHipError("add_bias_stats needs two dense channels_last fp32 HIP tensors with a GroupNorm-compatible C")
+    B, C = a.shape[0], a.shape[1]
+    HW = a.shape[2] * a.shape[3]
+    y = torch.empty_like(a)
+    stats = torch.empty(2 * B * groups, dtype=torch.float64, device=a.device)
+    with torch.cuda.device(a.device):
+        _check(lib().add_bias_stats_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, groups,
+                                        stats.data_ptr(), _stream()), "add_bias_stats_f32")
+    return y, stats
+
+
+def gn_apply(x, gamma, beta, groups: int, eps: float, silu: bool, stats):
+    """channels_last only: GroupNorm(+SiLU) of x from statistics computed by add_bias_stats."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32:
+        raise GqHipError("gn_apply needs a dense channels_last fp32 HIP tensor")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.shape[2] * x.shape[3]
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().gn_apply_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), B, C, HW, groups,
+                                  float(eps), 1 if silu else 0, stats.data_ptr(), _stream()), "gn_apply_f32")
     return y
 
 

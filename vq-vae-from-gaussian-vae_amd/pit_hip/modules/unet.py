@@ -54,6 +54,9 @@ def _norm_act(norm: nn.GroupNorm, x: torch.Tensor, act: bool = True, pre_bias=No
     if _use_fused(x, norm):
         from .. import _lib
 
+        st = getattr(x, "_gn_stats", None)   # left behind by the residual add that produced x (see _add)
+        if st is not None and pre_bias is None and st[1] == norm.num_groups and _lib.image_layout(x) == 1:
+            return _lib.gn_apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act, st[0])
         return _lib.gn_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=act, pre_bias=pre_bias)
     y = norm(_materialize(x, pre_bias))
     return _silu(y) if act else y
@@ -81,6 +84,12 @@ def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
         from .. import _lib
 
         la, lb = _lib.image_layout(a), _lib.image_layout(b)
+        if FUSED_ADD_STATS and la == 1 and lb == 1 and _lib.gn_nhwc_ok(a.shape[1], GN_GROUPS):
+            # every residual add of this UNet feeds a GroupNorm(32): leave its statistics with the sum, the
+            # consumer (_norm_act) then skips its own statistics pass over the tensor
+            y, stats = _lib.add_bias_stats(a, b, bias, GN_GROUPS)
+            y._gn_stats = (stats, GN_GROUPS)
+            return y
         if la is not None and la == lb and ((la == 0 and (a.shape[2] * a.shape[3]) % 4 == 0) or
                                             (la == 1 and a.shape[1] % 4 == 0)):
             return _lib.add_bias(a, b, bias)
@@ -88,6 +97,8 @@ def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
 
 
 FUSED_GN = True    # module-level switches (tests / A-B timing)
+FUSED_ADD_STATS = True   # residual add also produces the next GroupNorm's statistics (channels_last only)
+GN_GROUPS = 32     # unet.py:54-57: every Normalize is GroupNorm(32, C, eps=1e-6)
 DEFER_BIAS = True
 ATTN_MATH = "auto"  # explicit matmul/softmax/matmul instead of the fused SDPA kernel: "auto" = on HIP devices
 
