@@ -54,8 +54,8 @@ const char *gqhip_status_string(int status);
 int gqhip_last_hip_error(void);
 
 /* Filter kernel of the fused arg-max (gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32).  AUTO: the
- * split-bf16 MFMA filter for dims 8/16/32 (three bf16 products per fp32 product, ~3x faster), the fp32 MFMA filter
- * otherwise; FP32: always the fp32 MFMA filter.  Both feed the same exact re-rank: the indices are identical.
+ * split-bf16 MFMA filter for dims 4/8/16/32 (three bf16 products per fp32 product, ~3x faster; rows it cannot decide
+ * cascade through the fp32 MFMA filter, then an fp64 stage); FP32: always the fp32 MFMA filter.  Both feed the same exact re-rank: the indices are identical.
  * Process-wide; initial value from the environment (GQHIP_FILTER=fp32|bf16).  The workspace size depends on it:
  * query gqhip_workspace_bytes after changing it.  (No reference counterpart.) */
 #define GQHIP_FILTER_AUTO 0

@@ -426,7 +426,7 @@ FILTER_KINDS = {"auto": 0, "fp32": 1}
 
 
 def set_filter(kind: str) -> None:
-    """"auto": split-bf16 MFMA filter where it applies (dims 8/16/32), fp32 MFMA filter elsewhere; "fp32": always
+    """"auto": split-bf16 MFMA filter (dims 4/8/16/32; other dims use the exhaustive kernel either way); "fp32": always
     the fp32 MFMA filter.  Process-wide; indices are identical either way (the exact re-rank decides)."""
     if kind not in FILTER_KINDS:
         raise GqHipError(f"unknown filter {kind!r} (expected one of {sorted(FILTER_KINDS)})")
