@@ -99,7 +99,25 @@ int main() {
     for (int64_t j = 1; j < n; ++j) if (out[r * n + j] > out[r * n + am]) am = j;
     if (best[r] - second[r] > 1e-3f && am != ref[r]) ++bad_am;
   }
-  std::printf("cabi smoke: %lld rows, index mismatches %lld, zhat/dequant mismatches %lld, compat arg-max mismatches %lld\n",
-              (long long)rows, (long long)bad, (long long)bad_z, (long long)bad_am);
-  return (bad || bad_z || bad_am) ? 10 : 0;
+  // the other filter kernel (fp32 MFMA instead of the default split-bf16): new workspace size, same indices
+  int64_t bad_f = 0;
+  if (gqhip_get_filter() != GQHIP_FILTER_AUTO) return 6;
+  CHECK_GQ(gqhip_set_filter(GQHIP_FILTER_FP32));
+  const int64_t ws2_bytes = gqhip_workspace_bytes(rows, n, dim);
+  void *d_ws2;
+  int64_t *d_idx2;
+  CHECK_HIP(hipMalloc(&d_ws2, ws2_bytes));
+  CHECK_HIP(hipMalloc(&d_idx2, rows * 8));
+  CHECK_GQ(gq_argmax_f32(d_mu, d_sd, nullptr, d_cb, d_idx2, nullptr, dim, rows, n, beta, 0.f, d_ws2, ws2_bytes, st));
+  CHECK_GQ(gqhip_set_filter(GQHIP_FILTER_AUTO));
+  if (gqhip_set_filter(7) != GQHIP_ERR_INVALID_ARG) return 7;
+  std::vector<int64_t> idx2(rows);
+  CHECK_HIP(hipMemcpyAsync(idx2.data(), d_idx2, rows * 8, hipMemcpyDeviceToHost, st));
+  CHECK_HIP(hipStreamSynchronize(st));
+  for (int64_t r = 0; r < rows; ++r) bad_f += idx2[r] != ref[r];
+  std::printf("cabi smoke: %lld rows, index mismatches %lld (split-bf16 filter) / %lld (fp32 filter), zhat/dequant mismatches "
+              "%lld, compat arg-max mismatches %lld, workspace %lld / %lld bytes\n",
+              (long long)rows, (long long)bad, (long long)bad_f, (long long)bad_z, (long long)bad_am,
+              (long long)ws_bytes, (long long)ws2_bytes);
+  return (bad || bad_f || bad_z || bad_am) ? 10 : 0;
 }
