@@ -190,11 +190,17 @@ def main():
         step()
     sync()
     _lib.profile_enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread (async, ~free)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step()
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pick = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)
+    step_ms = {"p10": pick(0.10), "p50": pick(0.50), "p90": pick(0.90), "note": "device time between per-step events, rank 0"}
     launches, kernel_ms = _lib.profile_collect()
     _lib.profile_enable(False)
 
@@ -293,6 +299,8 @@ def main():
                        "parallelism": f"dp{world} image-sharded, one packed all_gather/step"},
             "roofline": roofline,
             "stages_ms": stages,
+            "step_ms": step_ms,
+            "quantiser_rows_per_s": round(rows / (stages["quantiser"] * 1e-3)),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(4)   # ~10 s of host work
