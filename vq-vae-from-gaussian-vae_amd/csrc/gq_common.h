@@ -18,13 +18,14 @@ constexpr int kMaxDim = 64;
 __device__ __host__ constexpr float half_log_2pi() { return 0.91893853320467274178f; }
 
 // One candidate record per (row, code split), produced by the filter kernel.
-//   m1 >= m2 >= m3 : the three largest half-pair maxima of the filter score
-//   id1, id2       : half-pair ids ((tile>>1)*2 + half) of m1 and m2; a half-pair
-//                    is the 2 x 16 codes one lane half sees in tiles 2p, 2p+1
+//   m1 >= m2 >= m3 >= m4 : the four largest half-group maxima of the filter score
+//   id1, id2, id3        : half-group ids ((tile / GT) * 2 + half) of m1, m2, m3; a half-group
+//                          is the GT x 16 codes one lane half sees in GT consecutive tiles
+// The fourth value only tells the re-rank whether a fourth group could matter (then the row is undecided).
 struct __attribute__((aligned(32))) Rec {
-  float m1, m2, m3;
-  int id1, id2;
-  int pad[3];
+  float m1, m2, m3, m4;
+  int id1, id2, id3;
+  int pad;
 };
 
 // Workspace header (first 256 bytes of the caller's workspace).
@@ -38,21 +39,37 @@ struct WsHeader {
 };
 static_assert(sizeof(WsHeader) == 512, "header is 512 bytes");
 
-// Insert (t, id) into a descending top-3 (ids kept for the top 2 only).
-__device__ __forceinline__ void top3_insert(float t, int id, float &m1, float &m2,
-                                            float &m3, int &i1, int &i2) {
+// Insert (t, id) into a descending top-4 (ids kept for the top 3 only).
+__device__ __forceinline__ void top4_insert(float t, int id, float &m1, float &m2, float &m3, float &m4,
+                                            int &i1, int &i2, int &i3) {
+  const bool g1 = t > m1;
+  const bool g2 = t > m2;
+  const bool g3 = t > m3;
+  m4 = __builtin_amdgcn_fmed3f(m3, m4, t);
+  m3 = __builtin_amdgcn_fmed3f(m2, m3, t);
+  m2 = __builtin_amdgcn_fmed3f(m1, m2, t);
+  m1 = __builtin_fmaxf(m1, t);
+  // plain selects (g1 implies g2 implies g3) -> v_cndmask, no control flow
+  i3 = g3 ? id : i3;
+  i3 = g2 ? i2 : i3;
+  i2 = g2 ? id : i2;
+  i2 = g1 ? i1 : i2;
+  i1 = g1 ? id : i1;
+}
+// Top-3 variant (ids of the top 2): the third value is kept in `m4`'s role by the caller (see the packed dim-4
+// filter, where the tracker's VALU work is on the critical path).
+__device__ __forceinline__ void top3_insert(float t, int id, float &m1, float &m2, float &m3, int &i1, int &i2) {
   const bool g1 = t > m1;
   const bool g2 = t > m2;
   m3 = __builtin_amdgcn_fmed3f(m2, m3, t);
   m2 = __builtin_amdgcn_fmed3f(m1, m2, t);
   m1 = __builtin_fmaxf(m1, t);
-  // three plain selects (g1 implies g2) -> v_cndmask, no control flow
   i2 = g2 ? id : i2;
   i2 = g1 ? i1 : i2;
   i1 = g1 ? id : i1;
 }
-__device__ __forceinline__ void top3_insert_value(float t, float m2, float &m3) {
-  m3 = __builtin_amdgcn_fmed3f(m2, m3, t);
+__device__ __forceinline__ void top4_insert_value(float t, float m3, float &m4) {
+  m4 = __builtin_amdgcn_fmed3f(m3, m4, t);
 }
 
 // torch.argmax order on (score, index): NaN is the maximum and the first NaN

@@ -5,9 +5,9 @@
 // which equals the reference score (pit/quantization/gaussian.py:142-147) up
 // to a per-row constant when  A = beta/2 - 1/(2 sd^2),  B = mu / sd^2
 // (and equals -|z - e_j|^2 + |z|^2 for VQ with A = -1, B = 2 z; vq.py:58-69).
-// The score matrix never leaves registers: each lane keeps the three largest
-// "half-pair" maxima it has seen (+ the ids of the best two); the re-rank kernel
-// (gq_rerank.h) re-evaluates those few half-pairs in the reference's exact
+// The score matrix never leaves registers: each lane keeps the four largest
+// "half-group" maxima it has seen (+ the ids of the best three); the re-rank kernel
+// (gq_rerank.h) re-evaluates those few half-groups in the reference's exact
 // operation order, which is what makes the indices bit-identical.
 //
 // Tiling (wave64, v_mfma_f32_32x32x2_f32):
@@ -121,7 +121,7 @@ __device__ __forceinline__ void tile_mfma(const float (&a)[DIM / 2], const float
 // fp32 MFMA and VALU share the SIMD's fp32 datapath on gfx950 (measured: every VALU
 // instruction next to a v_mfma_f32_32x32x2_f32 stream costs ~4.4 matrix-pipe cycles,
 // tools/mfma_peak.hip), so the epilogue is kept to the minimum instruction count:
-// 8 v_max3 per 16-MFMA chain, and ONE top-3 update per GROUP of GT tiles (a candidate
+// 8 v_max3 per 16-MFMA chain, and ONE top-4 update per GROUP of GT tiles (a candidate
 // "half-group" = the GT x 16 codes a lane saw in tiles GT*p .. GT*p+GT-1).  The main loop is
 // software pipelined so that nothing but those VALU instructions ever keeps the
 // matrix pipe waiting: the LDS operands of tile t+1 are fetched before the MFMAs of
@@ -185,12 +185,12 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   }
 
   const float NEG_INF = -__builtin_inff();
-  float m1[RT], m2[RT], m3[RT], tpend[RT];
-  int i1[RT], i2[RT];
+  float m1[RT], m2[RT], m3[RT], m4[RT], tpend[RT];
+  int i1[RT], i2[RT], i3[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    m1[rt] = m2[rt] = m3[rt] = tpend[rt] = NEG_INF;
-    i1[rt] = i2[rt] = 0;
+    m1[rt] = m2[rt] = m3[rt] = m4[rt] = tpend[rt] = NEG_INF;
+    i1[rt] = i2[rt] = i3[rt] = 0;
   }
 
   // ---- chunk staging: global -> registers -> LDS (values and their squares) ----
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   auto close_pair = [&](int tile) {   // after the last tile of a group of GT tiles (or a lone last tile)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      top3_insert(tpend[rt], tile / GT, m1[rt], m2[rt], m3[rt], i1[rt], i2[rt]);
+      top4_insert(tpend[rt], tile / GT, m1[rt], m2[rt], m3[rt], m4[rt], i1[rt], i2[rt], i3[rt]);
       tpend[rt] = NEG_INF;
     }
   };
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
         }
         // pin the order: LDS reads | first MFMAs | ONE VALU cluster | remaining MFMAs
         __builtin_amdgcn_sched_group_barrier(0x008, S0 * RT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, RT * (PREV_CLOSES ? 18 : 9), 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, RT * (PREV_CLOSES ? 22 : 9), 0);
         __builtin_amdgcn_sched_group_barrier(0x008, (2 * HD - S0) * RT, 0);
       };
       auto run_all = [&](auto... is) {
@@ -359,19 +359,20 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   // ---- merge the two lane halves of each row, write one record -------------
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt];
-    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h;   // half-group ids
-    const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32);
-    const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32);
-    top3_insert(b1, k1, a1, a2v, a3, j1, j2);
-    top3_insert(b2, k2, a1, a2v, a3, j1, j2);
-    top3_insert_value(b3, a2v, a3);
+    float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt], a4 = m4[rt];
+    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h, j3 = i3[rt] * 2 + h;   // half-group ids
+    const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32), b4 = __shfl_xor(a4, 32);
+    const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32), k3 = __shfl_xor(j3, 32);
+    top4_insert(b1, k1, a1, a2v, a3, a4, j1, j2, j3);
+    top4_insert(b2, k2, a1, a2v, a3, a4, j1, j2, j3);
+    top4_insert(b3, k3, a1, a2v, a3, a4, j1, j2, j3);
+    top4_insert_value(b4, a3, a4);
     const int pos = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
     if (h == 0 && pos < nrows) {
       const int row = p.row_list ? p.row_list[pos] : pos;
       Rec r;
-      r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.id1 = j1; r.id2 = j2;
-      r.pad[0] = r.pad[1] = r.pad[2] = 0;
+      r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.m4 = a4; r.id1 = j1; r.id2 = j2; r.id3 = j3;
+      r.pad = 0;
       p.rec[(long)split * p.rows + row] = r;
     }
   }

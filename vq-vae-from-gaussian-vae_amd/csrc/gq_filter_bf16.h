@@ -2,8 +2,8 @@
 //
 // Same contract as gq_filter_kernel: for every row r and code j it evaluates
 //     f(r, j) = sum_i  A[r,i] * c[j,i]^2  +  B[r,i] * c[j,i]
-// and keeps, per (row, code split), the three largest half-group maxima + the ids of the best two; the
-// re-rank kernel then decides exactly.  The products are formed on v_mfma_f32_32x32x16_bf16 (16x the fp32
+// and keeps, per (row, code split), the four largest half-group maxima + the ids of the best three (three / two
+// in the packed dim-4 kernel); the re-rank kernel then decides exactly.  The products are formed on v_mfma_f32_32x32x16_bf16 (16x the fp32
 // MFMA rate) from two-term bf16 splits of every fp32 operand q = q_h + q_l (+ residual <= 2^-18 |q|):
 //     A * s  ~  A_h s_h  +  A_h s_l  +  A_l s_h          (each bf16 x bf16 product is exact in fp32)
 // so a fp32 MAC costs three bf16 MACs and the filter value carries a relative error of ~3 * 2^-18 per
@@ -198,6 +198,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   constexpr int NT = 64 * WAVES;              // threads per block
   constexpr int R4 = CHUNK_Q / NT;            // 16-byte loads per thread per chunk
   constexpr int NM = BfLayout<NV>::NM;        // MFMAs per tile and row tile
+  // candidate tracker depth: top-4 (ids of three), except in the packed dim-4 kernel, which is bound by its
+  // epilogue's VALU work (top-3 there: +18 % filter time otherwise, measured)
+  constexpr bool TOP4 = NV > 0;
   static_assert(R4 >= 1 && CHUNK_Q % NT == 0 && CT % GT == 0, "chunk: whole tile groups, whole thread passes");
   __shared__ u32x4 lds[2][CHUNK_Q];
 
@@ -231,12 +234,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   }
 
   const float NEG_INF = -__builtin_inff();
-  float m1[RT], m2[RT], m3[RT], tpend[RT];
-  int i1[RT], i2[RT];
+  float m1[RT], m2[RT], m3[RT], m4[RT], tpend[RT];
+  int i1[RT], i2[RT], i3[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    m1[rt] = m2[rt] = m3[rt] = tpend[rt] = NEG_INF;
-    i1[rt] = i2[rt] = 0;
+    m1[rt] = m2[rt] = m3[rt] = m4[rt] = tpend[rt] = NEG_INF;
+    i1[rt] = i2[rt] = i3[rt] = 0;
   }
 
   // ---- chunk staging: global image -> registers -> LDS (a linear copy) ----
@@ -257,7 +260,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   auto close_group = [&](int tile) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      top3_insert(tpend[rt], tile / GT, m1[rt], m2[rt], m3[rt], i1[rt], i2[rt]);
+      if constexpr (TOP4)
+        top4_insert(tpend[rt], tile / GT, m1[rt], m2[rt], m3[rt], m4[rt], i1[rt], i2[rt], i3[rt]);
+      else
+        top3_insert(tpend[rt], tile / GT, m1[rt], m2[rt], m3[rt], i1[rt], i2[rt]);
       tpend[rt] = NEG_INF;
     }
   };
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         // PREVIOUS tile's epilogue (its accumulators are long complete; bf16 MFMAs and VALU overlap)
         // (VALU budget slightly under the real count, none after the last MFMA: a slot left over would pull the
         // NEXT step's epilogue -- the accumulators just written -- forward and stall on the MFMA latency)
-        constexpr int BUDGET = (PREV_CLOSES ? 16 : 8) * RT, K = NM * RT - 1;
+        constexpr int BUDGET = (PREV_CLOSES ? (TOP4 ? 20 : 16) : 8) * RT, K = NM * RT - 1;
         constexpr int PER = BUDGET / K, EXTRA = BUDGET % K;   // the first EXTRA MFMAs carry PER+1 VALU slots
 #pragma unroll
         for (int k = 0; k < EXTRA; ++k) {
@@ -391,18 +397,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   // ---- merge the two lane halves of each row, write one record ----
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt];
-    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h;
-    const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32);
-    const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32);
-    top3_insert(b1, k1, a1, a2v, a3, j1, j2);
-    top3_insert(b2, k2, a1, a2v, a3, j1, j2);
-    top3_insert_value(b3, a2v, a3);
+    float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt], a4 = m4[rt];
+    int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h, j3 = i3[rt] * 2 + h;   // half-group ids
+    if constexpr (TOP4) {
+      const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32), b4 = __shfl_xor(a4, 32);
+      const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32), k3 = __shfl_xor(j3, 32);
+      top4_insert(b1, k1, a1, a2v, a3, a4, j1, j2, j3);
+      top4_insert(b2, k2, a1, a2v, a3, a4, j1, j2, j3);
+      top4_insert(b3, k3, a1, a2v, a3, a4, j1, j2, j3);
+      top4_insert_value(b4, a3, a4);
+    } else {
+      // top-3 tracker: the record's third slot stays empty and its fourth value is the third-largest maximum,
+      // so the re-rank treats "third group within the margin" as undecided
+      const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32);
+      const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32);
+      top3_insert(b1, k1, a1, a2v, a3, j1, j2);
+      top3_insert(b2, k2, a1, a2v, a3, j1, j2);
+      a3 = __builtin_amdgcn_fmed3f(a2v, a3, b3);
+      a4 = a3;
+      a3 = -__builtin_inff();
+      j3 = 0;
+    }
     const int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;
     if (h == 0 && row < p.rows) {
       Rec r;
-      r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.id1 = j1; r.id2 = j2;
-      r.pad[0] = r.pad[1] = r.pad[2] = 0;
+      r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.m4 = a4; r.id1 = j1; r.id2 = j2; r.id3 = j3;
+      r.pad = 0;
       p.rec[(long)split * p.rows + row] = r;
     }
   }

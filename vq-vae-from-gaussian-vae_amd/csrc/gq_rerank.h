@@ -8,11 +8,12 @@
 // every code j,  |filter(r,j) + const(r) - ref_score(r,j)| <= E(r), where E is
 // the rigorous rounding bound computed below from (mu, sd, max|cb|, dim).  The
 // reference's arg-max j* therefore satisfies filter(r,j*) >= max_j filter(r,j)
-// - 2E, i.e. it lies in a half-pair whose maximum is within `margin` = 2.5 E of
-// the row maximum.  The filter keeps, per (row, split), the best two such
-// half-pairs by id and the third by value; if the third is also within the
-// margin (or the row has non-finite operands / bound) the row goes to the
-// exhaustive kernel instead.  Either way no approximation reaches the output.
+// - 2E, i.e. it lies in a half-group whose maximum is within `margin` = 2.5 E of
+// the row maximum.  The filter keeps, per (row, split), the best three such
+// half-groups by id and the fourth by value; if the fourth is also within the
+// margin (or the row has non-finite operands / bound) the row is undecided and
+// goes to the next stage (fp32 filter level of the cascade, then the fp64 second
+// stage) instead.  Either way no approximation reaches the output.
 #pragma once
 #include "gq_common.h"
 #include "gq_filter.h"
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   constexpr int RPW = 64 / GROUP;            // rows per wave
   constexpr int RPB = 4 * RPW;               // rows per block
   constexpr int NSI = kMaxSplit / GROUP;     // record passes per lane (code splits <= kMaxSplit)
-  __shared__ int cand[RPB][2 * kMaxSplit];
+  __shared__ int cand[RPB][3 * kMaxSplit];
   __shared__ RowOps rops[RPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % GROUP, grp = lane / GROUP;
@@ -247,8 +248,8 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   float fmax = NEG_INF;
 #pragma unroll
   for (int k = 0; k < NSI; ++k) {
-    r[k].m1 = r[k].m2 = r[k].m3 = NEG_INF;
-    r[k].id1 = r[k].id2 = 0;
+    r[k].m1 = r[k].m2 = r[k].m3 = r[k].m4 = NEG_INF;
+    r[k].id1 = r[k].id2 = r[k].id3 = 0;
     const int s = k * GROUP + sub;
     if (s < p.nsplit) r[k] = p.rec[(long)s * p.rows + row];
     fmax = __builtin_fmaxf(fmax, r[k].m1);
@@ -264,12 +265,14 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
 #pragma unroll
   for (int k = 0; k < NSI; ++k) {
     const bool c1 = (double)r[k].m1 >= thr, c2 = (double)r[k].m2 >= thr, c3 = (double)r[k].m3 >= thr;
+    const bool c4 = (double)r[k].m4 >= thr;
     const unsigned long long b1 = group_bits(c1), b2 = group_bits(c2), b3 = group_bits(c3);
-    third = third || b3 != 0ull;
-    const int n1 = __popcll(b1);
+    third = third || group_bits(c4) != 0ull;   // a fourth group of some split could matter: undecided
+    const int n1 = __popcll(b1), n2 = __popcll(b2);
     if (c1) cand[slot][total + __popcll(b1 & lt)] = r[k].id1;
     if (c2) cand[slot][total + n1 + __popcll(b2 & lt)] = r[k].id2;
-    total += n1 + __popcll(b2);
+    if (c3) cand[slot][total + n1 + n2 + __popcll(b3 & lt)] = r[k].id3;
+    total += n1 + n2 + __popcll(b3);
   }
   const bool undecided = bad || third;       // group-uniform
   if (undecided) {

@@ -446,10 +446,10 @@ def debug_plan(rows: int, n: int, dim: int) -> dict:
 
 
 def debug_records(ws: Workspace, rows: int, n: int, dim: int):
-    """Candidate records the filter left in the workspace: (m [nsplit, rows, 3] fp32, ids [nsplit, rows, 2] int32)."""
+    """Candidate records the filter left in the workspace: (m [nsplit, rows, 4] fp32, ids [nsplit, rows, 3] int32)."""
     pl = debug_plan(rows, n, dim)
     raw = ws.buf[pl["rec_offset"]: pl["rec_offset"] + pl["nsplit"] * rows * 32].view(torch.int32).reshape(pl["nsplit"], rows, 8)
-    return raw[..., :3].contiguous().view(torch.float32), raw[..., 3:5].contiguous()
+    return raw[..., :4].contiguous().view(torch.float32), raw[..., 4:7].contiguous()
 
 
 def debug_counters(ws: Workspace) -> Tuple[int, int]:
