@@ -185,6 +185,17 @@ int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y
 int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t W, int64_t C,
                         void *stream);
 
+/* Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (pit/modules/unet.py:69-73): src [B, H+1, W+1, 4*C] is the
+ * padding-1 2x2 convolution of the LOW-resolution input with the four phase kernels stacked along the output channels
+ * (phase (a, b) = sums of the 3x3 taps that fall on the same source pixel); y [B, 2H, 2W, C] NHWC,
+ * y[b][2i+a][2j+b'][c] = src[b][i+a][j+b'][(2a+b')*C + c].  2.25x fewer conv flops than upsampling first. */
+int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+
+/* The 2x2 patches (padding 1) of an NHWC tensor x [B, H, W, C] as GEMM rows: A [B*(H+1)*(W+1), 4*C],
+ * A[(b,p,q)][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c] (zero outside).  A x Wmat [4C, 4*Cout] is the `src` of
+ * upconv_shuffle_nhwc_f32 (the phase convolution as one hipBLASLt GEMM). */
+int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+
 /* ---- index wire format / usage histogram ----------------------------------- */
 int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n,
                        int32_t *hist, void *stream);

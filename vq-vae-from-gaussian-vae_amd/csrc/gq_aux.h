@@ -377,6 +377,45 @@ __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__res
   }
 }
 
+// im2col of the 2x2 phase convolution (padding 1) of an NHWC tensor: A[b][p][q][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c]
+// (zero outside), p in [0, H], q in [0, W].  One thread per (patch position, tap, channel quad).
+__global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__restrict__ x, float *__restrict__ A,
+                                                                 int H, int W, int C4, long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q4 = (int)(t % C4);
+    long r = t / C4;
+    const int tap = (int)(r & 3);
+    r >>= 2;
+    const int q = (int)(r % (W + 1));
+    r /= W + 1;
+    const int p = (int)(r % (H + 1));
+    const long b = r / (H + 1);
+    const int sy = p + (tap >> 1) - 1, sx = q + (tap & 1) - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q4];
+    reinterpret_cast<f32x4 *>(A)[t] = v;
+  }
+}
+
+// Pixel shuffle of the sub-pixel form of "nearest x2 upsample, then 3x3 conv" (unet.py:69-73): the four output phases
+// (a, b) = (oy & 1, ox & 1) are 2x2 convolutions of the LOW-resolution input (weights = sums of the 3x3 taps that fall
+// on the same source pixel); one conv computes all four as 4*C output channels on an (H+1) x (W+1) grid (padding 1),
+//   y[b][2i+a][2j+b'][c] = src[b][i+a][j+b'][(2a+b')*C + c].   NHWC, one thread per (output pixel, channel quad).
+__global__ __launch_bounds__(256) void upconv_shuffle_nhwc_kernel(const float *__restrict__ src, float *__restrict__ y,
+                                                                  int H, int W, int C4, long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q = (int)(t % C4);
+    long p = t / C4;
+    const int ox = (int)(p % (2 * W));
+    p /= 2 * W;
+    const int oy = (int)(p % (2 * H));
+    const long b = p / (2 * H);
+    const int a = oy & 1, bb = ox & 1;
+    const long sp = (b * (H + 1) + (oy >> 1) + a) * (W + 1) + (ox >> 1) + bb;   // source pixel
+    reinterpret_cast<f32x4 *>(y)[t] = reinterpret_cast<const f32x4 *>(src)[sp * (4L * C4) + (2 * a + bb) * C4 + q];
+  }
+}
+
 // y = a + b (+ bias[c]): the residual add of a ResnetBlock with the pending conv biases folded in.
 __global__ __launch_bounds__(256) void add_bias_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                        const float *__restrict__ bias, float *__restrict__ y, int C,

@@ -645,6 +645,30 @@ int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y
   return check_launch();
 }
 
+int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
+  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !A) return GQHIP_ERR_INVALID_ARG;
+  const long total = (long)(B * (H + 1) * (W + 1) * 4 * (C / 4));
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(upconv_im2col_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     A, (int)H, (int)W, (int)(C / 4), total);
+  return check_launch();
+}
+
+int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
+  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!src || !y) return GQHIP_ERR_INVALID_ARG;
+  const long total = (long)(B * 2 * H * 2 * W * (C / 4));
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(upconv_shuffle_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     src, y, (int)H, (int)W, (int)(C / 4), total);
+  return check_launch();
+}
+
 int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
   if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;

@@ -52,6 +52,8 @@ _SIGNATURES = {
                                    ctypes.c_int, _vp, _vp]),
     "add_bias_stats_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "gn_apply_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp]),
+    "upconv_im2col_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "upconv_shuffle_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "upsample2x_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
@@ -365,6 +367,30 @@ def gn_apply(x, gamma, beta, groups: int, eps: float, silu: bool, stats):
     with torch.cuda.device(x.device):
         _check(lib().gn_apply_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), B, C, HW, groups,
                                   float(eps), 1 if silu else 0, stats.data_ptr(), _stream()), "gn_apply_f32")
+    return y
+
+
+def upconv_im2col(x):
+    """2x2 patches (padding 1) of a channels_last fp32 HIP tensor [B, C, H, W] as GEMM rows [B*(H+1)*(W+1), 4C]."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 4:
+        raise GqHipError("upconv_im2col needs a dense channels_last fp32 HIP tensor with C % 4 == 0")
+    B, C, H, W = x.shape
+    A = torch.empty((B * (H + 1) * (W + 1), 4 * C), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().upconv_im2col_nhwc_f32(x.data_ptr(), A.data_ptr(), B, H, W, C, _stream()), "upconv_im2col_nhwc_f32")
+    return A
+
+
+def upconv_shuffle(src, C: int):
+    """Pixel shuffle of the sub-pixel upsample+conv: src [B, 4C, H+1, W+1] channels_last -> [B, C, 2H, 2W]."""
+    if image_layout(src) != 1 or not src.is_cuda or src.dtype != torch.float32 or src.shape[1] != 4 * C or C % 4:
+        raise GqHipError("upconv_shuffle needs a dense channels_last fp32 HIP tensor [B, 4C, H+1, W+1], C % 4 == 0")
+    B, _, H1, W1 = src.shape
+    y = torch.empty((B, C, 2 * (H1 - 1), 2 * (W1 - 1)), dtype=src.dtype, device=src.device,
+                    memory_format=torch.channels_last)
+    with torch.cuda.device(src.device):
+        _check(lib().upconv_shuffle_nhwc_f32(src.data_ptr(), y.data_ptr(), B, H1 - 1, W1 - 1, C, _stream()),
+               "upconv_shuffle_nhwc_f32")
     return y
 
 
