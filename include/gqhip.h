@@ -185,6 +185,13 @@ int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y
 int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t W, int64_t C,
                         void *stream);
 
+/* Winograd F(2x2, 3x3) data transforms for a stride-1, padding-1 3x3 convolution of an NHWC tensor (the decoder's wide
+ * ResnetBlock convolutions, pit/modules/unet.py:142, :149): V [16, tiles, C] = B^T d B of every 4x4 input tile
+ * (tiles = B * H/2 * W/2, H and W even); after the 16 GEMMs M[k] = V[k] x U[k] (U = G g G^T, [16, Cin, Cout]) the
+ * output transform writes y [B, H, W, Cout] = A^T M A.  16 instead of 36 multiplies per 2x2 outputs. */
+int wino_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+
 /* Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (pit/modules/unet.py:69-73): src [B, H+1, W+1, 4*C] is the
  * padding-1 2x2 convolution of the LOW-resolution input with the four phase kernels stacked along the output channels
  * (phase (a, b) = sums of the 3x3 taps that fall on the same source pixel); y [B, 2H, 2W, C] NHWC,

@@ -587,3 +587,43 @@ def test_subpixel_upsample_conv_matches_upsample_then_conv():
         got = y + b[None, :, None, None]
         assert torch.allclose(got, ref, atol=2e-5, rtol=1e-5), float((got - ref).abs().max())
         assert torch.allclose(y, y0, atol=2e-5, rtol=1e-5)
+
+
+def test_winograd_conv3x3_matches_direct_conv():
+    """Winograd F(2x2,3x3) path of the decoder's wide 3x3 convolutions (transform kernels + 16 hipBLASLt GEMMs)
+    against F.conv2d: same function up to fp32 rounding (the GEMM library's fp32 is ~3e-7 of sum|a||b|)."""
+    import torch.nn.functional as F
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(2)
+    for cin, cout, H, W in ((256, 256, 16, 24), (512, 256, 8, 8), (64, 32, 6, 10)):
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+        x = torch.randn(2, cin, H, W).to(DEV).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y = _lib.wino_conv3x3(x, U._wino_weights(conv))
+            ref = F.conv2d(x.double(), conv.weight.double(), None, 1, 1)
+            direct = F.conv2d(x, conv.weight, None, 1, 1)
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        scale = float(ref.abs().mean())
+        e_w, e_d = float((y.double() - ref).abs().max()) / scale, float((direct.double() - ref).abs().max()) / scale
+        print(f"winograd {cin}->{cout} {H}x{W}: max err / mean|y| = {e_w:.2e} (direct MIOpen conv: {e_d:.2e})")
+        assert e_w < 2e-4
+
+
+def test_decoder_with_and_without_winograd_agree():
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(0)
+    cfg = dict(ch=128, out_ch=3, in_channels=3, resolution=64, z_channels=16, double_z=True, ch_mult=[1, 2, 4, 4],
+               num_res_blocks=2, attn_resolutions=[8], dropout=0.0)
+    dec = U.Decoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
+    z = torch.randn(2, 16, 8, 8).to(DEV).contiguous(memory_format=torch.channels_last)
+    outs = []
+    with torch.no_grad():
+        for flag in (True, False):
+            U.WINOGRAD = flag
+            outs.append(dec(z))
+    U.WINOGRAD = True
+    d = float((outs[0] - outs[1]).abs().max())
+    assert d <= 2e-3 * max(1.0, float(outs[1].abs().max())), d

@@ -377,6 +377,83 @@ __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__res
   }
 }
 
+// ---- Winograd F(2x2, 3x3), NHWC, stride 1, padding 1 (used for the decoder's wide 3x3 convolutions) -------------
+// Y = A^T [ (G g G^T) . (B^T d B) ] A per 4x4 input tile d (stride 2) and 2x2 output tile: 16 multiplies per 4 outputs
+// instead of 36.  The element-wise products over the channels are 16 independent GEMMs [tiles, Cin] x [Cin, Cout]
+// (torch.bmm -> hipBLASLt); these two kernels are the data transforms around them.
+//   V[k][tile][c] = (B^T d B)[k]     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+//   y[2x2]        = A^T m A          A^T = [1 1 1 0; 0 1 -1 -1]
+// One thread per (tile, channel quad); tiles = B * (H/2) * (W/2), H and W even.
+__global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restrict__ x, float *__restrict__ V, int H, int W,
+                                                           int C4, long tiles, long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q = (int)(t % C4);
+    const long tile = t / C4;
+    const int tw = (int)(tile % (W / 2));
+    const long r = tile / (W / 2);
+    const int th = (int)(r % (H / 2));
+    const long b = r / (H / 2);
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sy = 2 * th - 1 + i, sx = 2 * tw - 1 + j;
+        d[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+          d[i][j] = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q];
+      }
+    f32x4 w[4][4];   // B^T d
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[0][j] = d[0][j] - d[2][j];
+      w[1][j] = d[1][j] + d[2][j];
+      w[2][j] = d[2][j] - d[1][j];
+      w[3][j] = d[1][j] - d[3][j];
+    }
+    f32x4 *o = reinterpret_cast<f32x4 *>(V) + tile * C4 + q;
+    const long plane = tiles * C4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // (B^T d) B
+      o[(4 * i + 0) * plane] = w[i][0] - w[i][2];
+      o[(4 * i + 1) * plane] = w[i][1] + w[i][2];
+      o[(4 * i + 2) * plane] = w[i][2] - w[i][1];
+      o[(4 * i + 3) * plane] = w[i][1] - w[i][3];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_out_nhwc_kernel(const float *__restrict__ M, float *__restrict__ y, int H, int W,
+                                                            int C4, long tiles, long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q = (int)(t % C4);
+    const long tile = t / C4;
+    const int tw = (int)(tile % (W / 2));
+    const long r = tile / (W / 2);
+    const int th = (int)(r % (H / 2));
+    const long b = r / (H / 2);
+    const f32x4 *mi = reinterpret_cast<const f32x4 *>(M) + tile * C4 + q;
+    const long plane = tiles * C4;
+    f32x4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[i][j] = mi[(4 * i + j) * plane];
+    f32x4 u[2][4];   // A^T m
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u[0][j] = m[0][j] + m[1][j] + m[2][j];
+      u[1][j] = m[1][j] - m[2][j] - m[3][j];
+    }
+    f32x4 *o = reinterpret_cast<f32x4 *>(y) + ((b * H + 2 * th) * W + 2 * tw) * C4 + q;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      o[(long)i * W * C4] = u[i][0] + u[i][1] + u[i][2];
+      o[(long)i * W * C4 + C4] = u[i][1] - u[i][2] - u[i][3];
+    }
+  }
+}
+
 // im2col of the 2x2 phase convolution (padding 1) of an NHWC tensor: A[b][p][q][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c]
 // (zero outside), p in [0, H], q in [0, W].  One thread per (patch position, tap, channel quad).
 __global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__restrict__ x, float *__restrict__ A,

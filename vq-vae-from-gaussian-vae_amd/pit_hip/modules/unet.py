@@ -73,8 +73,34 @@ def _conv(conv: nn.Conv2d, x: torch.Tensor):
     elementwise pass over the whole output; on the deferred path the conv runs bias-free and the
     bias is handed to the consumer (the next fused GroupNorm or residual add), which folds it in."""
     if _defer_ok(x, conv):
+        if (WINOGRAD and getattr(conv, "_gq_wino", False) and conv.in_channels >= WINOGRAD_MIN_CH
+                and conv.out_channels >= WINOGRAD_MIN_CH and conv.out_channels % 4 == 0 and x.shape[2] % 2 == 0
+                and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+            from .. import _lib
+
+            return _lib.wino_conv3x3(x, _wino_weights(conv)), conv.bias
         return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
     return conv(x), None
+
+
+def _wino_weights(conv: nn.Conv2d) -> torch.Tensor:
+    """U [16, Cin, Cout] = G g G^T of a 3x3 kernel (Winograd F(2x2, 3x3)), cached until the weight changes."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device)
+    if getattr(conv, "_wino_key", None) != key:
+        G = w.new_tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+        u = torch.einsum("ik,ockl,jl->ijco", G, w, G)          # [4, 4, Cin, Cout]
+        conv._wino_u = u.reshape(16, w.shape[1], w.shape[0]).contiguous()
+        conv._wino_key = key
+    return conv._wino_u
+
+
+def mark_winograd(module: nn.Module) -> None:
+    """Flag the stride-1, padding-1 3x3 convolutions of ``module`` for the Winograd path (see ``_conv``)."""
+    for m in module.modules():
+        if (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+                and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros"):
+            m._gq_wino = True
 
 
 def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
@@ -97,6 +123,8 @@ def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
 
 
 FUSED_GN = True    # module-level switches (tests / A-B timing)
+WINOGRAD = True          # decoder 3x3 convs with >= WINOGRAD_MIN_CH channels: Winograd F(2x2,3x3) + 16 hipBLASLt GEMMs
+WINOGRAD_MIN_CH = 256
 SUBPIXEL_UPCONV = True   # Upsample: nearest x2 + conv3x3 as four 2x2 phase convs of the low-res input (2.25x fewer flops)
 FUSED_ADD_STATS = True   # residual add also produces the next GroupNorm's statistics (channels_last only)
 GN_GROUPS = 32     # unet.py:54-57: every Normalize is GroupNorm(32, C, eps=1e-6)
@@ -364,6 +392,7 @@ class Decoder(nn.Module):
         self.up = nn.ModuleList(reversed(levels))  # index = resolution level, like the reference
         self.norm_out = _gn(cin)
         self.conv_out = _conv3(cin, out_ch, padding_mode)
+        mark_winograd(self)   # decoder only: the encoder's rounding decides indices, it stays on MIOpen's fp32 convs
 
     def get_last_layer(self, **kwargs) -> torch.Tensor:
         return self.conv_out.weight
