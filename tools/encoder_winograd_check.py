@@ -1,0 +1,36 @@
+"""What Winograd in the ENCODER does to the indices (it is on by default, unet.WINOGRAD_ENCODER): perturbation of z against the
+direct-conv encoder and against the CPU golden, and the number of index flips on a bs-16 random batch."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vq-vae-from-gaussian-vae_amd"))
+import bench
+from pit_hip.modules import unet
+
+dev = torch.device("cuda:0")
+vae = bench.build_model(dev).to(memory_format=torch.channels_last)
+d = np.load(os.path.join(ROOT, "tests", "golden", "g7_full_e2e.npz"))
+gx = torch.Generator().manual_seed(1000)
+x1 = (torch.rand(1, 3, 256, 256, generator=gx) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
+g = torch.Generator().manual_seed(5)
+x16 = (torch.rand(16, 3, 256, 256, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
+res = {}
+with torch.no_grad():
+    for name in ("direct", "winograd"):
+        unet.WINOGRAD = name == "winograd"
+        z1 = vae.encoder(x1)
+        _, i1 = vae.quant(x1)
+        z16 = vae.encoder(x16)
+        _, i16 = vae.quant(x16)
+        res[name] = (z1.cpu(), i1.cpu(), z16.cpu(), i16.cpu())
+unet.WINOGRAD = True
+zc = torch.from_numpy(d["z_enc"])
+for name in res:
+    z1, i1 = res[name][0], res[name][1]
+    print(f"{name:9s}: max|z - z_cpu| = {float((z1 - zc).abs().max()):.3e}; index mismatches vs CPU golden: "
+          f"{int((i1.numpy() != d['indices']).sum())} / {i1.numel()}")
+zd, zw = res["direct"][2], res["winograd"][2]
+flips = (res["direct"][3] != res["winograd"][3])
+print(f"bs16: max|z_wino - z_direct| = {float((zw - zd).abs().max()):.3e} (mean |z| {float(zd.abs().mean()):.3f}); "
+      f"index flips winograd vs direct: {int(flips.sum())} / {flips.numel()}")
