@@ -192,6 +192,18 @@ int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t 
 int wino_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
 int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
 
+/* NHWC only.  GroupNorm statistics alone (the first pass of gn_silu_f32): stats_out[2*(b*groups+g)] = sum, [+1] = sum of
+ * squares of x (+ pre_bias[c]) over the group, fp64, zeroed here. */
+int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64_t C, int64_t HW, int64_t groups,
+                 double *stats_out, void *stream);
+
+/* wino_in_nhwc_f32 with the producer fused in: the convolution's input is SiLU(GroupNorm(x + pre_bias)) (the
+ * `Normalize` -> `nonlinearity` -> conv chains of pit/modules/unet.py:140-142, :146-149); the normalised tensor is
+ * never written.  `stats` as produced by gn_stats_f32 / add_bias_stats_f32. */
+int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                        const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C,
+                        int64_t groups, double eps, int apply_silu, void *stream);
+
 /* Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (pit/modules/unet.py:69-73): src [B, H+1, W+1, 4*C] is the
  * padding-1 2x2 convolution of the LOW-resolution input with the four phase kernels stacked along the output channels
  * (phase (a, b) = sums of the 3x3 taps that fall on the same source pixel); y [B, 2H, 2W, C] NHWC,

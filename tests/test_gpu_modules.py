@@ -627,3 +627,24 @@ def test_decoder_with_and_without_winograd_agree():
     U.WINOGRAD = True
     d = float((outs[0] - outs[1]).abs().max())
     assert d <= 2e-3 * max(1.0, float(outs[1].abs().max())), d
+
+
+def test_winograd_with_fused_groupnorm_matches_unfused():
+    """GroupNorm+SiLU applied inside the Winograd input transform == gn_silu followed by the plain transform."""
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(256, 128, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+    norm = torch.nn.GroupNorm(32, 256, eps=1e-6).to(DEV)
+    with torch.no_grad():
+        norm.weight.normal_(); norm.bias.normal_()
+    x = torch.randn(3, 256, 12, 20).to(DEV).contiguous(memory_format=torch.channels_last)
+    pb = torch.randn(256).to(DEV)
+    with torch.no_grad():
+        Uw = U._wino_weights(conv)
+        for pre in (None, pb):
+            stats = _lib.gn_stats(x, 32, pre)
+            fused = _lib.wino_conv3x3(x, Uw, gn=(norm.weight, norm.bias, 32, 1e-6, True, stats, pre))
+            plain = _lib.wino_conv3x3(_lib.gn_silu(x, norm.weight, norm.bias, 32, 1e-6, silu=True, pre_bias=pre), Uw)
+            assert torch.allclose(fused, plain, atol=1e-5, rtol=1e-5), float((fused - plain).abs().max())

@@ -423,6 +423,78 @@ __global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restri
   }
 }
 
+// Input transform with the producer fused in: the conv input is GroupNorm(+SiLU) of x (unet.py:140-142, :146-149), so
+// the normalisation is applied to the 16 loaded values on the fly (statistics from gn_stats / add_bias_stats) and the
+// normalised tensor is never written: saves gn_apply's write and this kernel's read of it.  Zero padding applies to the
+// ACTIVATED tensor, so out-of-bounds taps stay exactly 0.
+template <int SILU>
+__global__ __launch_bounds__(256) void wino_in_gn_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              const float *__restrict__ pre_bias,
+                                                              const double *__restrict__ stats, float *__restrict__ V,
+                                                              int H, int W, int C4, int cpg, double eps, long tiles,
+                                                              long total) {
+  const int groups = 4 * C4 / cpg;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q = (int)(t % C4);
+    const long tile = t / C4;
+    const int tw = (int)(tile % (W / 2));
+    const long r = tile / (W / 2);
+    const int th = (int)(r % (H / 2));
+    const long b = r / (H / 2);
+    const int g = (4 * q) / cpg;
+    const double n = (double)cpg * (double)H * (double)W;
+    const double mean = stats[2 * (b * groups + g)] / n;
+    double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    f32x4 a, sh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = 4 * q + k;
+      const double pbk = pre_bias ? (double)pre_bias[c] : 0.0;
+      a[k] = (float)(rstd * (double)gamma[c]);
+      sh[k] = (float)((double)beta[c] + (pbk - mean) * rstd * (double)gamma[c]);
+    }
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sy = 2 * th - 1 + i, sx = 2 * tw - 1 + j;
+        d[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+          f32x4 v = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q] * a + sh;
+          if (SILU) {   // x * sigmoid(x); v_rcp_f32 (1 ulp) instead of an IEEE divide: every input pixel is activated by
+                        // the four tiles that overlap it, so the activation is on this kernel's critical path
+            v.x = v.x * __builtin_amdgcn_rcpf(1.0f + __expf(-v.x));
+            v.y = v.y * __builtin_amdgcn_rcpf(1.0f + __expf(-v.y));
+            v.z = v.z * __builtin_amdgcn_rcpf(1.0f + __expf(-v.z));
+            v.w = v.w * __builtin_amdgcn_rcpf(1.0f + __expf(-v.w));
+          }
+          d[i][j] = v;
+        }
+      }
+    f32x4 w[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[0][j] = d[0][j] - d[2][j];
+      w[1][j] = d[1][j] + d[2][j];
+      w[2][j] = d[2][j] - d[1][j];
+      w[3][j] = d[1][j] - d[3][j];
+    }
+    f32x4 *o = reinterpret_cast<f32x4 *>(V) + tile * C4 + q;
+    const long plane = tiles * C4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[(4 * i + 0) * plane] = w[i][0] - w[i][2];
+      o[(4 * i + 1) * plane] = w[i][1] + w[i][2];
+      o[(4 * i + 2) * plane] = w[i][2] - w[i][1];
+      o[(4 * i + 3) * plane] = w[i][1] - w[i][3];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wino_out_nhwc_kernel(const float *__restrict__ M, float *__restrict__ y, int H, int W,
                                                             int C4, long tiles, long total) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {

@@ -657,6 +657,42 @@ int wino_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, 
   return check_launch();
 }
 
+int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64_t C, int64_t HW, int64_t groups,
+                 double *stats_out, void *stream) {
+  if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !stats_out) return GQHIP_ERR_INVALID_ARG;
+  const int64_t cpg = C / groups;
+  if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(stats_out, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) return check_launch();
+  const int slabs = nhwc_slabs(C, HW);
+  hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, pre_bias_or_null, stats_out,
+                     (int)C, (long)HW, (int)cpg, slabs);
+  return check_launch();
+}
+
+int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                        const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                        double eps, int apply_silu, void *stream) {
+  if (B < 0 || H < 2 || W < 2 || H % 2 || W % 2 || C < 4 || C % 4 != 0 || groups < 1 || C % groups != 0 ||
+      (C / groups) % 4 != 0)
+    return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !gamma || !beta || !stats || !V) return GQHIP_ERR_INVALID_ARG;
+  const long tiles = (long)(B * (H / 2) * (W / 2)), total = tiles * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (apply_silu)
+    hipLaunchKernelGGL((wino_in_gn_nhwc_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
+                       pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
+  else
+    hipLaunchKernelGGL((wino_in_gn_nhwc_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
+                       pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
+  return check_launch();
+}
+
 int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
   if (B < 0 || H < 2 || W < 2 || H % 2 || W % 2 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;

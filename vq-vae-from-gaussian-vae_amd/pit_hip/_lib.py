@@ -53,6 +53,9 @@ _SIGNATURES = {
     "add_bias_stats_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "gn_apply_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp]),
     "wino_in_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
+                                            ctypes.c_int, _vp]),
     "wino_out_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "upconv_im2col_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "upconv_shuffle_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
@@ -372,9 +375,23 @@ def gn_apply(x, gamma, beta, groups: int, eps: float, silu: bool, stats):
     return y
 
 
-def wino_conv3x3(x, U):
+def gn_stats(x, groups: int, pre_bias=None):
+    """channels_last only: GroupNorm statistics of x (+ pre_bias[c]) as [2 * B * groups] fp64 (sum, sum of squares)."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or not gn_nhwc_ok(x.shape[1], groups):
+        raise GqHipError("gn_stats needs a dense channels_last fp32 HIP tensor with a GroupNorm-compatible C")
+    B, C = x.shape[0], x.shape[1]
+    stats = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().gn_stats_f32(x.data_ptr(), _ptr(pre_bias), B, C, x.shape[2] * x.shape[3], groups, stats.data_ptr(),
+                                  _stream()), "gn_stats_f32")
+    return stats
+
+
+def wino_conv3x3(x, U, gn=None):
     """3x3 stride-1 padding-1 convolution of a channels_last fp32 HIP tensor by Winograd F(2x2, 3x3):
-    U [16, Cin, Cout] = G g G^T (see unet._wino_weights).  Returns [B, Cout, H, W] channels_last, no bias."""
+    U [16, Cin, Cout] = G g G^T (see unet._wino_weights).  Returns [B, Cout, H, W] channels_last, no bias.
+    ``gn`` = (gamma, beta, groups, eps, silu, stats, pre_bias): the convolution's input is SiLU(GroupNorm(x + pre_bias)),
+    applied inside the input transform (the normalised tensor is never materialised)."""
     if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 4 or x.shape[2] % 2 or x.shape[3] % 2:
         raise GqHipError("wino_conv3x3 needs a dense channels_last fp32 HIP tensor, C % 4 == 0, even H and W")
     B, C, H, W = x.shape
@@ -382,7 +399,13 @@ def wino_conv3x3(x, U):
     tiles = B * (H // 2) * (W // 2)
     V = torch.empty((16, tiles, C), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().wino_in_nhwc_f32(x.data_ptr(), V.data_ptr(), B, H, W, C, _stream()), "wino_in_nhwc_f32")
+        if gn is None:
+            _check(lib().wino_in_nhwc_f32(x.data_ptr(), V.data_ptr(), B, H, W, C, _stream()), "wino_in_nhwc_f32")
+        else:
+            gamma, beta, groups, eps, silu, stats, pre_bias = gn
+            _check(lib().wino_in_gn_nhwc_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias),
+                                             stats.data_ptr(), V.data_ptr(), B, H, W, C, groups, float(eps),
+                                             1 if silu else 0, _stream()), "wino_in_gn_nhwc_f32")
         M = torch.bmm(V, U)                                   # 16 GEMMs [tiles, Cin] x [Cin, Cout] (hipBLASLt)
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         _check(lib().wino_out_nhwc_f32(M.data_ptr(), y.data_ptr(), B, H, W, cout, _stream()), "wino_out_nhwc_f32")

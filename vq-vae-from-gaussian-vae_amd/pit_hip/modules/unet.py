@@ -73,14 +73,35 @@ def _conv(conv: nn.Conv2d, x: torch.Tensor):
     elementwise pass over the whole output; on the deferred path the conv runs bias-free and the
     bias is handed to the consumer (the next fused GroupNorm or residual add), which folds it in."""
     if _defer_ok(x, conv):
-        if (WINOGRAD and getattr(conv, "_gq_wino", False) and conv.in_channels >= WINOGRAD_MIN_CH
-                and conv.out_channels >= WINOGRAD_MIN_CH and conv.out_channels % 4 == 0 and x.shape[2] % 2 == 0
-                and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+        if _wino_ok(conv, x):
             from .. import _lib
 
             return _lib.wino_conv3x3(x, _wino_weights(conv)), conv.bias
         return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
     return conv(x), None
+
+
+def _wino_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
+    return (WINOGRAD and getattr(conv, "_gq_wino", False) and conv.in_channels >= WINOGRAD_MIN_CH
+            and conv.out_channels >= WINOGRAD_MIN_CH and conv.out_channels % 4 == 0 and x.shape[2] % 2 == 0
+            and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
+
+
+def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None):
+    """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  On the Winograd path the GroupNorm(+SiLU) is applied
+    inside the input transform, so the normalised tensor is never written."""
+    if FUSED_WINO_GN and _defer_ok(x, conv) and _wino_ok(conv, x) and _use_fused(x, norm):
+        from .. import _lib
+
+        if _lib.image_layout(x) == 1:
+            st = getattr(x, "_gn_stats", None)
+            if st is not None and pre_bias is None and st[1] == norm.num_groups:
+                stats = st[0]
+            else:
+                stats = _lib.gn_stats(x, norm.num_groups, pre_bias)
+            gn = (norm.weight, norm.bias, norm.num_groups, norm.eps, True, stats, pre_bias)
+            return _lib.wino_conv3x3(x, _wino_weights(conv), gn=gn), conv.bias
+    return _conv(conv, _norm_act(norm, x, pre_bias=pre_bias))
 
 
 def _wino_weights(conv: nn.Conv2d) -> torch.Tensor:
@@ -125,6 +146,8 @@ def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
 FUSED_GN = True    # module-level switches (tests / A-B timing)
 WINOGRAD = True          # decoder 3x3 convs with >= WINOGRAD_MIN_CH channels: Winograd F(2x2,3x3) + 16 hipBLASLt GEMMs
 WINOGRAD_MIN_CH = 128
+FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the Winograd input transform: correct, but no faster (every input
+                         # pixel is activated by the four tiles that overlap it, the kernel stops being HBM-bound): off
 # also in the encoder: measured perturbation of z 4.2e-6 vs the CPU reference (direct MIOpen convs: 3.4e-6), no index
 # change on the CPU golden nor on 16 384 rows against the direct-conv encoder (tools/encoder_winograd_check.py)
 WINOGRAD_ENCODER = True
@@ -164,8 +187,11 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
         """``pre_bias``: bias of the conv that produced ``x``, not yet added (deferred path)."""
-        h, b1 = _conv(self.conv1, _norm_act(self.norm1, x, pre_bias=pre_bias))
-        h, bias = _conv(self.conv2, self.dropout(_norm_act(self.norm2, h, pre_bias=b1)))
+        h, b1 = _norm_act_conv(self.norm1, self.conv1, x, pre_bias)
+        if self.dropout.p > 0.0 and self.training:
+            h, bias = _conv(self.conv2, self.dropout(_norm_act(self.norm2, h, pre_bias=b1)))
+        else:   # dropout is the identity (unet.py:148 with p = 0 / eval)
+            h, bias = _norm_act_conv(self.norm2, self.conv2, h, b1)
         if self.in_channels != self.out_channels:
             # nin(x + pb) = nin_nobias(x) + W.pb + nin.bias : every constant goes into the fused add
             xs, bs = _conv(self.nin_shortcut, x)
