@@ -192,6 +192,12 @@ int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t 
 int wino_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
 int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
 
+/* Winograd F(4x4, 3x3): V [36, tiles, C] of the 6x6 input tiles (tiles = B * H/4 * W/4, H and W multiples of 4) and
+ * y [B, H, W, Cout] from M [36, tiles, Cout]; U = G g G^T is [36, Cin, Cout].  36 multiplies per 16 outputs and 2.25x
+ * (instead of 4x) the activation in V / M, at ~10x the rounding error of F(2x2,3x3): the decoder's convolutions. */
+int wino4_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+
 /* NHWC only.  GroupNorm statistics alone (the first pass of gn_silu_f32): stats_out[2*(b*groups+g)] = sum, [+1] = sum of
  * squares of x (+ pre_bias[c]) over the group, fp64, zeroed here. */
 int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64_t C, int64_t HW, int64_t groups,

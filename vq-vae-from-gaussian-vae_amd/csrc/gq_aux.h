@@ -526,6 +526,96 @@ __global__ __launch_bounds__(256) void wino_out_nhwc_kernel(const float *__restr
   }
 }
 
+// ---- Winograd F(4x4, 3x3): 6x6 input tiles (stride 4), 36 GEMMs, 4x4 output tiles: 36 multiplies per 16 outputs (4x
+// fewer than direct, 1.78x fewer than F(2x2,3x3)) and V / M are 2.25x the activation instead of 4x.  Larger transform
+// constants (up to 8) cost ~10x the rounding error of F(2x2,3x3): used in the decoder only.
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&o)[6]) {
+  o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+  o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+  o[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+  o[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+  o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&o)[4]) {
+  const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34;
+  o[1] = d12 + 2.f * d34;
+  o[2] = s12 + 4.f * s34;
+  o[3] = d12 + 8.f * d34 + m[5];
+}
+
+__global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restrict__ x, float *__restrict__ V, int H, int W,
+                                                            int C4, long tiles, long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q = (int)(t % C4);
+    const long tile = t / C4;
+    const int tw = (int)(tile % (W / 4));
+    const long r = tile / (W / 4);
+    const int th = (int)(r % (H / 4));
+    const long b = r / (H / 4);
+    f32x4 w[6][6];   // B^T d, column by column
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x4 col[6], o[6];
+      const int sx = 4 * tw - 1 + j;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int sy = 4 * th - 1 + i;
+        col[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+          col[i] = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q];
+      }
+      wino4_bt(col, o);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+    f32x4 *out = reinterpret_cast<f32x4 *>(V) + tile * C4 + q;
+    const long plane = tiles * C4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {   // (B^T d) B, row by row
+      f32x4 o[6];
+      wino4_bt(w[i], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) out[(6 * i + j) * plane] = o[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino4_out_nhwc_kernel(const float *__restrict__ M, float *__restrict__ y, int H, int W,
+                                                             int C4, long tiles, long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q = (int)(t % C4);
+    const long tile = t / C4;
+    const int tw = (int)(tile % (W / 4));
+    const long r = tile / (W / 4);
+    const int th = (int)(r % (H / 4));
+    const long b = r / (H / 4);
+    const f32x4 *mi = reinterpret_cast<const f32x4 *>(M) + tile * C4 + q;
+    const long plane = tiles * C4;
+    f32x4 u[4][6];   // A^T m, column by column
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x4 col[6], o[4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) col[i] = mi[(6 * i + j) * plane];
+      wino4_at(col, o);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u[i][j] = o[i];
+    }
+    f32x4 *out = reinterpret_cast<f32x4 *>(y) + ((b * H + 4 * th) * W + 4 * tw) * C4 + q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 o[4];
+      wino4_at(u[i], o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[((long)i * W + j) * C4] = o[j];
+    }
+  }
+}
+
 // im2col of the 2x2 phase convolution (padding 1) of an NHWC tensor: A[b][p][q][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c]
 // (zero outside), p in [0, H], q in [0, W].  One thread per (patch position, tap, channel quad).
 __global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__restrict__ x, float *__restrict__ A,

@@ -705,6 +705,30 @@ int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W,
   return check_launch();
 }
 
+int wino4_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
+  if (B < 0 || H < 4 || W < 4 || H % 4 || W % 4 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !V) return GQHIP_ERR_INVALID_ARG;
+  const long tiles = (long)(B * (H / 4) * (W / 4)), total = tiles * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(wino4_in_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, V,
+                     (int)H, (int)W, (int)(C / 4), tiles, total);
+  return check_launch();
+}
+
+int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
+  if (B < 0 || H < 4 || W < 4 || H % 4 || W % 4 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!M || !y) return GQHIP_ERR_INVALID_ARG;
+  const long tiles = (long)(B * (H / 4) * (W / 4)), total = tiles * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(wino4_out_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), M, y,
+                     (int)H, (int)W, (int)(C / 4), tiles, total);
+  return check_launch();
+}
+
 int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
   if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "add_bias_stats_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "gn_apply_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp]),
     "wino_in_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "wino4_in_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "wino4_out_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
@@ -396,19 +398,26 @@ def wino_conv3x3(x, U, gn=None):
         raise GqHipError("wino_conv3x3 needs a dense channels_last fp32 HIP tensor, C % 4 == 0, even H and W")
     B, C, H, W = x.shape
     cout = U.shape[2]
-    tiles = B * (H // 2) * (W // 2)
-    V = torch.empty((16, tiles, C), dtype=x.dtype, device=x.device)
+    f4 = U.shape[0] == 36                                     # F(4x4,3x3): 6x6 tiles, 36 GEMMs
+    if f4 and (H % 4 or W % 4 or gn is not None):
+        raise GqHipError("F(4x4,3x3) needs H, W multiples of 4 (and has no fused-GroupNorm input transform)")
+    t = 4 if f4 else 2
+    tiles = B * (H // t) * (W // t)
+    V = torch.empty((U.shape[0], tiles, C), dtype=x.dtype, device=x.device)
+    L = lib()
     with torch.cuda.device(x.device):
-        if gn is None:
-            _check(lib().wino_in_nhwc_f32(x.data_ptr(), V.data_ptr(), B, H, W, C, _stream()), "wino_in_nhwc_f32")
-        else:
+        if gn is not None:
             gamma, beta, groups, eps, silu, stats, pre_bias = gn
-            _check(lib().wino_in_gn_nhwc_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias),
-                                             stats.data_ptr(), V.data_ptr(), B, H, W, C, groups, float(eps),
-                                             1 if silu else 0, _stream()), "wino_in_gn_nhwc_f32")
-        M = torch.bmm(V, U)                                   # 16 GEMMs [tiles, Cin] x [Cin, Cout] (hipBLASLt)
+            _check(L.wino_in_gn_nhwc_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias),
+                                         stats.data_ptr(), V.data_ptr(), B, H, W, C, groups, float(eps),
+                                         1 if silu else 0, _stream()), "wino_in_gn_nhwc_f32")
+        else:
+            _check((L.wino4_in_nhwc_f32 if f4 else L.wino_in_nhwc_f32)(x.data_ptr(), V.data_ptr(), B, H, W, C, _stream()),
+                   "wino_in_nhwc_f32")
+        M = torch.bmm(V, U)                                   # 16 / 36 GEMMs [tiles, Cin] x [Cin, Cout] (hipBLASLt)
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        _check(lib().wino_out_nhwc_f32(M.data_ptr(), y.data_ptr(), B, H, W, cout, _stream()), "wino_out_nhwc_f32")
+        _check((L.wino4_out_nhwc_f32 if f4 else L.wino_out_nhwc_f32)(M.data_ptr(), y.data_ptr(), B, H, W, cout, _stream()),
+               "wino_out_nhwc_f32")
     return y
 
 

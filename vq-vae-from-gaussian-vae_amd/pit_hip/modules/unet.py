@@ -76,7 +76,8 @@ def _conv(conv: nn.Conv2d, x: torch.Tensor):
         if _wino_ok(conv, x):
             from .. import _lib
 
-            return _lib.wino_conv3x3(x, _wino_weights(conv)), conv.bias
+            f4 = WINOGRAD_F4 and getattr(conv, "_gq_wino4", False) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0
+            return _lib.wino_conv3x3(x, _wino_weights(conv, f4)), conv.bias
         return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
     return conv(x), None
 
@@ -104,24 +105,32 @@ def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bia
     return _conv(conv, _norm_act(norm, x, pre_bias=pre_bias))
 
 
-def _wino_weights(conv: nn.Conv2d) -> torch.Tensor:
-    """U [16, Cin, Cout] = G g G^T of a 3x3 kernel (Winograd F(2x2, 3x3)), cached until the weight changes."""
+_WINO_G2 = [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]]
+_WINO_G4 = [[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+            [1 / 24, -1 / 12, 1 / 6], [0.0, 0.0, 1.0]]
+
+
+def _wino_weights(conv: nn.Conv2d, f4: bool = False) -> torch.Tensor:
+    """U = G g G^T of a 3x3 kernel, [16, Cin, Cout] for F(2x2,3x3) or [36, Cin, Cout] for F(4x4,3x3) (formed in
+    fp64, rounded once); cached until the weight changes."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.device)
+    key = (w.data_ptr(), w._version, w.device, f4)
     if getattr(conv, "_wino_key", None) != key:
-        G = w.new_tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
-        u = torch.einsum("ik,ockl,jl->ijco", G, w, G)          # [4, 4, Cin, Cout]
-        conv._wino_u = u.reshape(16, w.shape[1], w.shape[0]).contiguous()
+        G = torch.tensor(_WINO_G4 if f4 else _WINO_G2, dtype=torch.float64, device=w.device)
+        u = torch.einsum("ik,ockl,jl->ijco", G, w.double(), G).float()
+        conv._wino_u = u.reshape(-1, w.shape[1], w.shape[0]).contiguous()
         conv._wino_key = key
     return conv._wino_u
 
 
-def mark_winograd(module: nn.Module) -> None:
-    """Flag the stride-1, padding-1 3x3 convolutions of ``module`` for the Winograd path (see ``_conv``)."""
+def mark_winograd(module: nn.Module, f4: bool = False) -> None:
+    """Flag the stride-1, padding-1 3x3 convolutions of ``module`` for the Winograd path (see ``_conv``);
+    ``f4``: F(4x4,3x3) where the spatial size allows it (decoder only: larger rounding error)."""
     for m in module.modules():
         if (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
                 and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros"):
             m._gq_wino = True
+            m._gq_wino4 = f4
 
 
 def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
@@ -146,6 +155,7 @@ def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
 FUSED_GN = True    # module-level switches (tests / A-B timing)
 WINOGRAD = True          # decoder 3x3 convs with >= WINOGRAD_MIN_CH channels: Winograd F(2x2,3x3) + 16 hipBLASLt GEMMs
 WINOGRAD_MIN_CH = 128
+WINOGRAD_F4 = True       # decoder: F(4x4,3x3) (36 GEMMs on 6x6 tiles) instead of F(2x2,3x3)
 FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the Winograd input transform: correct, but no faster (every input
                          # pixel is activated by the four tiles that overlap it, the kernel stops being HBM-bound): off
 # also in the encoder: measured perturbation of z 4.2e-6 vs the CPU reference (direct MIOpen convs: 3.4e-6), no index
@@ -377,7 +387,7 @@ class Encoder(nn.Module):
         self.norm_out = _gn(top)
         self.conv_out = _conv3(top, 2 * z_channels if double_z else z_channels, padding_mode)
         if WINOGRAD_ENCODER:
-            mark_winograd(self)
+            mark_winograd(self)   # F(2x2,3x3) only: the encoder's rounding decides indices
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h, pb = _conv(self.conv_in, x)
@@ -423,7 +433,7 @@ class Decoder(nn.Module):
         self.up = nn.ModuleList(reversed(levels))  # index = resolution level, like the reference
         self.norm_out = _gn(cin)
         self.conv_out = _conv3(cin, out_ch, padding_mode)
-        mark_winograd(self)
+        mark_winograd(self, f4=True)
 
     def get_last_layer(self, **kwargs) -> torch.Tensor:
         return self.conv_out.weight
