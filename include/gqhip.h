@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GQHIP_ABI_VERSION 2   /* 2: gqhip_set_filter / gqhip_get_filter / gqhip_debug_plan, upsample2x_nhwc_f32 */
+#define GQHIP_ABI_VERSION 3   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats */
 
 typedef enum gqhip_status {
   GQHIP_OK = 0,

@@ -17,8 +17,10 @@ g = torch.Generator().manual_seed(5)
 x16 = (torch.rand(16, 3, 256, 256, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
 res = {}
 with torch.no_grad():
-    for name in ("direct", "winograd"):
-        unet.WINOGRAD = name == "winograd"
+    for name in ("direct", "winograd", "winograd F(4,3)"):
+        unet.WINOGRAD = name != "direct"
+        if name == "winograd F(4,3)":
+            unet.mark_winograd(vae.encoder, f4=True)
         z1 = vae.encoder(x1)
         _, i1 = vae.quant(x1)
         z16 = vae.encoder(x16)
@@ -30,7 +32,9 @@ for name in res:
     z1, i1 = res[name][0], res[name][1]
     print(f"{name:9s}: max|z - z_cpu| = {float((z1 - zc).abs().max()):.3e}; index mismatches vs CPU golden: "
           f"{int((i1.numpy() != d['indices']).sum())} / {i1.numel()}")
-zd, zw = res["direct"][2], res["winograd"][2]
-flips = (res["direct"][3] != res["winograd"][3])
-print(f"bs16: max|z_wino - z_direct| = {float((zw - zd).abs().max()):.3e} (mean |z| {float(zd.abs().mean()):.3f}); "
-      f"index flips winograd vs direct: {int(flips.sum())} / {flips.numel()}")
+zd = res["direct"][2]
+for name in ("winograd", "winograd F(4,3)"):
+    zw = res[name][2]
+    flips = (res["direct"][3] != res[name][3])
+    print(f"bs16 {name}: max|z - z_direct| = {float((zw - zd).abs().max()):.3e} (mean |z| {float(zd.abs().mean()):.3f}); "
+          f"index flips vs direct: {int(flips.sum())} / {flips.numel()}")

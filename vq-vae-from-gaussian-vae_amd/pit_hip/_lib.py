@@ -101,7 +101,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.gqhip_abi_version() != 2:
+        if L.gqhip_abi_version() != 3:
             raise GqHipError("libgqhip.so ABI version mismatch")
         _lib = L
     return _lib
