@@ -653,3 +653,44 @@ def test_winograd_with_fused_groupnorm_matches_unfused():
             fused = _lib.wino_conv3x3(x, Uw, gn=(norm.weight, norm.bias, 32, 1e-6, True, stats, pre))
             plain = _lib.wino_conv3x3(_lib.gn_silu(x, norm.weight, norm.bias, 32, 1e-6, silu=True, pre_bias=pre), Uw)
             assert torch.allclose(fused, plain, atol=1e-5, rtol=1e-5), float((fused - plain).abs().max())
+
+
+def test_winograd_fused_tail_matches_unfused():
+    """Output transform + bias + residual + GroupNorm statistics in one pass == plain transform, add_bias_stats."""
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(6)
+    for cin, cout, H, W in ((256, 128, 16, 24), (128, 512, 8, 12)):
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+        x = torch.randn(3, cin, H, W).to(DEV).contiguous(memory_format=torch.channels_last)
+        res = torch.randn(3, cout, H, W).to(DEV).contiguous(memory_format=torch.channels_last)
+        bias = torch.randn(cout).to(DEV)
+        with torch.no_grad():
+            for f4 in (False, True):
+                Uw = U._wino_weights(conv, f4)
+                y, stats = _lib.wino_conv3x3(x, Uw, residual=res, bias=bias, stats_groups=32)
+                y0, stats0 = _lib.add_bias_stats(res, _lib.wino_conv3x3(x, Uw), bias, 32)
+                assert torch.allclose(y, y0, atol=1e-5, rtol=1e-5), float((y - y0).abs().max())
+                assert torch.allclose(stats, stats0, rtol=1e-6, atol=1e-4)
+
+
+def test_unet_with_and_without_fused_winograd_tail_agree():
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(0)
+    cfg = dict(ch=128, out_ch=3, in_channels=3, resolution=64, z_channels=16, double_z=True, ch_mult=[1, 2, 4, 4],
+               num_res_blocks=2, attn_resolutions=[8], dropout=0.0)
+    enc = U.Encoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
+    dec = U.Decoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
+    x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    outs = []
+    with torch.no_grad():
+        for flag in (True, False):
+            U.FUSED_WINO_TAIL = flag
+            z = enc(x)
+            outs.append((z, dec(z[:, :16])))
+    U.FUSED_WINO_TAIL = True
+    dz = float((outs[0][0] - outs[1][0]).abs().max())
+    dx = float((outs[0][1] - outs[1][1]).abs().max())
+    assert dz <= 1e-4 and dx <= 1e-3, (dz, dx)

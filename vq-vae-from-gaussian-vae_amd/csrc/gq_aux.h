@@ -616,6 +616,75 @@ __global__ __launch_bounds__(256) void wino4_out_nhwc_kernel(const float *__rest
   }
 }
 
+// Output transform with the ResnetBlock's tail fused in (unet.py:149-153): y = A^T M A + bias[c] + res, and the GroupNorm
+// statistics of y for the block that follows (as add_bias_stats_nhwc_kernel).  A block owns a range of tiles of ONE
+// image; thread -> channel quad q = tid % C4 (one GroupNorm group), tile lane = tid / C4.  T = 2: F(2x2,3x3), 4: F(4x4,3x3).
+template <int T>
+__global__ __launch_bounds__(256) void wino_out_res_nhwc_kernel(const float *__restrict__ M, const float *__restrict__ res,
+                                                                const float *__restrict__ bias, float *__restrict__ y,
+                                                                double *__restrict__ stats, int H, int W, int C4,
+                                                                int cpg, long tiles, int slabs) {
+  constexpr int NI = T + 2;   // transform size (4 or 6)
+  __shared__ double red[2 * 64];
+  const int groups = 4 * C4 / cpg, lanes = 256 / C4;
+  const long b = blockIdx.x / slabs;
+  const int slab = blockIdx.x % slabs;
+  const long tpi = (long)(H / T) * (W / T);           // tiles per image
+  const long per = (tpi + slabs - 1) / slabs;
+  const long lo = slab * per, hi = lo + per < tpi ? lo + per : tpi;
+  const int q = threadIdx.x % C4, tl = threadIdx.x / C4;
+  if (threadIdx.x < 2 * groups) red[threadIdx.x] = 0.0;
+  __syncthreads();
+  f32x4 pb = {0.f, 0.f, 0.f, 0.f};
+  if (bias) pb = reinterpret_cast<const f32x4 *>(bias)[q];
+  const long plane = tiles * C4;
+  float s = 0.f, ss = 0.f;
+  for (long ti = lo + tl; ti < hi; ti += lanes) {
+    const int tw = (int)(ti % (W / T)), th = (int)(ti / (W / T));
+    const f32x4 *mi = reinterpret_cast<const f32x4 *>(M) + (b * tpi + ti) * C4 + q;
+    f32x4 u[T][NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if constexpr (T == 4) {
+        f32x4 col[6], o[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = mi[(6 * i + j) * plane];
+        wino4_at(col, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i][j] = o[i];
+      } else {
+        const f32x4 m0 = mi[(0 + j) * plane], m1 = mi[(4 + j) * plane], m2 = mi[(8 + j) * plane], m3 = mi[(12 + j) * plane];
+        u[0][j] = m0 + m1 + m2;
+        u[1][j] = m1 - m2 - m3;
+      }
+    }
+    const long pix0 = ((b * H + (long)T * th) * W + (long)T * tw) * C4 + q;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      f32x4 o[T];
+      if constexpr (T == 4) {
+        wino4_at(u[i], o);
+      } else {
+        o[0] = u[i][0] + u[i][1] + u[i][2];
+        o[1] = u[i][1] - u[i][2] - u[i][3];
+      }
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        const long off = pix0 + ((long)i * W + j) * C4;
+        const f32x4 v = o[j] + pb + reinterpret_cast<const f32x4 *>(res)[off];
+        reinterpret_cast<f32x4 *>(y)[off] = v;
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+  }
+  const int g = (4 * q) / cpg;
+  atomicAdd(&red[2 * g], (double)s);
+  atomicAdd(&red[2 * g + 1], (double)ss);
+  __syncthreads();
+  if (threadIdx.x < 2 * groups) atomicAdd(&stats[2 * (b * groups) + threadIdx.x], red[threadIdx.x]);
+}
+
 // im2col of the 2x2 phase convolution (padding 1) of an NHWC tensor: A[b][p][q][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c]
 // (zero outside), p in [0, H], q in [0, W].  One thread per (patch position, tap, channel quad).
 __global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__restrict__ x, float *__restrict__ A,

@@ -729,6 +729,32 @@ int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W
   return check_launch();
 }
 
+int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or_null, float *y, double *stats_out,
+                          int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups, int tile, void *stream) {
+  if ((tile != 2 && tile != 4) || B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 ||
+      groups < 1 || C % groups != 0)
+    return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!M || !res || !y || !stats_out) return GQHIP_ERR_INVALID_ARG;
+  const int64_t cpg = C / groups;
+  if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(stats_out, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) return check_launch();
+  const long tpi = (long)((H / tile) * (W / tile)), tiles = (long)B * tpi;
+  const int lanes = (int)(256 / (C / 4));
+  long slabs = (tpi + (long)lanes * 4 - 1) / ((long)lanes * 4);    // ~4 tiles per thread
+  if (slabs > 1024) slabs = 1024;
+  if (slabs < 1) slabs = 1;
+  const dim3 grid((unsigned)(B * slabs));
+  if (tile == 4)
+    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<4>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
+                       (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs);
+  else
+    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<2>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
+                       (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs);
+  return check_launch();
+}
+
 int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
   if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;

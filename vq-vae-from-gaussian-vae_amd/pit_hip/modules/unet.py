@@ -155,6 +155,7 @@ def _add(a: torch.Tensor, b: torch.Tensor, bias=None) -> torch.Tensor:
 FUSED_GN = True    # module-level switches (tests / A-B timing)
 WINOGRAD = True          # decoder 3x3 convs with >= WINOGRAD_MIN_CH channels: Winograd F(2x2,3x3) + 16 hipBLASLt GEMMs
 WINOGRAD_MIN_CH = 128
+FUSED_WINO_TAIL = True   # Winograd output transform + bias + residual add + next GroupNorm's statistics in one pass
 WINOGRAD_F4 = True       # decoder: F(4x4,3x3) (36 GEMMs on 6x6 tiles) instead of F(2x2,3x3)
 FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the Winograd input transform: correct, but no faster (every input
                          # pixel is activated by the four tiles that overlap it, the kernel stops being HBM-bound): off
@@ -198,10 +199,6 @@ class ResnetBlock(nn.Module):
     def forward(self, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
         """``pre_bias``: bias of the conv that produced ``x``, not yet added (deferred path)."""
         h, b1 = _norm_act_conv(self.norm1, self.conv1, x, pre_bias)
-        if self.dropout.p > 0.0 and self.training:
-            h, bias = _conv(self.conv2, self.dropout(_norm_act(self.norm2, h, pre_bias=b1)))
-        else:   # dropout is the identity (unet.py:148 with p = 0 / eval)
-            h, bias = _norm_act_conv(self.norm2, self.conv2, h, b1)
         if self.in_channels != self.out_channels:
             # nin(x + pb) = nin_nobias(x) + W.pb + nin.bias : every constant goes into the fused add
             xs, bs = _conv(self.nin_shortcut, x)
@@ -210,6 +207,25 @@ class ResnetBlock(nn.Module):
                 bs = wpb if bs is None else bs + wpb
         else:
             xs, bs = x, pre_bias
+        if self.dropout.p > 0.0 and self.training:
+            h, bias = _conv(self.conv2, self.dropout(_norm_act(self.norm2, h, pre_bias=b1)))
+        else:   # dropout is the identity (unet.py:148 with p = 0 / eval)
+            hn = _norm_act(self.norm2, h, pre_bias=b1)
+            if (FUSED_WINO_TAIL and _defer_ok(hn, self.conv2) and _wino_ok(self.conv2, hn) and xs.shape[1] == self.out_channels
+                    and xs.is_contiguous(memory_format=torch.channels_last) and not xs.is_contiguous()):
+                from .. import _lib
+
+                if _lib.gn_nhwc_ok(self.out_channels, GN_GROUPS):
+                    # conv2, its bias, the shortcut's constants, the residual add and the next GroupNorm's statistics
+                    # in one output-transform pass
+                    bias = self.conv2.bias if bs is None else self.conv2.bias + bs
+                    f4 = (WINOGRAD_F4 and getattr(self.conv2, "_gq_wino4", False) and hn.shape[2] % 4 == 0
+                          and hn.shape[3] % 4 == 0)
+                    y, stats = _lib.wino_conv3x3(hn, _wino_weights(self.conv2, f4), residual=xs, bias=bias,
+                                                 stats_groups=GN_GROUPS)
+                    y._gn_stats = (stats, GN_GROUPS)
+                    return y
+            h, bias = _conv(self.conv2, hn)
         if bs is not None:
             bias = bs if bias is None else bias + bs
         return _add(xs, h, bias)
