@@ -199,7 +199,7 @@ int wino4_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W,
 int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
 
 /* Output transform (tile = 2: F(2x2,3x3), M [16, tiles, C]; tile = 4: F(4x4,3x3), M [36, tiles, C]) with the ResnetBlock's
- * tail fused in (pit/modules/unet.py:149-153): y = A^T M A + bias[c] + res, plus the GroupNorm statistics of y
+ * tail fused in (pit/modules/unet.py:149-153): y = A^T M A + bias[c] (+ res, may be NULL), plus the GroupNorm statistics of y
  * (stats_out as add_bias_stats_f32) for the block that follows.  Needs (C/groups) % 4 == 0, 256 % (C/4) == 0. */
 int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or_null, float *y, double *stats_out,
                           int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups, int tile, void *stream);

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void wino4_out_nhwc_kernel(const float *__rest
   }
 }
 
-// Output transform with the ResnetBlock's tail fused in (unet.py:149-153): y = A^T M A + bias[c] + res, and the GroupNorm
+// Output transform with the ResnetBlock's tail fused in (unet.py:149-153): y = A^T M A + bias[c] (+ res), and the GroupNorm
 // statistics of y for the block that follows (as add_bias_stats_nhwc_kernel).  A block owns a range of tiles of ONE
 // image; thread -> channel quad q = tid % C4 (one GroupNorm group), tile lane = tid / C4.  T = 2: F(2x2,3x3), 4: F(4x4,3x3).
 template <int T>
@@ -671,7 +671,8 @@ __global__ __launch_bounds__(256) void wino_out_res_nhwc_kernel(const float *__r
 #pragma unroll
       for (int j = 0; j < T; ++j) {
         const long off = pix0 + ((long)i * W + j) * C4;
-        const f32x4 v = o[j] + pb + reinterpret_cast<const f32x4 *>(res)[off];
+        f32x4 v = o[j] + pb;
+        if (res) v = v + reinterpret_cast<const f32x4 *>(res)[off];
         reinterpret_cast<f32x4 *>(y)[off] = v;
         s += (v.x + v.y) + (v.z + v.w);
         ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);

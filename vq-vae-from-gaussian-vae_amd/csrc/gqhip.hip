@@ -735,7 +735,7 @@ int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or
       groups < 1 || C % groups != 0)
     return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
-  if (!M || !res || !y || !stats_out) return GQHIP_ERR_INVALID_ARG;
+  if (!M || !y || !stats_out) return GQHIP_ERR_INVALID_ARG;   // res may be NULL: bias + statistics only
   const int64_t cpg = C / groups;
   if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -395,8 +395,8 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0)
     U [16, Cin, Cout] = G g G^T (see unet._wino_weights).  Returns [B, Cout, H, W] channels_last, no bias.
     ``gn`` = (gamma, beta, groups, eps, silu, stats, pre_bias): the convolution's input is SiLU(GroupNorm(x + pre_bias)),
     applied inside the input transform (the normalised tensor is never materialised).
-    ``residual`` (+ ``bias``, ``stats_groups``): the output transform also adds bias[c] + residual and returns
-    (y, GroupNorm statistics of y) -- the tail of a ResnetBlock in the same pass."""
+    ``stats_groups`` > 0: the output transform also adds bias[c] (+ ``residual``) and returns
+    (y, GroupNorm statistics of y) -- the tail of a ResnetBlock, or conv1 + the statistics norm2 needs, in one pass."""
     if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 4 or x.shape[2] % 2 or x.shape[3] % 2:
         raise GqHipError("wino_conv3x3 needs a dense channels_last fp32 HIP tensor, C % 4 == 0, even H and W")
     B, C, H, W = x.shape
@@ -419,11 +419,12 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0)
                    "wino_in_nhwc_f32")
         M = torch.bmm(V, U)                                   # 16 / 36 GEMMs [tiles, Cin] x [Cin, Cout] (hipBLASLt)
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        if residual is not None:
-            if image_layout(residual) != 1 or tuple(residual.shape) != tuple(y.shape) or not gn_nhwc_ok(cout, stats_groups):
+        if stats_groups:
+            if (residual is not None and (image_layout(residual) != 1 or tuple(residual.shape) != tuple(y.shape))) \
+                    or not gn_nhwc_ok(cout, stats_groups):
                 raise GqHipError("fused Winograd tail needs a channels_last residual of the output shape and a GroupNorm-compatible C")
             stats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device)
-            _check(L.wino_out_res_nhwc_f32(M.data_ptr(), residual.data_ptr(), _ptr(bias), y.data_ptr(), stats.data_ptr(),
+            _check(L.wino_out_res_nhwc_f32(M.data_ptr(), _ptr(residual), _ptr(bias), y.data_ptr(), stats.data_ptr(),
                                            B, H, W, cout, stats_groups, t, _stream()), "wino_out_res_nhwc_f32")
             return y, stats
         _check((L.wino4_out_nhwc_f32 if f4 else L.wino_out_nhwc_f32)(M.data_ptr(), y.data_ptr(), B, H, W, cout, _stream()),

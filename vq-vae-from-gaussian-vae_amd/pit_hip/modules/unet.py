@@ -68,15 +68,21 @@ def _defer_ok(x: torch.Tensor, conv: nn.Conv2d) -> bool:
             and conv.bias is not None and conv.padding_mode == "zeros")
 
 
-def _conv(conv: nn.Conv2d, x: torch.Tensor):
+def _conv(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
     """Run ``conv`` and return (y, pending_bias).  ATen's MIOpen path adds the bias in a separate
     elementwise pass over the whole output; on the deferred path the conv runs bias-free and the
-    bias is handed to the consumer (the next fused GroupNorm or residual add), which folds it in."""
+    bias is handed to the consumer (the next fused GroupNorm or residual add), which folds it in.
+    ``want_stats``: the consumer is a GroupNorm(32) -- on the Winograd path its statistics come with the output."""
     if _defer_ok(x, conv):
         if _wino_ok(conv, x):
             from .. import _lib
 
             f4 = WINOGRAD_F4 and getattr(conv, "_gq_wino4", False) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0
+            if want_stats and FUSED_WINO_TAIL and _lib.gn_nhwc_ok(conv.out_channels, GN_GROUPS):
+                # the consumer is a GroupNorm: add the bias here and leave the statistics with the output
+                y, stats = _lib.wino_conv3x3(x, _wino_weights(conv, f4), bias=conv.bias, stats_groups=GN_GROUPS)
+                y._gn_stats = (stats, GN_GROUPS)
+                return y, None
             return _lib.wino_conv3x3(x, _wino_weights(conv, f4)), conv.bias
         return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
     return conv(x), None
@@ -88,7 +94,7 @@ def _wino_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
             and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
 
 
-def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None):
+def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None, want_stats: bool = False):
     """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  On the Winograd path the GroupNorm(+SiLU) is applied
     inside the input transform, so the normalised tensor is never written."""
     if FUSED_WINO_GN and _defer_ok(x, conv) and _wino_ok(conv, x) and _use_fused(x, norm):
@@ -102,7 +108,7 @@ def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bia
                 stats = _lib.gn_stats(x, norm.num_groups, pre_bias)
             gn = (norm.weight, norm.bias, norm.num_groups, norm.eps, True, stats, pre_bias)
             return _lib.wino_conv3x3(x, _wino_weights(conv), gn=gn), conv.bias
-    return _conv(conv, _norm_act(norm, x, pre_bias=pre_bias))
+    return _conv(conv, _norm_act(norm, x, pre_bias=pre_bias), want_stats)
 
 
 _WINO_G2 = [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]]
@@ -198,7 +204,7 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
         """``pre_bias``: bias of the conv that produced ``x``, not yet added (deferred path)."""
-        h, b1 = _norm_act_conv(self.norm1, self.conv1, x, pre_bias)
+        h, b1 = _norm_act_conv(self.norm1, self.conv1, x, pre_bias, want_stats=True)   # norm2 follows
         if self.in_channels != self.out_channels:
             # nin(x + pb) = nin_nobias(x) + W.pb + nin.bias : every constant goes into the fused add
             xs, bs = _conv(self.nin_shortcut, x)
