@@ -14,7 +14,8 @@ d = np.load(os.path.join(ROOT, "tests", "golden", "g7_full_e2e.npz"))
 gx = torch.Generator().manual_seed(1000)
 x1 = (torch.rand(1, 3, 256, 256, generator=gx) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
 g = torch.Generator().manual_seed(5)
-x16 = (torch.rand(16, 3, 256, 256, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
+NB = int(os.environ.get("GQ_CHECK_BATCHES", "8"))   # bs-16 batches for the flip statistics
+xs = [(torch.rand(16, 3, 256, 256, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last) for _ in range(NB)]
 res = {}
 with torch.no_grad():
     for name in ("direct", "winograd", "winograd F(4,3)"):
@@ -23,9 +24,9 @@ with torch.no_grad():
             unet.mark_winograd(vae.encoder, f4=True)
         z1 = vae.encoder(x1)
         _, i1 = vae.quant(x1)
-        z16 = vae.encoder(x16)
-        _, i16 = vae.quant(x16)
-        res[name] = (z1.cpu(), i1.cpu(), z16.cpu(), i16.cpu())
+        z16 = torch.cat([vae.encoder(xb).cpu() for xb in xs])
+        i16 = torch.cat([vae.quant(xb)[1].cpu() for xb in xs])
+        res[name] = (z1.cpu(), i1.cpu(), z16, i16)
 unet.WINOGRAD = True
 zc = torch.from_numpy(d["z_enc"])
 for name in res:
@@ -36,5 +37,5 @@ zd = res["direct"][2]
 for name in ("winograd", "winograd F(4,3)"):
     zw = res[name][2]
     flips = (res["direct"][3] != res[name][3])
-    print(f"bs16 {name}: max|z - z_direct| = {float((zw - zd).abs().max()):.3e} (mean |z| {float(zd.abs().mean()):.3f}); "
+    print(f"{NB} x bs16 {name}: max|z - z_direct| = {float((zw - zd).abs().max()):.3e} (mean |z| {float(zd.abs().mean()):.3f}); "
           f"index flips vs direct: {int(flips.sum())} / {flips.numel()}")
