@@ -88,6 +88,15 @@ def _conv(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
     return conv(x), None
 
 
+def _match_layout(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    """A module converted with ``.to(memory_format=torch.channels_last)`` gets its input in NHWC too (the fast conv
+    stack -- Winograd, sub-pixel upsample, NHWC GroupNorm kernels -- is the channels_last one)."""
+    if (x.is_cuda and x.dim() == 4 and conv.weight.is_contiguous(memory_format=torch.channels_last)
+            and not conv.weight.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last)):
+        return x.contiguous(memory_format=torch.channels_last)
+    return x
+
+
 def _wino_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
     return (WINOGRAD and getattr(conv, "_gq_wino", False) and conv.in_channels >= WINOGRAD_MIN_CH
             and conv.out_channels >= WINOGRAD_MIN_CH and conv.out_channels % 4 == 0 and x.shape[2] % 2 == 0
@@ -412,6 +421,7 @@ class Encoder(nn.Module):
             mark_winograd(self)   # F(2x2,3x3) only: the encoder's rounding decides indices
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = _match_layout(x, self.conv_in)
         h, pb = _conv(self.conv_in, x)
         for lvl, level in enumerate(self.down):
             h, pb = level.run(h, pb), None
@@ -462,6 +472,7 @@ class Decoder(nn.Module):
 
     def forward(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
         self.last_z_shape = z.shape
+        z = _match_layout(z, self.conv_in)
         h, pb = _conv(self.conv_in, z)
         h, pb = self.mid(h, pb), None
         for lvl in reversed(range(self.num_resolutions)):
