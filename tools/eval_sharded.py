@@ -38,6 +38,8 @@ def main():
     if a.ckpt:
         model.load_state_dict(torch.load(a.ckpt, map_location="cpu")["state_dict"], strict=False)
     model = model.eval().to(device)
+    if device.type == "cuda":
+        model = model.to(memory_format=torch.channels_last)   # NHWC: the fast conv stack (inputs are converted by the modules)
     if getattr(model.regularization, "backend", None) == "cuda":
         model.regularization.backend = "hip"
     if a.dataset:
