@@ -699,3 +699,18 @@ def test_unet_with_and_without_fused_winograd_tail_agree():
     dz = float((outs[0][0] - outs[1][0]).abs().max())
     dx = float((outs[0][1] - outs[1][1]).abs().max())
     assert dz <= 1e-4 and dx <= 1e-3, (dz, dx)
+
+
+def test_attention_fused_qkv_matches_three_convs():
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(3)
+    blk = U.AttnBlock(128).eval().to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 128, 8, 8).to(DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        U.FUSED_QKV = True
+        y1 = blk(x)
+        U.FUSED_QKV = False
+        y0 = blk(x)
+        U.FUSED_QKV = True
+    assert torch.allclose(y1, y0, atol=2e-5, rtol=1e-5), float((y1 - y0).abs().max())

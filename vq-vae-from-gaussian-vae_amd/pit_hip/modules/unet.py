@@ -178,6 +178,7 @@ FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the Winograd input tran
 # change on the CPU golden nor on 16 384 rows against the direct-conv encoder (tools/encoder_winograd_check.py)
 WINOGRAD_ENCODER = True
 SUBPIXEL_UPCONV = True   # Upsample: nearest x2 + conv3x3 as four 2x2 phase convs of the low-res input (2.25x fewer flops)
+FUSED_QKV = True         # attention: q, k, v as one GEMM with fused biases (channels_last)
 FUSED_ADD_STATS = True   # residual add also produces the next GroupNorm's statistics (channels_last only)
 GN_GROUPS = 32     # unet.py:54-57: every Normalize is GroupNorm(32, C, eps=1e-6)
 DEFER_BIAS = True
@@ -257,13 +258,31 @@ class AttnBlock(nn.Module):
         self.v = nn.Conv2d(ch, ch, 1)
         self.proj_out = nn.Conv2d(ch, ch, 1)
 
+    def _qkv_weights(self):
+        """([c, 3c] GEMM matrix, [3c] bias) of the q / k / v 1x1 convolutions; cached until a weight changes."""
+        ps = (self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_qkv_key", None) != key:
+            c = self.q.weight.shape[0]
+            self._qkv_w = torch.cat([p.reshape(c, c) for p in ps[:3]], 0).t().contiguous()
+            self._qkv_b = torch.cat(ps[3:], 0).contiguous()
+            self._qkv_key = key
+        return self._qkv_w, self._qkv_b
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b, c, h, w = x.shape
         y = _norm_act(self.norm, x, act=False)
         # [b, c, h, w] -> [b, 1, hw, c]
         if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
             # channels_last: [b, hw, c] is a free view of the conv output and of the result
-            q, k, v = (f(y).permute(0, 2, 3, 1).reshape(b, 1, h * w, c) for f in (self.q, self.k, self.v))
+            if FUSED_QKV and y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled():
+                # q, k, v = three 1x1 convolutions of the same tensor = ONE GEMM [b*hw, c] x [c, 3c] with the biases in
+                # its epilogue (instead of 3 MIOpen launches + 3 bias-add passes); the thirds are strided views
+                wqkv, bqkv = self._qkv_weights()
+                qkv = torch.addmm(bqkv, y.permute(0, 2, 3, 1).reshape(b * h * w, c), wqkv).view(b, 1, h * w, 3 * c)
+                q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+            else:
+                q, k, v = (f(y).permute(0, 2, 3, 1).reshape(b, 1, h * w, c) for f in (self.q, self.k, self.v))
             a = _sdpa(q, k, v)
             a = a.reshape(b, h, w, c).permute(0, 3, 1, 2)
         else:
