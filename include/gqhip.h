@@ -215,6 +215,10 @@ int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64
 int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                         const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C,
                         int64_t groups, double eps, int apply_silu, void *stream);
+/* the same for F(4x4,3x3) (V [36, tiles, C], H and W multiples of 4) */
+int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                         const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C,
+                         int64_t groups, double eps, int apply_silu, void *stream);
 
 /* Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (pit/modules/unet.py:69-73): src [B, H+1, W+1, 4*C] is the
  * padding-1 2x2 convolution of the LOW-resolution input with the four phase kernels stacked along the output channels

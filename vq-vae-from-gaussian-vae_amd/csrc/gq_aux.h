@@ -584,6 +584,73 @@ __global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restr
   }
 }
 
+// wino4_in_nhwc_kernel with the producer fused in (see wino_in_gn_nhwc_kernel): every pixel is activated by the 2.25 tiles
+// that overlap it (4 with F(2x2,3x3), where the fusion brought nothing).
+template <int SILU>
+__global__ __launch_bounds__(256) void wino4_in_gn_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta,
+                                                               const float *__restrict__ pre_bias,
+                                                               const double *__restrict__ stats, float *__restrict__ V,
+                                                               int H, int W, int C4, int cpg, double eps, long tiles,
+                                                               long total) {
+  const int groups = 4 * C4 / cpg;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q = (int)(t % C4);
+    const long tile = t / C4;
+    const int tw = (int)(tile % (W / 4));
+    const long r = tile / (W / 4);
+    const int th = (int)(r % (H / 4));
+    const long b = r / (H / 4);
+    const int g = (4 * q) / cpg;
+    const double n = (double)cpg * (double)H * (double)W;
+    const double mean = stats[2 * (b * groups + g)] / n;
+    double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    f32x4 a, sh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = 4 * q + k;
+      const double pbk = pre_bias ? (double)pre_bias[c] : 0.0;
+      a[k] = (float)(rstd * (double)gamma[c]);
+      sh[k] = (float)((double)beta[c] + (pbk - mean) * rstd * (double)gamma[c]);
+    }
+    f32x4 w[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x4 col[6], o[6];
+      const int sx = 4 * tw - 1 + j;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int sy = 4 * th - 1 + i;
+        col[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+          f32x4 v = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q] * a + sh;
+          if (SILU) {
+            v.x = v.x * __builtin_amdgcn_rcpf(1.0f + __expf(-v.x));
+            v.y = v.y * __builtin_amdgcn_rcpf(1.0f + __expf(-v.y));
+            v.z = v.z * __builtin_amdgcn_rcpf(1.0f + __expf(-v.z));
+            v.w = v.w * __builtin_amdgcn_rcpf(1.0f + __expf(-v.w));
+          }
+          col[i] = v;
+        }
+      }
+      wino4_bt(col, o);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+    f32x4 *out = reinterpret_cast<f32x4 *>(V) + tile * C4 + q;
+    const long plane = tiles * C4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      f32x4 o[6];
+      wino4_bt(w[i], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) out[(6 * i + j) * plane] = o[j];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wino4_out_nhwc_kernel(const float *__restrict__ M, float *__restrict__ y, int H, int W,
                                                              int C4, long tiles, long total) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {

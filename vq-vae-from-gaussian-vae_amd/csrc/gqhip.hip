@@ -672,18 +672,27 @@ int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64
   return check_launch();
 }
 
-int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+static int wino_in_gn_nhwc_f32_impl(int tile, const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                         const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                         double eps, int apply_silu, void *stream) {
-  if (B < 0 || H < 2 || W < 2 || H % 2 || W % 2 || C < 4 || C % 4 != 0 || groups < 1 || C % groups != 0 ||
+  if (B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 || groups < 1 || C % groups != 0 ||
       (C / groups) % 4 != 0)
     return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!x || !gamma || !beta || !stats || !V) return GQHIP_ERR_INVALID_ARG;
-  const long tiles = (long)(B * (H / 2) * (W / 2)), total = tiles * (C / 4);
+  const long tiles = (long)(B * (H / tile) * (W / tile)), total = tiles * (C / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tile == 4) {
+    if (apply_silu)
+      hipLaunchKernelGGL((wino4_in_gn_nhwc_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
+                         pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
+    else
+      hipLaunchKernelGGL((wino4_in_gn_nhwc_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
+                         pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
+    return check_launch();
+  }
   if (apply_silu)
     hipLaunchKernelGGL((wino_in_gn_nhwc_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
                        pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
@@ -691,6 +700,18 @@ int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, c
     hipLaunchKernelGGL((wino_in_gn_nhwc_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
                        pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
   return check_launch();
+}
+
+int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                        const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                        double eps, int apply_silu, void *stream) {
+  return wino_in_gn_nhwc_f32_impl(2, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, stream);
+}
+
+int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                         const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                         double eps, int apply_silu, void *stream) {
+  return wino_in_gn_nhwc_f32_impl(4, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, stream);
 }
 
 int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
+    "wino4_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
+                                             ctypes.c_int, _vp]),
     "wino_out_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "upconv_im2col_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "upconv_shuffle_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
@@ -402,8 +404,8 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0)
     B, C, H, W = x.shape
     cout = U.shape[2]
     f4 = U.shape[0] == 36                                     # F(4x4,3x3): 6x6 tiles, 36 GEMMs
-    if f4 and (H % 4 or W % 4 or gn is not None):
-        raise GqHipError("F(4x4,3x3) needs H, W multiples of 4 (and has no fused-GroupNorm input transform)")
+    if f4 and (H % 4 or W % 4):
+        raise GqHipError("F(4x4,3x3) needs H, W multiples of 4")
     t = 4 if f4 else 2
     tiles = B * (H // t) * (W // t)
     V = torch.empty((U.shape[0], tiles, C), dtype=x.dtype, device=x.device)
@@ -411,9 +413,9 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0)
     with torch.cuda.device(x.device):
         if gn is not None:
             gamma, beta, groups, eps, silu, stats, pre_bias = gn
-            _check(L.wino_in_gn_nhwc_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias),
-                                         stats.data_ptr(), V.data_ptr(), B, H, W, C, groups, float(eps),
-                                         1 if silu else 0, _stream()), "wino_in_gn_nhwc_f32")
+            _check((L.wino4_in_gn_nhwc_f32 if f4 else L.wino_in_gn_nhwc_f32)(
+                x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(), V.data_ptr(), B, H, W, C,
+                groups, float(eps), 1 if silu else 0, _stream()), "wino_in_gn_nhwc_f32")
         else:
             _check((L.wino4_in_nhwc_f32 if f4 else L.wino_in_nhwc_f32)(x.data_ptr(), V.data_ptr(), B, H, W, C, _stream()),
                    "wino_in_nhwc_f32")

@@ -104,19 +104,27 @@ def _wino_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
 
 
 def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None, want_stats: bool = False):
-    """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  On the Winograd path the GroupNorm(+SiLU) is applied
-    inside the input transform, so the normalised tensor is never written."""
-    if FUSED_WINO_GN and _defer_ok(x, conv) and _wino_ok(conv, x) and _use_fused(x, norm):
+    """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  The GroupNorm(+SiLU) can be applied inside the Winograd
+    input transform so that the normalised tensor is never written (FUSED_WINO_GN / FUSED_WINO_GN_F4) -- measured:
+    no gain (every pixel is activated by the 4 / 2.25 tiles that overlap it and the transform stops being HBM-bound),
+    so both switches are off and the plain gn_silu -> transform sequence runs."""
+    if _defer_ok(x, conv) and _wino_ok(conv, x) and _use_fused(x, norm):
         from .. import _lib
 
-        if _lib.image_layout(x) == 1:
+        f4 = WINOGRAD_F4 and getattr(conv, "_gq_wino4", False) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0
+        if _lib.image_layout(x) == 1 and (FUSED_WINO_GN_F4 if f4 else FUSED_WINO_GN):
             st = getattr(x, "_gn_stats", None)
             if st is not None and pre_bias is None and st[1] == norm.num_groups:
                 stats = st[0]
             else:
                 stats = _lib.gn_stats(x, norm.num_groups, pre_bias)
             gn = (norm.weight, norm.bias, norm.num_groups, norm.eps, True, stats, pre_bias)
-            return _lib.wino_conv3x3(x, _wino_weights(conv), gn=gn), conv.bias
+            U = _wino_weights(conv, f4)
+            if want_stats and FUSED_WINO_TAIL and _lib.gn_nhwc_ok(conv.out_channels, GN_GROUPS):
+                y, ostats = _lib.wino_conv3x3(x, U, gn=gn, bias=conv.bias, stats_groups=GN_GROUPS)
+                y._gn_stats = (ostats, GN_GROUPS)
+                return y, None
+            return _lib.wino_conv3x3(x, U, gn=gn), conv.bias
     return _conv(conv, _norm_act(norm, x, pre_bias=pre_bias), want_stats)
 
 
@@ -172,8 +180,9 @@ WINOGRAD = True          # decoder 3x3 convs with >= WINOGRAD_MIN_CH channels: W
 WINOGRAD_MIN_CH = 128
 FUSED_WINO_TAIL = True   # Winograd output transform + bias + residual add + next GroupNorm's statistics in one pass
 WINOGRAD_F4 = True       # decoder: F(4x4,3x3) (36 GEMMs on 6x6 tiles) instead of F(2x2,3x3)
-FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the Winograd input transform: correct, but no faster (every input
+FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the F(2x2,3x3) input transform: correct, but no faster (every input
                          # pixel is activated by the four tiles that overlap it, the kernel stops being HBM-bound): off
+FUSED_WINO_GN_F4 = False # ... inside the F(4x4,3x3) input transform (2.25 tiles per pixel): also measured, 1 % slower: off
 # also in the encoder: measured perturbation of z 4.2e-6 vs the CPU reference (direct MIOpen convs: 3.4e-6), no index
 # change on the CPU golden nor on 16 384 rows against the direct-conv encoder (tools/encoder_winograd_check.py)
 WINOGRAD_ENCODER = True
@@ -226,22 +235,32 @@ class ResnetBlock(nn.Module):
         if self.dropout.p > 0.0 and self.training:
             h, bias = _conv(self.conv2, self.dropout(_norm_act(self.norm2, h, pre_bias=b1)))
         else:   # dropout is the identity (unet.py:148 with p = 0 / eval)
-            hn = _norm_act(self.norm2, h, pre_bias=b1)
-            if (FUSED_WINO_TAIL and _defer_ok(hn, self.conv2) and _wino_ok(self.conv2, hn) and xs.shape[1] == self.out_channels
-                    and xs.is_contiguous(memory_format=torch.channels_last) and not xs.is_contiguous()):
+            if (FUSED_WINO_TAIL and _defer_ok(h, self.conv2) and _wino_ok(self.conv2, h) and _use_fused(h, self.norm2)
+                    and xs.shape[1] == self.out_channels and xs.is_contiguous(memory_format=torch.channels_last)
+                    and not xs.is_contiguous()):
                 from .. import _lib
 
-                if _lib.gn_nhwc_ok(self.out_channels, GN_GROUPS):
+                if _lib.gn_nhwc_ok(self.out_channels, GN_GROUPS) and _lib.image_layout(h) == 1:
                     # conv2, its bias, the shortcut's constants, the residual add and the next GroupNorm's statistics
-                    # in one output-transform pass
+                    # in one output-transform pass (and, with F(4x4,3x3), norm2 + swish inside the input transform)
                     bias = self.conv2.bias if bs is None else self.conv2.bias + bs
-                    f4 = (WINOGRAD_F4 and getattr(self.conv2, "_gq_wino4", False) and hn.shape[2] % 4 == 0
-                          and hn.shape[3] % 4 == 0)
-                    y, stats = _lib.wino_conv3x3(hn, _wino_weights(self.conv2, f4), residual=xs, bias=bias,
-                                                 stats_groups=GN_GROUPS)
-                    y._gn_stats = (stats, GN_GROUPS)
+                    f4 = (WINOGRAD_F4 and getattr(self.conv2, "_gq_wino4", False) and h.shape[2] % 4 == 0
+                          and h.shape[3] % 4 == 0)
+                    if FUSED_WINO_GN_F4 if f4 else FUSED_WINO_GN:
+                        st = getattr(h, "_gn_stats", None)
+                        if st is not None and b1 is None and st[1] == self.norm2.num_groups:
+                            stats = st[0]
+                        else:
+                            stats = _lib.gn_stats(h, self.norm2.num_groups, b1)
+                        gn = (self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, stats, b1)
+                        src = h
+                    else:
+                        gn, src = None, _norm_act(self.norm2, h, pre_bias=b1)
+                    y, ostats = _lib.wino_conv3x3(src, _wino_weights(self.conv2, f4), gn=gn, residual=xs, bias=bias,
+                                                  stats_groups=GN_GROUPS)
+                    y._gn_stats = (ostats, GN_GROUPS)
                     return y
-            h, bias = _conv(self.conv2, hn)
+            h, bias = _conv(self.conv2, _norm_act(self.norm2, h, pre_bias=b1))
         if bs is not None:
             bias = bs if bias is None else bias + bs
         return _add(xs, h, bias)
