@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define GQHIP_ABI_VERSION 3   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats */
+#define GQHIP_ABI_VERSION 4   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
+                               * 4: four-launch fused arg-max (no caller-cached max|cb|; noise / zhat_noquant in gq_quantize_z_f32), profile_reserve */
 
 typedef enum gqhip_status {
   GQHIP_OK = 0,
@@ -72,14 +73,10 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8);
 /* ---- workspace ------------------------------------------------------------
  * Bytes of scratch gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32 need for
  * `rows` rows against `n` codes of width `dim`.  The caller allocates once
- * (device memory, 256-B aligned) and reuses it; contents are don't-care. */
+ * (device memory, 256-B aligned) and reuses it; contents are don't-care: every call
+ * rebuilds what it needs (codebook image, max|cb|, counters) from its arguments, so
+ * nothing derived from a codebook or from rows is ever reused across calls. */
 int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim);
-
-/* max |cb[j,i]| over the codebook -> *absmax_out (device float).  Callers cache
- * the value per codebook and pass it to the fused entry points (cb_absmax);
- * passing cb_absmax <= 0 makes them recompute it (one extra tiny kernel). */
-int gqhip_codebook_absmax(const float *cb, int64_t n, int64_t dim,
-                          float *absmax_out, void *stream);
 
 /* ---- compat op: the reference's native boundary ---------------------------
  * out[r, j] = sum_i -((cb[j,i]-mu[r,i])/sd[r,i])^2 + cb[j,i]^2 * beta
@@ -95,13 +92,14 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
  * zhat[r] = cb[idx[r]]  (optional, may be NULL).
  * logsd_or_null: log(sd) as the caller computed it; NULL -> the kernel uses
  *           float(log(double(sd))) (correctly rounded).
- * cb_absmax: cached max|cb| (see gqhip_codebook_absmax) or <= 0.
- * dim: any 1..64 (4, 8, 16, 32 run on the MFMA filter; others exhaustive). */
+ * dim: any 1..64 (4, 8, 16, 32 run on the MFMA filter; others exhaustive).
+ * Four launches on `stream` for the MFMA dims: prep (operand images, bound sums,
+ * max|cb|) -> filter -> exact re-rank -> tail (undecided rows; returns at once
+ * when there are none). */
 int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null,
                   const float *cb, int64_t *idx, float *zhat_or_null,
                   int64_t dim, int64_t rows, int64_t n, double beta,
-                  float cb_absmax, void *workspace, int64_t workspace_bytes,
-                  void *stream);
+                  void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- module-level fused quantiser -----------------------------------------
  * z is the encoder output holding [mu | logvar] along its channel axis.
@@ -113,18 +111,20 @@ int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null,
  * K = c / dim.  logvar is clamped to [lv_min, lv_max]; sd = exp(0.5*logvar) and
  * log(sd) are evaluated in fp64 and rounded once (numerics).
  * mu_out/sd_out (optional, [rows, dim], row = (b*L + l)*K + k) receive the
- * permuted operands so callers/tests can replay them through the oracle. */
+ * permuted operands so callers/tests can replay them through the oracle.
+ * noise_or_null / zhat_noquant_or_null (both in the layout of zhat): when given,
+ * zhat_noquant = mu + noise * sd (gaussian.py:121; the caller draws `noise` with
+ * its own generator, e.g. torch.randn) is written by the same first launch. */
 #define GQHIP_LAYOUT_BCHW 0
 #define GQHIP_LAYOUT_BLC 1
 #define GQHIP_GROUP_STRIDED 0
 #define GQHIP_GROUP_CONTIGUOUS 1
-int gq_quantize_z_f32(const float *z, const float *cb, int64_t *idx,
-                      float *zhat_or_null, float *mu_out_or_null,
-                      float *sd_out_or_null, int64_t B, int64_t L, int64_t c,
-                      int64_t dim, int64_t n, int layout, int grouping,
-                      double lv_min, double lv_max, double beta,
-                      float cb_absmax, void *workspace,
-                      int64_t workspace_bytes, void *stream);
+int gq_quantize_z_f32(const float *z, const float *noise_or_null, const float *cb,
+                      int64_t *idx, float *zhat_or_null, float *zhat_noquant_or_null,
+                      float *mu_out_or_null, float *sd_out_or_null, int64_t B,
+                      int64_t L, int64_t c, int64_t dim, int64_t n, int layout,
+                      int grouping, double lv_min, double lv_max, double beta,
+                      void *workspace, int64_t workspace_bytes, void *stream);
 
 /* zhat from indices (same layouts as above). */
 int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B,
@@ -134,8 +134,7 @@ int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B,
 /* ---- VQ: argmin_j |z_r - e_j|^2 (fp64 arbiter, first min wins) ------------- */
 int vq_argmin_f32(const float *z, const float *emb, int64_t *idx,
                   float *zq_or_null, int64_t dim, int64_t rows, int64_t n,
-                  float emb_absmax, void *workspace, int64_t workspace_bytes,
-                  void *stream);
+                  void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- LFQ: sign quantisation + big-endian bit pack -------------------------- */
 int lfq_pack_f32(const float *x, int64_t *idx, float *q_or_null, int64_t rows,
@@ -245,6 +244,9 @@ int gq_indices_from_u16(const uint16_t *in, int64_t *idx, int64_t count,
  * events and returns the number of launches and their total/avg milliseconds;
  * it resets the recorder.  Disabled by default (zero overhead). */
 int gqhip_profile_enable(int on);
+/* Pre-create `pairs` event pairs (outside any timed region): profiled launches only take events from this pool, a
+ * launch that finds it empty is not recorded; collected events return to the pool. */
+int gqhip_profile_reserve(int pairs);
 int gqhip_profile_collect(int *launches_host, double *total_ms_host);
 
 /* Diagnostics of the last fused call on `workspace` (device-side counters,

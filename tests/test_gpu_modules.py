@@ -98,8 +98,7 @@ def test_g5_edge_rows():
 
     d = load("g5_edges.npz")
     q = GaussianQuantRegularizer("bchw", 2048, group=16, backend="hip").eval().to(DEV)
-    q.prior_samples.copy_(torch.from_numpy(d["cb"]))
-    q._absmax = float(np.abs(d["cb"]).max())
+    q.prior_samples.copy_(torch.from_numpy(d["cb"]))   # in-place edit: nothing cached from the old codebook exists
     zhat, info = q(torch.from_numpy(d["z"]).to(DEV))
     ind = info["indices"].cpu().numpy()
     assert np.array_equal(ind, d["indices"])
@@ -442,7 +441,7 @@ def test_quantizer_is_hip_graph_capturable():
     from pit_hip import _lib
 
     run = lambda: _lib.gq_quantize_z(z_static, q.prior_samples, 16, "bchw", _lib.GQHIP_GROUP_STRIDED,
-                                     absmax=q._absmax, ws=q._ws)
+                                     ws=q._ws)
     run()  # warm-up: sizes the workspace outside the capture
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
@@ -453,8 +452,7 @@ def test_quantizer_is_hip_graph_capturable():
         z_static.copy_(z_new)
         graph.replay()
         torch.cuda.synchronize()
-        idx_e, zhat_e = _lib.gq_quantize_z(z_new, q.prior_samples, 16, "bchw", _lib.GQHIP_GROUP_STRIDED,
-                                           absmax=q._absmax)
+        idx_e, zhat_e = _lib.gq_quantize_z(z_new, q.prior_samples, 16, "bchw", _lib.GQHIP_GROUP_STRIDED)
         assert torch.equal(idx_g, idx_e) and torch.equal(zhat_g, zhat_e)
 
 

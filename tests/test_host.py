@@ -37,7 +37,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(dll, name), f"libgqhip.so does not export {name}"
     assert declared == set(L.EXPORTED_SYMBOLS), "python binding and header disagree"
-    assert L.lib().gqhip_abi_version() == 3
+    assert L.lib().gqhip_abi_version() == L.ABI_VERSION == 4
     assert L.lib().gqhip_status_string(2) == b"workspace missing or too small"
 
 
@@ -52,7 +52,7 @@ def test_workspace_sizing_is_host_only_and_monotone():
 
 def test_invalid_arguments_return_status_not_crash():
     L = _lib().lib()
-    assert L.gq_argmax_f32(None, None, None, None, None, None, 16, 4, 1024, 1.0, 0.0, None, 0, None) == 1
+    assert L.gq_argmax_f32(None, None, None, None, None, None, 16, 4, 1024, 1.0, None, 0, None) == 1
     assert L.gq_scores_f32(None, None, None, None, 16, 4, 1024, 1.0, None) == 1
     assert L.lfq_pack_f32(None, None, None, 4, 16, None) == 1
 
@@ -94,7 +94,8 @@ def test_regularizer_buffers_match_reference_hashes():
     assert sha(q.prior_samples.numpy()) == want["cb_sha"]
     assert sha(q.normal_log_prob.numpy()) == want["nlp_sha"]
     assert len(q.state_dict()) == 0 and q.group == 16 and q.n_samples == 65536
-    assert q._absmax == want["absmax"]
+    assert float(q.prior_samples.abs().max()) == want["absmax"]
+    assert not hasattr(q, "_absmax")   # nothing derived from the codebook is cached on the host
 
 
 def _sd_sha(sd):
@@ -224,3 +225,94 @@ def test_graft_entry_build_runs():
     import __graft_entry__ as ge
 
     ge.build()
+
+
+# ---------------------------------------------------------------------------------------------- round 2
+def test_get_psnr_matches_reference_golden():
+    """pit/evaluations/psnr.py:17-35 via golden g12 (captured from the imported reference)."""
+    from pit_hip.eval_dist import get_psnr, psnr_zero_mean
+
+    d = np.load(os.path.join(G, "g12_psnr.npz"))
+    x, xr = torch.from_numpy(d["x"]), torch.from_numpy(d["x_rec"])
+    assert np.array_equal(get_psnr(x, xr, zero_mean=True).numpy(), d["psnr_zero_mean"])
+    assert np.array_equal(psnr_zero_mean(x, xr).numpy(), d["psnr_zero_mean"])
+    assert np.array_equal(get_psnr((x + 1) / 2, (xr + 1) / 2).numpy(), d["psnr_unit"])
+    assert torch.isinf(get_psnr(x[:1], x[:1], zero_mean=True)).all()   # identical images: +inf, like the reference
+
+
+def test_cal_ent_known_answers():
+    """eval.py:137-141: usage = share of non-empty bins, entropy = -sum p log2(p + 1e-5)."""
+    from pit_hip.eval_dist import cal_ent
+
+    n = 65536
+    usage, ent = cal_ent(torch.ones(n))
+    assert float(usage) == 1.0
+    assert abs(float(ent) - (-np.log2(1.0 / n + 1e-5))) < 1e-3     # 15.27 bits, not 16: the reference's 1e-5 offset
+    hist = torch.zeros(n)
+    hist[:4] = torch.tensor([1.0, 1.0, 2.0, 4.0])
+    usage, ent = cal_ent(hist)
+    assert abs(float(usage) - 4 / n) < 1e-9
+    p = np.array([1, 1, 2, 4]) / 8.0
+    assert abs(float(ent) - float(-(p * np.log2(p + 1e-5)).sum())) < 1e-5
+    assert cal_ent(hist.to(torch.int32))[1] == ent                  # integer histograms (the HIP kernel's) are accepted
+
+
+def test_checkpoint_round_trip_with_loss_keys(tmp_path):
+    """autoencoder.py:313-329 / eval.py:112-113: a Lightning-style checkpoint {"state_dict": ...} whose state_dict also
+    carries `loss.*` (LPIPS / discriminator) keys loads with strict=False: encoder / decoder / VQ codebook restored,
+    `loss.*` reported as unexpected, GQ buffers (non-persistent) neither saved nor expected."""
+    from pit_hip.models.autoencoder import AutoencodingEngine
+
+    unet = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=32, in_channels=3, out_ch=3, ch=32,
+                ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], dropout=0.0)
+    mk = lambda seed, reg: (torch.manual_seed(seed), AutoencodingEngine(
+        encoder_config={"target": "pit.modules.unet.Encoder", "params": unet},
+        decoder_config={"target": "pit.modules.unet.Decoder", "params": unet}, regularizer_config=reg))[1]
+    gq = {"target": "pit.quantization.gaussian.GaussianQuantRegularizer", "params": {"format": "bchw", "group": 16, "n_samples": 256}}
+    src = mk(1, gq)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    assert not any(k.startswith("regularization") for k in sd)
+    sd["loss.perceptual_loss.net.slice1.0.weight"] = torch.zeros(4, 3, 3, 3)
+    sd["loss.discriminator.main.0.weight"] = torch.ones(8)
+    path = tmp_path / "model.ckpt"
+    torch.save({"state_dict": sd, "global_step": 5000}, path)
+    dst = mk(2, gq)
+    assert not torch.equal(dst.encoder.conv_in.weight, src.encoder.conv_in.weight)
+    missing, unexpected = dst.init_from_ckpt(str(path))
+    assert missing == [] and sorted(unexpected) == sorted(k for k in sd if k.startswith("loss."))
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    # ckpt_path in the constructor (the YAML route) and ignore_keys
+    via_ctor = (torch.manual_seed(3), AutoencodingEngine(
+        encoder_config={"target": "pit.modules.unet.Encoder", "params": unet},
+        decoder_config={"target": "pit.modules.unet.Decoder", "params": unet}, regularizer_config=gq, ckpt_path=str(path)))[1]
+    assert torch.equal(via_ctor.decoder.conv_out.weight, src.decoder.conv_out.weight)
+    part = mk(4, gq)
+    missing, _ = part.init_from_ckpt(str(path), ignore_keys=("decoder.",))
+    assert missing and all(k.startswith("decoder.") for k in missing)
+    assert torch.equal(part.encoder.conv_in.weight, src.encoder.conv_in.weight)
+    # VQ: the codebook IS a parameter (vq.py:33) and must come back from the checkpoint
+    vq = {"target": "pit.quantization.vq.VQQuantizer", "params": {"format": "bchw", "n": 64, "dim": 16}}
+    unet_v = dict(unet, double_z=False)
+    mkv = lambda seed: (torch.manual_seed(seed), AutoencodingEngine(
+        encoder_config={"target": "pit.modules.unet.Encoder", "params": unet_v},
+        decoder_config={"target": "pit.modules.unet.Decoder", "params": unet_v}, regularizer_config=vq))[1]
+    a, b = mkv(5), mkv(6)
+    torch.save({"state_dict": a.state_dict()}, path)
+    assert "regularization.embedding.weight" in a.state_dict()
+    b.init_from_ckpt(str(path))
+    assert torch.equal(b.regularization.embedding.weight, a.regularization.embedding.weight)
+
+
+def test_step_record_validates_shape_and_range():
+    from pit_hip.eval_dist import StepRecord
+
+    lay = StepRecord(2, 3, n_metrics=1, check_range=True)
+    idx = torch.tensor([[1, 2, 65535], [0, 7, 9]])
+    rec = lay.pack(idx, torch.tensor([[1.5], [2.5]]))
+    got, met = lay.unpack(rec)
+    assert torch.equal(got, idx) and met.reshape(-1).tolist() == [1.5, 2.5]
+    with pytest.raises(ValueError, match="65536"):
+        lay.pack(torch.tensor([[1, 2, 65536], [0, 7, 9]]), torch.zeros(2, 1))
+    with pytest.raises(ValueError, match="layout"):
+        lay.pack(torch.zeros(2, 4, dtype=torch.int64), torch.zeros(2, 1))

@@ -153,3 +153,27 @@ def test_g10_bsq_fsq():
     zhat, ind, margin = O.fsq_forward(d["x"], d["levels"].tolist(), with_margin=True)
     assert np.array_equal(ind, d["indices"]) and np.array_equal(zhat, d["zhat"])
     assert np.array_equal(O.fsq_dequant(ind, d["levels"].tolist()), d["zhat"])
+
+
+def test_torch_restatement_matches_reference_goldens():
+    """oracle/gq_torch_ref.py (the reference's backend="torch" arithmetic, timed by bench.py's cpu_baseline)
+    reproduces the reference-captured indices and the C oracle on the kernel-boundary golden, and the g7 full-path
+    golden's first rows at the module boundary."""
+    import torch
+
+    from oracle import gq_torch_ref as T
+
+    d = load("g2_dim16_n1024.npz")
+    cb = O.codebook(1024, 16, 42)
+    idx, zhat = T.argmax_rows(torch.from_numpy(d["mu"]), torch.from_numpy(d["std"]), torch.from_numpy(cb))
+    assert np.array_equal(idx.numpy(), d["indices"])
+    assert np.array_equal(zhat.numpy(), cb[d["indices"]])
+    assert np.array_equal(T.normal_log_prob(torch.from_numpy(cb)).numpy(), O.nlp_table(cb))
+    # module boundary, strided grouping (K = 2), small codebook: torch restatement == C oracle
+    g = np.random.default_rng(5)
+    z = np.concatenate([0.9 * g.standard_normal((1, 16, 4, 4)), -1.5 + 0.3 * g.standard_normal((1, 16, 4, 4))],
+                       axis=1).astype(np.float32)
+    cb8 = O.codebook(2048, 8, 42)
+    zt, it = T.gq1_forward(torch.from_numpy(z), torch.from_numpy(cb8), 8)
+    zo, io = O.gq1_forward(z, cb8, 8)
+    assert np.array_equal(it.numpy(), io) and np.array_equal(zt.numpy(), zo)

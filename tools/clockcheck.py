@@ -13,7 +13,7 @@ sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(rows, dim, generator=g))).to(dev)
 cb = torch.randn(n, dim, generator=g).clamp(-4.6, 4.6).to(dev)
 ws = _lib.Workspace()
 for _ in range(100):
-    _lib.gq_argmax(mu, sd, cb, 1.0, absmax=4.6, ws=ws)
+    _lib.gq_argmax(mu, sd, cb, 1.0, ws=ws)
 torch.cuda.synchronize()
 L = _lib.lib()
 pl = _lib.debug_plan(rows, n, dim)

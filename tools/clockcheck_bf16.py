@@ -15,7 +15,7 @@ cb = torch.randn(n, dim, generator=g).clamp(-4.6, 4.6).to(dev)
 ws = _lib.Workspace()
 for reps in (1, 100):
     for _ in range(reps):
-        _lib.gq_argmax(mu, sd, cb, 1.0, absmax=4.6, ws=ws)
+        _lib.gq_argmax(mu, sd, cb, 1.0, ws=ws)
     torch.cuda.synchronize()
     st = ws.buf[128:128 + 48 * 8].cpu().numpy().view(np.uint64).reshape(24, 2).astype(np.float64)
     ghz = st[:, 0] / st[:, 1] * 0.1

@@ -30,10 +30,10 @@ for name, z in (("randn z", torch.randn(16, 32, 32, 32, generator=g)),
         _lib.set_filter(filt)
         ws = _lib.Workspace()
         _lib.debug_enable(True)
-        _lib.gq_quantize_z(z, cb, 16, "bchw", _lib.GQHIP_GROUP_STRIDED, (-30.0, 20.0), 1.0, absmax=4.6, ws=ws)
+        _lib.gq_quantize_z(z, cb, 16, "bchw", _lib.GQHIP_GROUP_STRIDED, (-30.0, 20.0), 1.0, ws=ws)
         torch.cuda.synchronize()
         fb, rr = _lib.debug_counters(ws)
         _lib.debug_enable(False)
-        t = timed(lambda: _lib.gq_quantize_z(z, cb, 16, "bchw", _lib.GQHIP_GROUP_STRIDED, (-30.0, 20.0), 1.0, absmax=4.6, ws=ws))
+        t = timed(lambda: _lib.gq_quantize_z(z, cb, 16, "bchw", _lib.GQHIP_GROUP_STRIDED, (-30.0, 20.0), 1.0, ws=ws))
         print(f"{name:32s} filter={filt:5s}: {t:.3f} ms, second-stage rows {fb}, candidates/row {rr/16384:.3f}")
 _lib.set_filter("auto")

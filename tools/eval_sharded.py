@@ -14,8 +14,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vq-vae-from-gaussian-vae_amd"))
-from pit_hip import _lib  # noqa: E402
-from pit_hip.eval_dist import evaluate_sharded, init_from_env  # noqa: E402
+from pit_hip.eval_dist import codebook_usage, evaluate_sharded, init_from_env  # noqa: E402
 from pit_hip.util import instantiate_from_config, load_config  # noqa: E402
 
 
@@ -36,7 +35,7 @@ def main():
     torch.manual_seed(1234)
     model = instantiate_from_config(cfg["model"])
     if a.ckpt:
-        model.load_state_dict(torch.load(a.ckpt, map_location="cpu")["state_dict"], strict=False)
+        model.init_from_ckpt(a.ckpt)   # autoencoder.py:313-329: strict=False, `loss.*` keys ignored
     model = model.eval().to(device)
     if device.type == "cuda":
         model = model.to(memory_format=torch.channels_last)   # NHWC: the fast conv stack (inputs are converted by the modules)
@@ -60,11 +59,13 @@ def main():
         psnr = out["psnr"].float()
         print(f"PSNR: {psnr.mean():.4f} (±{psnr.std(unbiased=False):.4f})  over {psnr.numel()} images")
         n_codes = getattr(model.regularization, "n_samples", 65536)
-        hist = _lib.index_histogram(out["indices"].to(device).contiguous(), n_codes).float()
-        usage = 1 - (hist == 0).float().mean()
-        p = hist / hist.sum()
-        ent = -(p * torch.log2(p + 1e-5)).sum()
-        print(f"codebook usage: {usage:.4f}  entropy: {ent:.3f} bits")  # eval.py:137-141
+        _, usage, ent = codebook_usage(out["indices"].to(device), n_codes)   # eval.py:137-141
+        print(f"codebook usage: {usage:.4f}  entropy: {ent:.3f} bits")
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -28,15 +28,14 @@ def main():
     mu = (0.9 * torch.randn(a.rows, a.dim, generator=g)).to(dev)
     sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(a.rows, a.dim, generator=g))).to(dev)
     cb = torch.randn(a.n, a.dim, generator=g).clamp(-4.6, 4.6).to(dev)
-    absmax = _lib.codebook_absmax(cb)
     ws = _lib.Workspace()
     for _ in range(5):
-        _lib.gq_argmax(mu, sd, cb, 1.0, absmax=absmax, ws=ws)
+        _lib.gq_argmax(mu, sd, cb, 1.0, ws=ws)
     torch.cuda.synchronize()
     _lib.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.iters):
-        _lib.gq_argmax(mu, sd, cb, 1.0, absmax=absmax, ws=ws)
+        _lib.gq_argmax(mu, sd, cb, 1.0, ws=ws)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / a.iters
     launches, ms = _lib.profile_collect()
@@ -44,7 +43,7 @@ def main():
     flops = 4.0 * a.dim * a.n * a.rows
     kms = ms / max(launches, 1)
     _lib.debug_enable(True)
-    _lib.gq_argmax(mu, sd, cb, 1.0, absmax=absmax, ws=ws)
+    _lib.gq_argmax(mu, sd, cb, 1.0, ws=ws)
     torch.cuda.synchronize()
     fb, rr = _lib.debug_counters(ws)
     _lib.debug_enable(False)

@@ -42,19 +42,18 @@ rows = 16 * 4096  # config 5: bs 16, 512x512
 z = torch.randn(rows, 16, generator=g).to(dev)
 emb = torch.randn(n, 16, generator=g).to(dev)
 ws = _lib.Workspace()
-am = _lib.codebook_absmax(emb)
-t = timed(lambda: _lib.vq_argmin(z, emb, absmax=am, ws=ws), 10)
+t = timed(lambda: _lib.vq_argmin(z, emb, ws=ws), 10)
 print(f"vq_argmin rows={rows} (bs16 @512^2): {t:.3f} ms -> {2 * 2 * 16 * n * rows / t / 1e9:.1f} TFLOP/s (4*dim*N convention)")
 t = timed(lambda: _lib.lfq_pack(z))
 print(f"lfq_pack rows={rows}: {t * 1e3:.1f} us -> {(rows * 16 * 4 * 2 + rows * 8) / t / 1e6:.0f} GB/s")
 zz = torch.cat([0.9 * torch.randn(16, 16, 32, 32, generator=g), -1.5 + 0.3 * torch.randn(16, 16, 32, 32, generator=g)], 1).to(dev)
-t = timed(lambda: _lib.gq_quantize_z(zz, cb, 16, "bchw", 0, absmax=4.6, ws=ws))
+t = timed(lambda: _lib.gq_quantize_z(zz, cb, 16, "bchw", 0, ws=ws))
 _lib.debug_enable(True)
-_lib.gq_quantize_z(zz, cb, 16, "bchw", 0, absmax=4.6, ws=ws)
+_lib.gq_quantize_z(zz, cb, 16, "bchw", 0, ws=ws)
 torch.cuda.synchronize()
 fb, rr = _lib.debug_counters(ws)
 _lib.debug_enable(False)
 print(f"gq_quantize_z bs16 256^2 (prep+split+filter+rerank+second stage): {t:.3f} ms; second-stage rows {fb}, candidates/row {rr / 16384:.3f}")
-idx, _ = _lib.gq_quantize_z(zz, cb, 16, "bchw", 0, absmax=4.6, ws=ws)
+idx, _ = _lib.gq_quantize_z(zz, cb, 16, "bchw", 0, ws=ws)
 t = timed(lambda: _lib.gq_dequant(idx, cb, 16, "bchw", 0))
 print(f"gq_dequant bs16: {t * 1e3:.1f} us")

@@ -9,11 +9,10 @@ mu = torch.randn(rows, dim, generator=g).to(dev)
 for name, sd in (("abs(randn)+1e-3", torch.abs(torch.randn(rows, dim, generator=g)) + 1e-3), ("lognormal(-0.75,0.15)", torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(rows, dim, generator=g))))):
     sd = sd.to(dev)
     ws = _lib.Workspace()
-    am = _lib.codebook_absmax(noise)
-    for _ in range(2): _lib.gq_argmax(mu, sd, noise, 1.0, absmax=am, ws=ws)
+    for _ in range(2): _lib.gq_argmax(mu, sd, noise, 1.0, ws=ws)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5): _lib.gq_argmax(mu, sd, noise, 1.0, absmax=am, ws=ws)
+    for _ in range(5): _lib.gq_argmax(mu, sd, noise, 1.0, ws=ws)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-    _lib.debug_enable(True); _lib.gq_argmax(mu, sd, noise, 1.0, absmax=am, ws=ws); torch.cuda.synchronize()
+    _lib.debug_enable(True); _lib.gq_argmax(mu, sd, noise, 1.0, ws=ws); torch.cuda.synchronize()
     fb, rr = _lib.debug_counters(ws); _lib.debug_enable(False)
     print(f"sd={name}: {dt*1e3:.2f} ms per call, fallback rows {fb} ({100*fb/rows:.2f}%), candidates/row {rr/rows:.2f}")

@@ -8,72 +8,6 @@
 
 namespace gqhip {
 
-// max |cb| -> *out via integer atomicMax on the (non-negative) float bits; a
-// NaN/inf element maps to +inf so the fused paths fall back to exhaustive.
-__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ cb, long count,
-                                                      float *out) {
-  float m = 0.0f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
-    const float v = fabsf(cb[i]);
-    m = (v != v) ? __builtin_inff() : __builtin_fmaxf(m, v);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int *>(out), __float_as_int(m));
-}
-
-// ---- operand prep: z [mu | logvar] -> mu, sd, lsd rows ---------------------
-// pit/quantization/gaussian.py:62-81,122-123 (GQ1) / :273-287 (GQ2), with
-// sd = float(exp(0.5*logvar)) and lsd = float(log(sd)) evaluated in fp64.
-struct PrepParams {
-  const float *z;
-  float *mu, *sd, *lsd;   // [rows, dim]
-  long rows;
-  int dim, K, L, c;       // c = channels of mu (z has 2c)
-  int layout, grouping;
-  float lv_min, lv_max;
-};
-
-__global__ __launch_bounds__(256) void prep_kernel(const PrepParams p) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= p.rows * p.dim) return;
-  // BCHW reads are coalesced along l when consecutive threads walk l; rows are
-  // (pos*K + k) so we index threads as (b, ch, l) for BCHW and (pos, ch) for BLC.
-  long row, b, l, pos;
-  int g, k, ch;
-  if (p.layout == 0) {
-    l = t % p.L;
-    ch = (int)((t / p.L) % p.c);
-    b = t / ((long)p.L * p.c);
-    pos = b * p.L + l;
-  } else {
-    ch = (int)(t % p.c);
-    pos = t / p.c;
-    b = pos / p.L;
-    l = pos % p.L;
-  }
-  if (p.grouping == 0) { g = ch / p.K; k = ch % p.K; } else { k = ch / p.dim; g = ch % p.dim; }
-  row = pos * p.K + k;
-  float m, lv;
-  if (p.layout == 0) {
-    m = p.z[(b * 2 * p.c + ch) * p.L + l];
-    lv = p.z[(b * 2 * p.c + p.c + ch) * p.L + l];
-  } else {
-    m = p.z[pos * 2 * p.c + ch];
-    lv = p.z[pos * 2 * p.c + p.c + ch];
-  }
-  // torch.clamp propagates NaN; min/max with explicit compares keeps that.
-  lv = lv < p.lv_min ? p.lv_min : lv;
-  lv = lv > p.lv_max ? p.lv_max : lv;
-  const float half = 0.5f * lv;
-  const float s = (float)exp((double)half);
-  const float ls = (float)log((double)s);
-  const long o = row * p.dim + g;
-  p.mu[o] = m;
-  p.sd[o] = s;
-  p.lsd[o] = ls;
-}
-
 // ---- dequant: zhat <- cb[idx] in the module layout -------------------------
 struct DequantParams {
   const int64_t *idx;

@@ -28,16 +28,23 @@ struct __attribute__((aligned(32))) Rec {
   int pad;
 };
 
-// Workspace header (first 256 bytes of the caller's workspace).
+// Workspace header (first 2 KiB of the caller's workspace).  Everything in it is (re)written by the kernels of ONE
+// call: gq_prep_kernel resets the counters and writes the max|cb| partials, the level-1 re-rank reduces them to
+// `absmax` for the tail kernel.  Nothing here is read across calls.
+constexpr int kAbsmaxParts = 256;
 struct WsHeader {
   int fb_count;                       // rows the first filter + re-rank could not decide (list A)
   int fb2_count;                      // rows still undecided after the fp32 second-level filter (list B)
   unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly
-  float absmax;                       // max |cb| (device-computed when needed)
-  int pad1[27];
+  float absmax;                       // max |cb|, reduced from absmax_part by the level-1 re-rank
+  unsigned bar_count, bar_gen;        // grid barrier of the tail kernel (cascade path only)
+  int bar_timeout;                    // set if a barrier spin ever ran out (never expected; gqhip_debug_counters reports it)
+  int pad1[24];
+  float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
+  int pad2[128];
 };
-static_assert(sizeof(WsHeader) == 512, "header is 512 bytes");
+static_assert(sizeof(WsHeader) == 2048, "header is 2 KiB");
 
 // Insert (t, id) into a descending top-4 (ids kept for the top 3 only).
 __device__ __forceinline__ void top4_insert(float t, int id, float &m1, float &m2, float &m3, float &m4,

@@ -42,8 +42,7 @@ struct FilterParams {
   int rows, n;
   float beta;
   int nsplit, tiles_total, tiles_per_split;
-  WsHeader *hdr;        // block 0 initialises the workspace header
-  float absmax;         // caller-provided max|cb| (<= 0: a later kernel computes it)
+  WsHeader *hdr;
   void *dbg;            // diagnostic builds only
   // second-level use (behind the split-bf16 filter): only the rows listed in row_list[0 .. *row_count) are
   // processed, and only if there are more than min_count of them; records are still indexed by row id
@@ -129,7 +128,7 @@ __device__ __forceinline__ void tile_mfma(const float (&a)[DIM / 2], const float
 // MFMAs of tile t (no wait for the accumulators to drain; each MFMA<->VALU switch
 // costs ~9 cycles, so the VALU work is clustered, not spread).
 template <int DIM, int RT, int CT, int MODE, int GT>
-__global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p) {
+__device__ __forceinline__ void filter_block(const FilterParams &p, const int vblock) {
   constexpr int HD = DIM / 2;                 // dims per lane half
   constexpr int TILE_F = kTileCodes * DIM;    // floats per 32-code tile
   constexpr int CHUNK_F = CT * TILE_F;        // floats per LDS chunk (per array)
@@ -141,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const int split = blockIdx.x % p.nsplit;
-  const int rowblk = blockIdx.x / p.nsplit;
+  const int split = vblock % p.nsplit;
+  const int rowblk = vblock / p.nsplit;
   const int t_begin = split * p.tiles_per_split;          // multiple of GT (tiles_per_split is)
   const int t_end = min(t_begin + p.tiles_per_split, p.tiles_total);
   const int t_full_end = min(t_end, p.n / kTileCodes);    // complete tiles only
@@ -155,11 +154,6 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   if (p.row_list) {
     nrows = *p.row_count;
     if (nrows <= p.min_count || rowblk * (128 * RT) >= nrows) return;   // block-uniform
-  } else if (blockIdx.x == 0 && tid == 0) {  // workspace header for the kernels that follow on the stream
-    p.hdr->fb_count = 0;
-    p.hdr->fb2_count = 0;
-    p.hdr->reranked = 0ull;
-    if (p.absmax > 0.f) p.hdr->absmax = p.absmax;
   }
 
   // ---- row coefficients (B operands), fixed for the whole kernel ----------
@@ -347,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
   }
 
 #ifdef GQHIP_CLOCK_STAMPS
-  if (tid == 0 && blockIdx.x < 2048) {   // diagnostic build only: per-block timeline + placement
-    unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + 4 * blockIdx.x;
+  if (tid == 0 && vblock < 2048) {   // diagnostic build only: per-block timeline + placement
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + 4 * vblock;
     o[0] = st_r0;
     o[1] = __builtin_amdgcn_s_memrealtime();
     o[2] = ((st_r1 - st_r0) << 32) | (st_r2 - st_r0);   // prologue end, loop end (100 MHz ticks from block start)
@@ -376,6 +370,11 @@ __global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p)
       p.rec[(long)split * p.rows + row] = r;
     }
   }
+}
+
+template <int DIM, int RT, int CT, int MODE, int GT>
+__global__ __launch_bounds__(256, 2) void gq_filter_kernel(const FilterParams p) {
+  filter_block<DIM, RT, CT, MODE, GT>(p, (int)blockIdx.x);
 }
 
 }  // namespace gqhip

@@ -12,9 +12,9 @@
 //
 // K layout.  Per "type" (hh, lh, hl) there are 2*DIM slots [ squares of dims 0..DIM-1 | values of dims
 // 0..DIM-1 ]; MFMA m of a type covers slots 16m .. 16m+15, lane half h supplies slots 16m+8h .. 16m+8h+7.
-// NV = DIM/8 MFMAs per type (DIM = 4 packs its three 8-slot types into two MFMAs, see bf16_split_kernel).  Code side: vectors 0..NV-1 hold the h parts, NV..2NV-1 the l parts; row side
+// NV = DIM/8 MFMAs per type (DIM = 4 packs its three 8-slot types into two MFMAs, see below).  Code side: vectors 0..NV-1 hold the h parts, NV..2NV-1 the l parts; row side
 // likewise with the coefficients [A | B].  MFMA (type, m):  hh -> (code m, row m), lh -> (code NV+m, row m),
-// hl -> (code m, row NV+m).  Both images are produced once per call by bf16_split_kernel (below), the
+// hl -> (code m, row NV+m).  Both images are produced once per call by gq_prep_kernel (gq_prep.h), the
 // codebook image already in the LDS tile order, so staging is a linear 16-byte copy.
 //
 // Tile image: [tile][code vector cv][half h][code c] x 16 bytes  ->  a wave's ds_read_b128 of one vector is
@@ -37,15 +37,7 @@ struct FilterBfParams {
   int rows, n;
   int nsplit, tiles_total, tiles_per_split;
   WsHeader *hdr;
-  float absmax;
   void *dbg;            // diagnostic builds only
-};
-
-struct SplitParams {
-  const float *mu, *sd, *cb;
-  u32x4 *cbimg, *rowimg;
-  int rows, n, tiles_total;
-  float beta;
 };
 
 // round-to-nearest-even fp32 -> bf16 (as the upper 16 bits); finite inputs (non-finite rows / codebooks never
@@ -60,93 +52,10 @@ __device__ __forceinline__ void bf16_split(float q, unsigned &hi, unsigned &lo) 
   lo = bf16_rne(r);
 }
 
-// One thread per (code, half) and per (row, half): builds both operand images.
+// Both operand images are built by gq_prep_kernel (gq_prep.h), once per call.
 // DIM == 4 ("packed", NV = 0 in the filter): a type has only 8 slots, so two MFMAs carry the three types:
 //   MFMA 0: half 0 = hh (code h parts x row h parts), half 1 = lh (code l parts x row h parts)
 //   MFMA 1: half 0 = hl (code h parts x row l parts), half 1 = zero padding
-template <int MODE, int DIM>
-__global__ __launch_bounds__(256) void bf16_split_kernel(const SplitParams p) {
-  static_assert(DIM == 4 || DIM == 8 || DIM == 16 || DIM == 32, "split-bf16 filter: dims 4, 8, 16, 32");
-  constexpr bool PACKED = DIM == 4;
-  constexpr int NV = PACKED ? 1 : DIM / 8;     // 8-slot groups this thread splits
-  constexpr int NVEC = PACKED ? 2 : 2 * NV;    // vectors per (code | row, half) in the image
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const long ncode_threads = (long)p.tiles_total * 64;
-  float q[NV][8];
-  u32x4 *dst;
-  long stride;      // in u32x4 between consecutive vectors
-  int h;
-  bool is_code;
-  if (t < ncode_threads) {
-    is_code = true;
-    const int tile = (int)(t >> 6), c = (int)t & 31;
-    h = (int)(t >> 5) & 1;
-    const long code = (long)tile * 32 + c;
-#pragma unroll
-    for (int m = 0; m < NV; ++m)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int g = PACKED ? k : 16 * m + 8 * h + k;     // slot: [ squares | values ]
-        float v = 0.0f;
-        if (code < p.n) {
-          v = p.cb[code * DIM + (g < DIM ? g : g - DIM)];
-          if (g < DIM) v = v * v;
-        }
-        q[m][k] = v;
-      }
-    dst = p.cbimg + (long)tile * (NVEC * 64) + h * 32 + c;
-    stride = 64;
-  } else {
-    is_code = false;
-    const long u = t - ncode_threads;
-    const long row = u >> 1;
-    h = (int)u & 1;
-    if (row >= p.rows) return;
-#pragma unroll
-    for (int m = 0; m < NV; ++m)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int g = PACKED ? k : 16 * m + 8 * h + k;
-        const int i = g < DIM ? g : g - DIM;
-        float v;
-        if constexpr (MODE == kModeGQ) {
-          const double sg = (double)p.sd[row * DIM + i];
-          const double inv = 1.0 / (sg * sg);
-          v = g < DIM ? (float)(0.5 * (double)p.beta - 0.5 * inv) : (float)((double)p.mu[row * DIM + i] * inv);
-        } else {
-          v = g < DIM ? -1.0f : 2.0f * p.mu[row * DIM + i];
-        }
-        q[m][k] = v;
-      }
-    dst = p.rowimg + row * (NVEC * 2) + h;
-    stride = 2;
-  }
-#pragma unroll
-  for (int m = 0; m < NV; ++m) {
-    unsigned hi[8], lo[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bf16_split(q[m][k], hi[k], lo[k]);
-    u32x4 vh, vl;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      vh[w] = hi[2 * w] | (hi[2 * w + 1] << 16);
-      vl[w] = lo[2 * w] | (lo[2 * w + 1] << 16);
-    }
-    if constexpr (PACKED) {
-      const u32x4 zero = {0u, 0u, 0u, 0u};
-      if (is_code) {   // vector 0: (h, l) parts by half; vector 1: (h parts, padding)
-        dst[0] = h == 0 ? vh : vl;
-        dst[stride] = h == 0 ? vh : zero;
-      } else {         // vector 0: h parts in both halves; vector 1: (l parts, padding)
-        dst[0] = vh;
-        dst[stride] = h == 0 ? vl : zero;
-      }
-    } else {
-      dst[(long)m * stride] = vh;
-      dst[(long)(NV + m) * stride] = vl;
-    }
-  }
-}
 
 // f(integral_constant<int, 0>{}, ..., integral_constant<int, N-1>{})
 template <class F, int... I>
@@ -216,13 +125,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
 #ifdef GQHIP_CLOCK_STAMPS
   const unsigned long long st_b0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (blockIdx.x == 0 && tid == 0) {  // workspace header for the kernels that follow on the stream
-    p.hdr->fb_count = 0;
-    p.hdr->fb2_count = 0;
-    p.hdr->reranked = 0ull;
-    if (p.absmax > 0.f) p.hdr->absmax = p.absmax;
-  }
-
   // ---- row operands (B side of the MFMA), fixed for the whole kernel ----
   u32x4 rv[RT][NCV];
 #pragma unroll

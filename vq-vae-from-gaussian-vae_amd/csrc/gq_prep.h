@@ -1,0 +1,292 @@
+// gq_prep.h -- the first launch of every fused arg-max call: everything that is derived from the inputs once.
+//
+// Row blocks (one 256-thread block per 256 / DIM consecutive rows):
+//   * FROM_Z: z [mu | logvar] in the module layout -> mu, sd = float(exp(double(0.5 lv))), lsd = float(log(double(sd)))
+//     rows (pit/quantization/gaussian.py:62-81,122-123 / :273-287; the group permutes are index arithmetic here), and
+//     zhat_noquant = mu + noise * sd straight into the module layout (gaussian.py:121);
+//     otherwise the caller's (mu, sd[, lsd]) rows are used as they are.
+//   * the filter's row operands A = beta/2 - 1/(2 sd^2), B = mu / sd^2 (fp64, rounded once), split into two bf16
+//     terms and written as the row image of gq_filter_bf16.h;
+//   * four per-row sums the re-rank's rounding bound is made of (so that no kernel after this one divides in fp64):
+//       S0 = sum 1/sd^2, S1 = sum |mu|/sd^2, S2 = sum mu^2/sd^2, S3 = sum |log sd|      (VQ: S1 = sum |z|).
+// Code blocks (the 256 blocks after the row blocks): the bf16 tile image of the codebook [n^2 | n] (h / l parts, in the
+// LDS tile order of the filter) and max |cb| as one partial per block.  Both are rebuilt on EVERY call from the
+// codebook the caller passes: nothing derived from a codebook outlives the call, so a codebook that was edited in
+// place (by whatever means) can never meet a stale image or a stale bound.
+// Block 0 also resets the workspace header for the kernels that follow on the stream.
+#pragma once
+#include "gq_common.h"
+#include "gq_filter_bf16.h"
+#include "gq_rerank.h"
+
+namespace gqhip {
+
+constexpr int kPrepCodeBlocks = kAbsmaxParts;   // one max|cb| partial per code block
+
+struct PrepParams {
+  // FROM_Z
+  const float *z;            // [B, 2c, L] (BCHW) or [B, L, 2c] (BLC)
+  const float *noise;        // module layout of zhat_noquant, or NULL
+  float *zhat_noquant;       // [B, c, L] / [B, L, c], or NULL
+  float lv_min, lv_max;
+  // rows: outputs when FROM_Z, inputs otherwise (lsd may then be NULL: lsd_out receives float(log(double(sd))))
+  float *mu, *sd, *lsd;      // [rows, dim]
+  float *lsd_out;            // !FROM_Z only, may be NULL
+  double *rowsum;            // [rows, 4]
+  u32x4 *rowimg;             // [rows][NVEC][2] or NULL (fp32 filter: no images)
+  const float *cb;           // [n, dim]
+  u32x4 *cbimg;              // [tiles_total + CT][NVEC][2][32] or NULL
+  WsHeader *hdr;
+  long rows;
+  int n, tiles_total;
+  int row_blocks;            // blocks [0, row_blocks) prepare rows, the kPrepCodeBlocks after them the codebook
+  float beta;
+  OutMap omap;               // module layout (mode 1 BCHW, 2 BLC; 0: plain rows)
+};
+
+template <int MODE, int DIM, bool FROM_Z>
+__global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
+  static_assert(DIM == 4 || DIM == 8 || DIM == 16 || DIM == 32, "MFMA filter dims");
+  constexpr bool PACKED = DIM == 4;
+  constexpr int NV = PACKED ? 1 : DIM / 8;     // 8-slot groups per operand half
+  constexpr int NVEC = PACKED ? 2 : 2 * NV;    // 16-byte vectors per (code | row, half) in an image
+  constexpr int RB = 256 / DIM;                // rows per block
+  const int tid = threadIdx.x;
+
+  if (blockIdx.x == 0 && tid == 0) {           // header for the kernels that follow on the stream
+    p.hdr->fb_count = 0;
+    p.hdr->fb2_count = 0;
+    p.hdr->reranked = 0ull;
+    p.hdr->bar_count = 0u;
+    p.hdr->bar_timeout = 0;
+  }
+
+  if ((int)blockIdx.x >= p.row_blocks) {
+    // ------------------------------------------------------------------ codebook image + max |cb|
+    const int cbk = blockIdx.x - p.row_blocks;
+    float amax = 0.0f;
+    if (p.cbimg) {
+      const long items = (long)p.tiles_total * 64;   // (tile, half, code)
+      for (long t = (long)cbk * 256 + tid; t < items; t += (long)kPrepCodeBlocks * 256) {
+        const int tile = (int)(t >> 6), c = (int)t & 31, h = (int)(t >> 5) & 1;
+        const long code = (long)tile * 32 + c;
+        u32x4 *dst = p.cbimg + (long)tile * (NVEC * 64) + h * 32 + c;
+#pragma unroll
+        for (int m = 0; m < NV; ++m) {
+          unsigned hi[8], lo[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int g = PACKED ? k : 16 * m + 8 * h + k;   // slot: [ squares of dims | values of dims ]
+            float v = 0.0f;
+            if (code < p.n) {
+              v = p.cb[code * DIM + (g < DIM ? g : g - DIM)];
+              const float a = fabsf(v);
+              amax = (a != a) ? __builtin_inff() : __builtin_fmaxf(amax, a);
+              if (g < DIM) v = v * v;
+            }
+            bf16_split(v, hi[k], lo[k]);
+          }
+          u32x4 vh, vl;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            vh[w] = hi[2 * w] | (hi[2 * w + 1] << 16);
+            vl[w] = lo[2 * w] | (lo[2 * w + 1] << 16);
+          }
+          if constexpr (PACKED) {   // vector 0: (h, l) parts by half; vector 1: (h parts, zero padding)
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            dst[0] = h == 0 ? vh : vl;
+            dst[64] = h == 0 ? vh : zero;
+          } else {
+            dst[(long)m * 64] = vh;
+            dst[(long)(NV + m) * 64] = vl;
+          }
+        }
+      }
+    } else {
+      const long count = (long)p.n * DIM;
+      for (long i = (long)cbk * 256 + tid; i < count; i += (long)kPrepCodeBlocks * 256) {
+        const float a = fabsf(p.cb[i]);
+        amax = (a != a) ? __builtin_inff() : __builtin_fmaxf(amax, a);
+      }
+    }
+    __shared__ float s_amax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, o));
+    if ((tid & 63) == 0) s_amax[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0)
+      p.hdr->absmax_part[cbk] = __builtin_fmaxf(__builtin_fmaxf(s_amax[0], s_amax[1]), __builtin_fmaxf(s_amax[2], s_amax[3]));
+    return;
+  }
+
+  // -------------------------------------------------------------------- rows
+  __shared__ __attribute__((aligned(16))) float s_mu[256], s_sd[256], s_lsd[256];
+  __shared__ __attribute__((aligned(16))) unsigned short s_hi[RB][2 * DIM], s_lo[RB][2 * DIM];
+  __shared__ double s_sum[256][4];
+  const long row0 = (long)blockIdx.x * RB;
+  // element of the tile handled in phase 1: rows fastest for BCHW (consecutive l -> coalesced z reads), else dims fastest
+  int lr, g;
+  if (FROM_Z && p.omap.mode == 1) { lr = tid % RB; g = tid / RB; } else { lr = tid / DIM; g = tid % DIM; }
+  const long row = row0 + lr;
+  const bool live = row < p.rows;
+  float m = 0.0f, s = 1.0f, ls = 0.0f;
+  if (live) {
+    if constexpr (FROM_Z) {
+      // row = pos * K + k; channel of (k, g): strided g*K + k (GQ1), contiguous k*dim + g (GQ2)
+      const OutMap &om = p.omap;
+      const long pos = row / om.K;
+      const int k = (int)(row % om.K);
+      const long ch = om.grouping == 0 ? (long)g * om.K + k : (long)k * DIM + g;
+      long zo_mu, zo_lv, oo;
+      if (om.mode == 1) {
+        const long b = pos / om.L, l = pos % om.L;
+        zo_mu = (b * 2 * om.c + ch) * om.L + l;
+        zo_lv = (b * 2 * om.c + om.c + ch) * om.L + l;
+        oo = (b * om.c + ch) * om.L + l;
+      } else {
+        zo_mu = pos * 2 * om.c + ch;
+        zo_lv = zo_mu + om.c;
+        oo = pos * om.c + ch;
+      }
+      m = p.z[zo_mu];
+      float lv = p.z[zo_lv];
+      // torch.clamp propagates NaN; min/max with explicit compares keeps that.
+      lv = lv < p.lv_min ? p.lv_min : lv;
+      lv = lv > p.lv_max ? p.lv_max : lv;
+      const float half = 0.5f * lv;
+      s = (float)exp((double)half);
+      ls = (float)log((double)s);
+      if (p.zhat_noquant) {
+#pragma clang fp contract(off)
+        const float e = p.noise[oo] * s;
+        p.zhat_noquant[oo] = m + e;
+      }
+    } else {
+      m = p.mu[row * DIM + g];
+      if constexpr (MODE == kModeGQ) {
+        s = p.sd[row * DIM + g];
+        ls = p.lsd ? p.lsd[row * DIM + g] : (float)log((double)s);
+      }
+    }
+  }
+  float cA, cB;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  if constexpr (MODE == kModeGQ) {
+    const double sg = (double)s;
+    double inv = 1.0 / (sg * sg);
+    cA = (float)(0.5 * (double)p.beta - 0.5 * inv);
+    cB = (float)((double)m * inv);
+    if (!(sg > 0.0)) inv = __builtin_nan("");   // sd <= 0 or NaN: the row's bound is NaN -> undecided -> exhaustive semantics
+    const double am = fabs((double)m);
+    t0 = inv; t1 = am * inv; t2 = am * am * inv; t3 = fabs((double)ls);
+  } else {
+    cA = -1.0f;
+    cB = 2.0f * m;
+    t1 = fabs((double)m);
+  }
+  s_mu[lr * DIM + g] = m;
+  s_sd[lr * DIM + g] = s;
+  s_lsd[lr * DIM + g] = ls;
+  unsigned ah, al, bh, bl;
+  bf16_split(cA, ah, al);
+  bf16_split(cB, bh, bl);
+  s_hi[lr][g] = (unsigned short)ah;
+  s_lo[lr][g] = (unsigned short)al;
+  s_hi[lr][DIM + g] = (unsigned short)bh;
+  s_lo[lr][DIM + g] = (unsigned short)bl;
+  s_sum[lr * DIM + g][0] = t0;
+  s_sum[lr * DIM + g][1] = t1;
+  s_sum[lr * DIM + g][2] = t2;
+  s_sum[lr * DIM + g][3] = t3;
+  __syncthreads();
+
+  // ---- phase 2: everything leaves the block as contiguous runs ----
+  const long e_out = row0 * DIM + tid;               // the tile is contiguous in [rows, dim]
+  if (e_out < p.rows * DIM) {
+    if constexpr (FROM_Z) {
+      p.mu[e_out] = s_mu[tid];
+      p.sd[e_out] = s_sd[tid];
+      p.lsd[e_out] = s_lsd[tid];
+    } else if (MODE == kModeGQ && p.lsd_out) {
+      p.lsd_out[e_out] = s_lsd[tid];
+    }
+  }
+  if (tid < RB * 4 && row0 + tid / 4 < p.rows) {     // four sums per row, ascending dim order (deterministic)
+    const int r = tid / 4, q = tid % 4;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) acc += s_sum[r * DIM + i][q];
+    p.rowsum[(row0 + r) * 4 + q] = acc;
+  }
+  if (p.rowimg && tid < RB * NVEC * 2) {
+    const int r = tid / (NVEC * 2), v = (tid / 2) % NVEC, h = tid % 2;
+    if (row0 + r < p.rows) {
+      u32x4 out;
+      if constexpr (PACKED) {   // vector 0: h parts in both halves; vector 1: (l parts, zero padding)
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        out = v == 0 ? *reinterpret_cast<const u32x4 *>(&s_hi[r][0])
+                     : (h == 0 ? *reinterpret_cast<const u32x4 *>(&s_lo[r][0]) : zero);
+      } else {                  // vectors 0..NV-1: h parts of slots 16m+8h..+7; NV..2NV-1: l parts
+        const int mm = v % NV;
+        out = v < NV ? *reinterpret_cast<const u32x4 *>(&s_hi[r][16 * mm + 8 * h])
+                     : *reinterpret_cast<const u32x4 *>(&s_lo[r][16 * mm + 8 * h]);
+      }
+      p.rowimg[(row0 + r) * (NVEC * 2) + v * 2 + h] = out;
+    }
+  }
+}
+
+// Legacy operand prep for shapes the MFMA filters do not cover (dim not in {4, 8, 16, 32}: exhaustive kernel):
+// z [mu | logvar] -> mu, sd, lsd rows and zhat_noquant, one thread per element.
+struct PrepPlainParams {
+  const float *z, *noise;
+  float *zhat_noquant;
+  float *mu, *sd, *lsd;   // [rows, dim]
+  long rows;
+  int dim;
+  float lv_min, lv_max;
+  OutMap omap;
+};
+
+__global__ __launch_bounds__(256) void prep_plain_kernel(const PrepPlainParams p) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.rows * p.dim) return;
+  const OutMap &om = p.omap;
+  // BCHW reads are coalesced along l when consecutive threads walk l: threads are (b, ch, l) for BCHW, (pos, ch) for BLC
+  long b, l, pos;
+  int ch;
+  if (om.mode == 1) {
+    l = t % om.L;
+    ch = (int)((t / om.L) % om.c);
+    b = t / ((long)om.L * om.c);
+    pos = b * om.L + l;
+  } else {
+    ch = (int)(t % om.c);
+    pos = t / om.c;
+    b = pos / om.L;
+    l = pos % om.L;
+  }
+  int g, k;
+  if (om.grouping == 0) { g = ch / om.K; k = ch % om.K; } else { k = ch / p.dim; g = ch % p.dim; }
+  const long row = pos * om.K + k;
+  long zo, oo;
+  if (om.mode == 1) { zo = (b * 2 * om.c + ch) * om.L + l; oo = (b * om.c + ch) * om.L + l; }
+  else { zo = pos * 2 * om.c + ch; oo = pos * om.c + ch; }
+  const float m = p.z[zo];
+  float lv = p.z[zo + (om.mode == 1 ? (long)om.c * om.L : (long)om.c)];
+  lv = lv < p.lv_min ? p.lv_min : lv;
+  lv = lv > p.lv_max ? p.lv_max : lv;
+  const float half = 0.5f * lv;
+  const float s = (float)exp((double)half);
+  const long o = row * p.dim + g;
+  p.mu[o] = m;
+  p.sd[o] = s;
+  p.lsd[o] = (float)log((double)s);
+  if (p.zhat_noquant) {
+#pragma clang fp contract(off)
+    const float e = p.noise[oo] * s;
+    p.zhat_noquant[oo] = m + e;
+  }
+}
+
+}  // namespace gqhip

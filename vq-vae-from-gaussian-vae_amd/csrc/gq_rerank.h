@@ -66,7 +66,8 @@ struct SpreadSlot {
 struct RerankParams {
   const float *mu;    // [rows, dim] (VQ: z)
   const float *sd;    // [rows, dim]
-  const float *lsd;   // [rows, dim] or NULL
+  const float *lsd;   // [rows, dim] (NULL only on the exhaustive path: fp64 log of sd)
+  const double *rowsum;  // [rows, 4] sums of gq_prep_kernel (bound of the re-rank)
   const float *cb;    // [n, dim]
   const Rec *rec;     // [nsplit, rows]
   int64_t *idx;
@@ -179,28 +180,71 @@ __device__ __forceinline__ void write_result(const RerankParams &p, long row, in
     p.zhat[out_zhat_offset(p.omap, row, lane, p.dim)] = p.cb[(long)best * p.dim + lane];
 }
 
+// max |cb| from the per-block partials gq_prep_kernel left in the header (one 1-KiB coalesced load per wave).
+__device__ __forceinline__ float wave_absmax(const WsHeader *hdr, int lane) {
+  const f32x4 v = reinterpret_cast<const f32x4 *>(hdr->absmax_part)[lane];
+  float m = __builtin_fmaxf(__builtin_fmaxf(v.x, v.y), __builtin_fmaxf(v.z, v.w));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+static_assert(kAbsmaxParts == 256, "wave_absmax reads 4 partials per lane");
+
+// The rounding bound of one row from the four sums gq_prep_kernel left (S0 = sum 1/sd^2, S1 = sum |mu|/sd^2,
+// S2 = sum mu^2/sd^2, S3 = sum |log sd|; VQ: S1 = sum |z|) and N1 = max|cb|:
+//   T = sum_i (|beta|/2 + 1/(2 sd^2)) N1^2 + |mu| N1 / sd^2,
+//   G = sum_i (N1 + |mu|)^2 / (2 sd^2) + |log sd| + c + |beta| (N1^2 / 2 + c)         (DESIGN.md section 3).
+template <int MODE>
+__device__ __forceinline__ void row_bound(const double *rs, double N1, int dim, float beta, double &T, double &G) {
+  const double N2 = N1 * N1;
+  if constexpr (MODE == kModeGQ) {
+    const double b = fabs((double)beta), c = (double)half_log_2pi();
+    T = (0.5 * b * dim + 0.5 * rs[0]) * N2 + rs[1] * N1;
+    G = 0.5 * (N2 * rs[0] + 2.0 * N1 * rs[1] + rs[2]) + rs[3] + dim * (c + b * (0.5 * N2 + c));
+  } else {
+    T = dim * N2 + 2.0 * rs[1] * N1;
+    G = 0.0;
+  }
+}
+
+// The reference score with the row operands in registers (same operation order as ref_score_ops).
+template <int DIM>
+__device__ __forceinline__ float ref_score_regs(const float (&n)[DIM], const float (&mu)[DIM], const float (&var2)[DIM],
+                                                const float (&lsd)[DIM], float beta) {
+#pragma clang fp contract(off)
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = k < DIM ? ref_term(n[k], mu[k], var2[k], lsd[k], beta) : 0.0f;
+#pragma unroll
+  for (int i0 = 8; i0 < DIM; i0 += 8)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = acc[k] + ref_term(n[i0 + k], mu[i0 + k], var2[i0 + k], lsd[i0 + k], beta);
+  float s = acc[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+    if (k < DIM) s = s + acc[k];
+  return s;
+}
+
 // GROUP lanes per row, GROUP = codes per candidate (16 * gt): a wave handles 64 / GROUP rows, each lane group
 // walks its row's candidate list one candidate (= GROUP codes, one per lane) at a time.  The kernel is a chain of
-// dependent memory round trips (records -> row operands / code rows -> result), so rows per wave is what sets
-// its duration: 4 rows per wave with the split-bf16 filter's 16-code candidates.
-template <int MODE, int GROUP>
-__global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
+// dependent memory round trips (records -> code rows -> result), so everything a row needs besides the records is in
+// flight at once: the row operands go to REGISTERS (every lane of a group loads its row's mu / sd / log sd as 16-byte
+// broadcast loads), the bound comes from the four sums of gq_prep_kernel (no fp64 division here), and at level 1 the
+// results of a block's consecutive rows leave through LDS as contiguous runs in the module layout.
+constexpr int kCandPad = 3 * kMaxSplit + 17;   // odd-ish stride: the row slots of a wave start in different LDS banks
+template <int MODE, int GROUP, int DIM>
+__device__ __forceinline__ void rerank_block(const RerankParams &p, const int vblock, const int nrows) {
   constexpr int RPW = 64 / GROUP;            // rows per wave
   constexpr int RPB = 4 * RPW;               // rows per block
   constexpr int NSI = kMaxSplit / GROUP;     // record passes per lane (code splits <= kMaxSplit)
-  __shared__ int cand[RPB][3 * kMaxSplit];
-  __shared__ RowOps rops[RPB];
+  __shared__ int cand[RPB][kCandPad];
+  __shared__ float s_zhat[RPB][DIM + 1];
+  __shared__ int s_best[RPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % GROUP, grp = lane / GROUP;
   const int slot = wave * RPW + grp;
-  // level 1: every row; level 2 (cascade): the rows of list A, if there are more than kCascadeMin of them
-  int nrows = p.rows;
-  if (p.level == 2) {
-    nrows = p.hdr->fb_count;
-    if (nrows <= kCascadeMin) return;
-  }
-  const long pos_raw = (long)blockIdx.x * RPB + slot;
-  if ((long)blockIdx.x * RPB + wave * RPW >= nrows) return;          // whole wave past the end
+  const long pos_raw = (long)vblock * RPB + slot;
   const bool live = pos_raw < nrows;
   const long pos_c = live ? pos_raw : nrows - 1;                     // dead groups mirror the last row, write nothing
   const long row = p.level == 2 ? (long)p.fb_list[pos_c] : pos_c;
@@ -208,52 +252,61 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
   const unsigned long long glow = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
   auto group_bits = [&](bool c) { return (__ballot(c) >> gshift) & glow; };
 
-  // ---- rounding bound E(r) -> margin --------------------------------------
-  const double u = 5.9604644775390625e-08;  // 2^-24
-  const double N1 = (double)p.hdr->absmax, N2 = N1 * N1;
-  double T = 0.0, G = 0.0;
-  bool bad = !(N1 == N1) || N1 > 1e18;
-  for (int i = sub; i < p.dim; i += GROUP) {
-    const double m = fabs((double)p.mu[row * p.dim + i]);
-    if constexpr (MODE == kModeGQ) {
-      const double s = (double)p.sd[row * p.dim + i];
-      const double l = p.lsd ? (double)p.lsd[row * p.dim + i] : log(s);
-      const double inv = 1.0 / (s * s);
-      const double b = fabs((double)p.beta);
-      const double t = (0.5 * b + 0.5 * inv) * N2 + m * inv * N1;
-      const double g = (N1 + m) * (N1 + m) * 0.5 * inv + fabs(l) + (double)half_log_2pi() +
-                       b * (0.5 * N2 + (double)half_log_2pi());
-      T += t;
-      G += g;
-      bad = bad || !(s > 0.0) || !(t < 1e30) || !(g < 1e30);
-    } else {
-      const double t = N2 + 2.0 * m * N1;
-      T += t;
-      bad = bad || !(t < 1e30);
-    }
+  // ---- everything the row needs, issued together ---------------------------
+  const float N1f = p.level == 2 ? p.hdr->absmax : wave_absmax(p.hdr, lane);
+  if (p.level == 1 && vblock == 0 && threadIdx.x == 0) p.hdr->absmax = N1f;   // for the tail kernel
+  double rs[4];
+  {
+    const double *q = p.rowsum + row * 4;
+    rs[0] = q[0]; rs[1] = q[1]; rs[2] = q[2]; rs[3] = q[3];
   }
-#pragma unroll
-  for (int o = GROUP / 2; o > 0; o >>= 1) {
-    T += __shfl_xor(T, o);
-    G += __shfl_xor(G, o);
-  }
-  const double Ef = (double)p.ef_coeff * u * T;
-  const double Er = MODE == kModeGQ ? (p.dim + 16.0) * u * G : 1e-12 * T;
-  const double margin = 2.5 * (Ef + Er) + 1e-30;
-  bad = group_bits(bad) != 0ull || !(margin < 1e30);
-
-  // ---- gather the per-split records ----------------------------------------
   const float NEG_INF = -__builtin_inff();
   Rec r[NSI];
-  float fmax = NEG_INF;
 #pragma unroll
   for (int k = 0; k < NSI; ++k) {
     r[k].m1 = r[k].m2 = r[k].m3 = r[k].m4 = NEG_INF;
     r[k].id1 = r[k].id2 = r[k].id3 = 0;
     const int s = k * GROUP + sub;
     if (s < p.nsplit) r[k] = p.rec[(long)s * p.rows + row];
-    fmax = __builtin_fmaxf(fmax, r[k].m1);
   }
+  float mu[DIM], var2[DIM], lsd[DIM];
+  {
+#pragma clang fp contract(off)
+    const f32x4 *pm = reinterpret_cast<const f32x4 *>(p.mu + row * DIM);
+#pragma unroll
+    for (int q = 0; q < DIM / 4; ++q) {
+      const f32x4 v = pm[q];
+      mu[4 * q] = v.x; mu[4 * q + 1] = v.y; mu[4 * q + 2] = v.z; mu[4 * q + 3] = v.w;
+    }
+    if constexpr (MODE == kModeGQ) {
+      const f32x4 *ps = reinterpret_cast<const f32x4 *>(p.sd + row * DIM);
+      const f32x4 *pl = reinterpret_cast<const f32x4 *>(p.lsd + row * DIM);
+#pragma unroll
+      for (int q = 0; q < DIM / 4; ++q) {
+        const f32x4 v = ps[q], w = pl[q];
+        var2[4 * q] = 2.0f * (v.x * v.x); var2[4 * q + 1] = 2.0f * (v.y * v.y);
+        var2[4 * q + 2] = 2.0f * (v.z * v.z); var2[4 * q + 3] = 2.0f * (v.w * v.w);
+        lsd[4 * q] = w.x; lsd[4 * q + 1] = w.y; lsd[4 * q + 2] = w.z; lsd[4 * q + 3] = w.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) var2[i] = lsd[i] = 0.0f;
+    }
+  }
+
+  // ---- rounding bound E(r) -> margin --------------------------------------
+  const double u = 5.9604644775390625e-08;  // 2^-24
+  const double N1 = (double)N1f;
+  double T, G;
+  row_bound<MODE>(rs, N1, DIM, p.beta, T, G);
+  const double Ef = (double)p.ef_coeff * u * T;
+  const double Er = MODE == kModeGQ ? (DIM + 16.0) * u * G : 1e-12 * T;
+  const double margin = 2.5 * (Ef + Er) + 1e-30;
+  bool bad = !(N1 == N1) || N1 > 1e18 || !(T < 1e30) || !(G < 1e30) || !(margin < 1e30);
+
+  float fmax = NEG_INF;
+#pragma unroll
+  for (int k = 0; k < NSI; ++k) fmax = __builtin_fmaxf(fmax, r[k].m1);
 #pragma unroll
   for (int o = GROUP / 2; o > 0; o >>= 1) fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, o));
   bad = bad || !(fmax == fmax) || !(fmax > NEG_INF) || !(fmax < __builtin_inff());
@@ -283,7 +336,6 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
     }
     total = 0;
   }
-  for (int i = sub; i < p.dim; i += GROUP) load_row_ops(p, row, i, rops[slot]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -298,7 +350,16 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
       const int tile = (id >> 1) * p.gt + (sub >> 4);
       const int code = tile * kTileCodes + (sub & 3) + 8 * ((sub & 15) >> 2) + 4 * (id & 1);
       if (code < p.n) {
-        const double s = exact_score<MODE>(p, rops[slot], code);
+        float n[DIM];
+        const f32x4 *pn = reinterpret_cast<const f32x4 *>(p.cb + (long)code * DIM);
+#pragma unroll
+        for (int q = 0; q < DIM / 4; ++q) {
+          const f32x4 v = pn[q];
+          n[4 * q] = v.x; n[4 * q + 1] = v.y; n[4 * q + 2] = v.z; n[4 * q + 3] = v.w;
+        }
+        double s;
+        if constexpr (MODE == kModeGQ) s = (double)ref_score_regs<DIM>(n, mu, var2, lsd, p.beta);
+        else s = vq_neg_dist(n, mu, DIM);
         if (!have || better_d(s, code, best_s, best_i)) {
           best_s = s;
           best_i = code;
@@ -318,12 +379,39 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
       have = true;
     }
   }
-  if (!live || undecided) return;
-  if (p.stats && sub == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)total);
-  if (sub == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best_i;
-  if (p.zhat)
-    for (int i = sub; i < p.dim; i += GROUP)
-      p.zhat[out_zhat_offset(p.omap, row, i, p.dim)] = p.cb[(long)best_i * p.dim + i];
+  const bool decided = live && !undecided;
+  if (p.stats && decided && sub == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)total);
+  if (p.level == 2) {   // listed rows are scattered: write directly
+    if (decided) {
+      if (sub == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best_i;
+      if (p.zhat)
+        for (int i = sub; i < DIM; i += GROUP)
+          p.zhat[out_zhat_offset(p.omap, row, i, DIM)] = p.cb[(long)best_i * DIM + i];
+    }
+    return;
+  }
+  // level 1: the block's RPB consecutive rows leave as contiguous runs (BCHW: along l per channel)
+  if (sub == 0) s_best[slot] = decided ? best_i : -1;
+  if (p.zhat && decided)
+    for (int i = sub; i < DIM; i += GROUP) s_zhat[slot][i] = p.cb[(long)best_i * DIM + i];
+  __syncthreads();
+  const long row0 = (long)vblock * RPB;
+  if (threadIdx.x < RPB) {
+    const int b = s_best[threadIdx.x];
+    if (b >= 0) p.idx[out_idx_offset(p.omap, row0 + threadIdx.x)] = (int64_t)b;
+  }
+  if (p.zhat) {
+    for (int j = threadIdx.x; j < RPB * DIM; j += 256) {
+      int lr, g;
+      if (p.omap.mode == 1) { lr = j % RPB; g = j / RPB; } else { lr = j / DIM; g = j % DIM; }
+      if (s_best[lr] >= 0) p.zhat[out_zhat_offset(p.omap, row0 + lr, g, DIM)] = s_zhat[lr][g];
+    }
+  }
+}
+
+template <int MODE, int GROUP, int DIM>
+__global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
+  rerank_block<MODE, GROUP, DIM>(p, (int)blockIdx.x, p.rows);
 }
 
 // Second-stage filter for the rows the fp32 filter could not decide (fallback list).
@@ -340,7 +428,7 @@ __global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
 constexpr int kFallbackRows = 8;
 
 template <int MODE, int DIM>
-__device__ __forceinline__ void fallback64_long_list(const RerankParams &p) {
+__device__ __forceinline__ void fallback64_long_list(const RerankParams &p, const int vblock, const int nvblocks) {
   constexpr int FR = kFallbackRows;
   __shared__ RowOps rops[FR];
   __shared__ double sh_d[8];
@@ -351,13 +439,13 @@ __device__ __forceinline__ void fallback64_long_list(const RerankParams &p) {
   second_stage_list(p, list, count);
   // Many listed rows: 8 rows per block (a half-wave each).  Few: the whole block on ONE row, so a
   // lone fallback row costs ~60 us instead of ~3 ms.
-  const bool wide = count < 4 * (int)gridDim.x;       // block-uniform
+  const bool wide = count < 4 * nvblocks;              // block-uniform
   const int R = wide ? 1 : FR;
   const int r = wide ? 0 : tid >> 5;                   // row slot
   const int cl = wide ? tid : tid & 31;                // code lane
   const int cstride = wide ? 256 : 32;
   const double INF = __builtin_inf();
-  for (int grp = blockIdx.x; grp * R < count; grp += gridDim.x) {
+  for (int grp = vblock; grp * R < count; grp += nvblocks) {
     const int nrow = min(R, count - grp * R);
     const bool live = r < nrow;
     const long row = live ? list[grp * R + r] : 0;
@@ -485,7 +573,7 @@ __device__ __forceinline__ void fallback64_long_list(const RerankParams &p) {
 constexpr int kSpreadCodes = 16;    // codes per thread held in registers (slice <= 256 * kSpreadCodes codes)
 
 template <int MODE, int DIM>
-__device__ __forceinline__ void fallback64_spread(const RerankParams &p) {
+__device__ __forceinline__ void fallback64_spread(const RerankParams &p, const int vblock) {
   __shared__ RowOps rops;
   __shared__ double sh_d[4];
   __shared__ int sh_i[4];
@@ -493,7 +581,7 @@ __device__ __forceinline__ void fallback64_spread(const RerankParams &p) {
   const int *list;
   int count;
   second_stage_list(p, list, count);
-  const int e = blockIdx.x / kSpreadSlices, sl = blockIdx.x % kSpreadSlices;
+  const int e = vblock / kSpreadSlices, sl = vblock % kSpreadSlices;
   if (e >= count) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long row = list[e];
@@ -648,18 +736,57 @@ __device__ __forceinline__ void fallback64_spread(const RerankParams &p) {
   }
 }
 
-// The second stage as ONE launch: the list length (known only on the device) picks the variant.
-// Grid: max(listed-row capacity of the spread variant x slices, row groups of the long-list variant), <= 2048 blocks.
+// The fp64 second stage: the list length (known only on the device) picks the variant.  Any grid size works
+// (both variants walk virtual blocks).
 template <int MODE, int DIM>
-__global__ __launch_bounds__(256, 2) void gq_fallback64_kernel(const RerankParams p) {
+__device__ __forceinline__ void second_stage(const RerankParams &p) {
   const int *list;
   int count;
   second_stage_list(p, list, count);
   if (count == 0) return;
-  if (count <= kSpreadRows && count * kSpreadSlices <= (int)gridDim.x)
-    fallback64_spread<MODE, DIM>(p);
-  else
-    fallback64_long_list<MODE, DIM>(p);
+  if (count <= kSpreadRows) {
+    for (int vb = blockIdx.x; vb < count * kSpreadSlices; vb += gridDim.x) {
+      fallback64_spread<MODE, DIM>(p, vb);
+      __syncthreads();
+    }
+  } else {
+    fallback64_long_list<MODE, DIM>(p, (int)blockIdx.x, (int)gridDim.x);
+  }
+}
+
+// Grid barrier of the tail kernel (all blocks co-resident: the host sizes the grid with the occupancy API).
+// Producer side: every wave drains its stores, the block meets, lane 0 releases at agent scope and arrives;
+// consumer side: relaxed agent-scope poll, ONE acquire, block barrier (MI355X_MICROARCH.md, inter-workgroup
+// visibility: per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores).
+__device__ __forceinline__ void grid_barrier(WsHeader *hdr, unsigned nblocks) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned gen = __hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned arrived = __hip_atomic_fetch_add(&hdr->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == nblocks - 1) {
+      __hip_atomic_store(&hdr->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&hdr->bar_gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // bounded (MI355X_MICROARCH.md: "bound every spin"): ~4 s, orders of magnitude beyond any real wait; if the
+      // grid were ever not co-resident the call ends with wrong rows flagged in the header instead of a hung GPU
+      long spins = 0;
+      while (__hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1L << 24)) {
+          hdr->bar_timeout = 1;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
 }
 
 // Exhaustive exact arg-max: one block per listed row (grid-stride over the

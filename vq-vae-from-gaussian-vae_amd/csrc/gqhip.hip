@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -15,7 +16,9 @@
 #include "gq_common.h"
 #include "gq_filter.h"
 #include "gq_filter_bf16.h"
+#include "gq_prep.h"
 #include "gq_rerank.h"
+#include "gq_tail.h"
 
 using namespace gqhip;
 
@@ -102,7 +105,7 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WsLayout {
-  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, cbimg, rowimg, total;
+  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, rowsum, cbimg, rowimg, total;
 };
 
 WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
@@ -119,6 +122,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.mu = off;  off += align256(4 * rows * dim);
   w.sd = off;  off += align256(4 * rows * dim);
   w.lsd = off; off += align256(4 * rows * dim);
+  w.rowsum = off; off += pl.mfma ? align256(8 * 4 * rows) : 0;
   // split-bf16 operand images: 2*NV vectors of 16 B per (code, half) / (row, half), NV = dim / 8
   const int64_t nvec = dim == 4 ? 2 : dim / 4;
   w.cbimg = off;  off += pl.bf16 ? align256((int64_t)(pl.tiles_total + pl.ct) * nvec * 64 * 16) : 0;
@@ -131,20 +135,24 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 int g_debug_stats = 0;
-std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;   // attached to a dispatch, not yet collected
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;     // created ahead of time (gqhip_profile_reserve)
 
 // When profiling is on, the filter is launched through hipExtLaunchKernelGGL with a start and a
 // stop event attached to the dispatch itself, so the elapsed time is the kernel's own duration on
-// its stream (what rocprofv3 --kernel-trace reports), not a marker-to-marker bracket.
+// its stream (what rocprofv3 --kernel-trace reports), not a marker-to-marker bracket.  The event pairs
+// come from a pool filled by gqhip_profile_reserve(): nothing is created on the launch path, and a
+// launch that finds the pool empty simply is not recorded.
 struct ProfScope {
   hipEvent_t a = nullptr, b = nullptr;
-  bool on;
+  bool on = false;
   explicit ProfScope(bool enable = true) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    on = g_prof_on && enable;
-    if (on) {
-      (void)hipEventCreate(&a);
-      (void)hipEventCreate(&b);
+    if (g_prof_on && enable && !g_prof_pool.empty()) {
+      a = g_prof_pool.back().first;
+      b = g_prof_pool.back().second;
+      g_prof_pool.pop_back();
+      on = true;
     }
   }
   ~ProfScope() {
@@ -187,31 +195,32 @@ int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t s
   return check_launch();
 }
 
-// re-rank: GROUP = codes per candidate = lanes per row
+// re-rank: GROUP = codes per candidate = lanes per row (16 * gt); DIM in registers
 template <int MODE>
-void launch_rerank(const RerankParams &rp, int64_t rows, hipStream_t st) {
-  if (rp.gt == 1)
-    hipLaunchKernelGGL((gq_rerank_kernel<MODE, 16>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, rp);
-  else if (rp.gt == 2)
-    hipLaunchKernelGGL((gq_rerank_kernel<MODE, 32>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, rp);
-  else
-    hipLaunchKernelGGL((gq_rerank_kernel<MODE, 64>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rp);
+int launch_rerank(const RerankParams &rp, int64_t rows, int dim, hipStream_t st) {
+#define GQ_RR(G, D)                                                                                     \
+  hipLaunchKernelGGL((gq_rerank_kernel<MODE, G, D>), dim3((unsigned)((rows + (256 / G) - 1) / (256 / G))), \
+                     dim3(256), 0, st, rp)
+  const int key = rp.gt * 100 + dim;
+  switch (key) {
+    case 104: GQ_RR(16, 4); break;
+    case 108: GQ_RR(16, 8); break;
+    case 116: GQ_RR(16, 16); break;
+    case 132: GQ_RR(16, 32); break;
+    case 216: GQ_RR(32, 16); break;
+    case 232: GQ_RR(32, 32); break;
+    case 404: GQ_RR(64, 4); break;
+    case 408: GQ_RR(64, 8); break;
+    default: return GQHIP_ERR_INVALID_ARG;
+  }
+#undef GQ_RR
+  return check_launch();
 }
 
 template <int MODE>
-int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitParams &sp, int dim, hipStream_t st) {
-  const long split_threads = (long)pl.tiles_total * 64 + (long)sp.rows * 2;
-  const dim3 sgrid((unsigned)((split_threads + 255) / 256)), grid((unsigned)(pl.row_blocks * pl.nsplit)), block(256);
+int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, hipStream_t st) {
+  const dim3 grid((unsigned)(pl.row_blocks * pl.nsplit));
   const dim3 fblock((unsigned)(64 * pl.waves));
-  switch (dim) {
-    case 4: hipLaunchKernelGGL((bf16_split_kernel<MODE, 4>), sgrid, block, 0, st, sp); break;
-    case 8: hipLaunchKernelGGL((bf16_split_kernel<MODE, 8>), sgrid, block, 0, st, sp); break;
-    case 16: hipLaunchKernelGGL((bf16_split_kernel<MODE, 16>), sgrid, block, 0, st, sp); break;
-    case 32: hipLaunchKernelGGL((bf16_split_kernel<MODE, 32>), sgrid, block, 0, st, sp); break;
-    default: return GQHIP_ERR_INVALID_ARG;
-  }
-  int rc = check_launch();
-  if (rc != GQHIP_OK) return rc;
   ProfScope prof;
 #define GQ_LAUNCH_BF1(NV, R, C, G, W)                                                                       \
   do {                                                                                                    \
@@ -225,7 +234,6 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitPara
     if (pl.waves == 8 && pl.gt == 4) GQ_LAUNCH_BF1(NV, R, C, 4, 8);                                       \
     else if (pl.waves == 8) GQ_LAUNCH_BF1(NV, R, C, 1, 8);                                                \
     else if (pl.gt == 1) GQ_LAUNCH_BF1(NV, R, C, 1, 4);                                                   \
-    else if (pl.gt == 2) GQ_LAUNCH_BF1(NV, R, C, 2, 4);                                                   \
     else GQ_LAUNCH_BF1(NV, R, C, 4, 4);                                                                   \
   } while (0)
   if (pl.rt == 2) {
@@ -248,31 +256,90 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, const SplitPara
   return check_launch();
 }
 
-// filter -> re-rank -> exhaustive, shared by GQ and VQ.
+// Grid of the tail kernel: every block must be co-resident (it contains grid barriers on the cascade path), so it
+// is sized from the device: min(occupancy API, 2) blocks per CU x CU count, cached per (device, kernel).
+int tail_grid(const void *kernel) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, int> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({dev, kernel});
+  if (it != cache.end()) return it->second;
+  int cus = 0, nb = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) return 0;
+  const int grid = cus * (nb < 2 ? nb : 2);
+  cache[{dev, kernel}] = grid;
+  return grid;
+}
+
 template <int MODE>
-int run_argmax(const float *mu, const float *sd, const float *lsd, const float *cb, int64_t *idx,
-               float *zhat, int64_t dim, int64_t rows, int64_t n, double beta, float cb_absmax,
-               void *workspace, int64_t workspace_bytes, const OutMap &omap, hipStream_t st) {
+int launch_tail(const RerankParams &rp, const FilterParams &f2, int dim, hipStream_t st) {
+#define GQ_TAIL(D)                                                                               \
+  do {                                                                                           \
+    const int g = tail_grid(reinterpret_cast<const void *>(&gq_tail_kernel<MODE, D>));            \
+    if (g < 1) return GQHIP_ERR_LAUNCH;                                                          \
+    hipLaunchKernelGGL((gq_tail_kernel<MODE, D>), dim3((unsigned)g), dim3(256), 0, st, rp, f2);  \
+  } while (0)
+  switch (dim) {
+    case 4: GQ_TAIL(4); break;
+    case 8: GQ_TAIL(8); break;
+    case 16: GQ_TAIL(16); break;
+    case 32: GQ_TAIL(32); break;
+    default: return GQHIP_ERR_INVALID_ARG;
+  }
+#undef GQ_TAIL
+  return check_launch();
+}
+
+// What the first launch reads: either z in the module layout (FROM_Z) or ready-made rows.
+struct PrepInput {
+  const float *z = nullptr, *noise = nullptr;
+  float *zhat_noquant = nullptr;
+  float lv_min = 0.f, lv_max = 0.f;
+  float *mu_out = nullptr, *sd_out = nullptr;   // FROM_Z: optional copies of the row operands for the caller
+};
+
+template <int MODE, bool FROM_Z>
+int launch_prep(const PrepParams &pp, int dim, hipStream_t st) {
+  const dim3 grid((unsigned)(pp.row_blocks + kPrepCodeBlocks));
+  switch (dim) {
+    case 4: hipLaunchKernelGGL((gq_prep_kernel<MODE, 4, FROM_Z>), grid, dim3(256), 0, st, pp); break;
+    case 8: hipLaunchKernelGGL((gq_prep_kernel<MODE, 8, FROM_Z>), grid, dim3(256), 0, st, pp); break;
+    case 16: hipLaunchKernelGGL((gq_prep_kernel<MODE, 16, FROM_Z>), grid, dim3(256), 0, st, pp); break;
+    case 32: hipLaunchKernelGGL((gq_prep_kernel<MODE, 32, FROM_Z>), grid, dim3(256), 0, st, pp); break;
+    default: return GQHIP_ERR_INVALID_ARG;
+  }
+  return check_launch();
+}
+
+// prep -> filter -> re-rank -> tail (MFMA dims) | prep -> exhaustive (other dims), shared by GQ and VQ.
+// Four launches per call; nothing derived from the codebook or the rows survives the call.
+template <int MODE>
+int run_argmax(const PrepInput &in, const float *mu, const float *sd, const float *lsd, const float *cb, int64_t *idx,
+               float *zhat, int64_t dim, int64_t rows, int64_t n, double beta, void *workspace,
+               int64_t workspace_bytes, const OutMap &omap, hipStream_t st) {
   if (dim < 1 || dim > kMaxDim || rows < 0 || n < 1 || n > 0x3fffffff || rows > 0x3fffffff)
     return GQHIP_ERR_INVALID_ARG;
   if (rows == 0) return GQHIP_OK;   // empty batch: nothing to do (pointers may be NULL)
-  if (!mu || !cb || !idx || (MODE == kModeGQ && !sd)) return GQHIP_ERR_INVALID_ARG;
+  const bool from_z = in.z != nullptr;
+  if (!cb || !idx || (!from_z && (!mu || (MODE == kModeGQ && !sd)))) return GQHIP_ERR_INVALID_ARG;
   const WsLayout w = ws_layout(rows, n, dim);
   if (!workspace || workspace_bytes < w.total) return GQHIP_ERR_WORKSPACE;
   char *ws = static_cast<char *>(workspace);
   WsHeader *hdr = reinterpret_cast<WsHeader *>(ws + w.hdr);
   const Plan pl = make_plan(rows, n, dim);
-
-  auto launch_absmax = [&]() {
-    const long count = (long)n * dim;
-    const int blocks = (int)((count + 256 * 16 - 1) / (256 * 16));
-    hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(256), 0,
-                       st, cb, count, &hdr->absmax);
-  };
-  const bool need_absmax = !(cb_absmax > 0.f);
+  float *ws_mu = reinterpret_cast<float *>(ws + w.mu), *ws_sd = reinterpret_cast<float *>(ws + w.sd);
+  float *ws_lsd = reinterpret_cast<float *>(ws + w.lsd);
+  // the rows every later kernel reads
+  const float *r_mu = from_z ? (in.mu_out ? in.mu_out : ws_mu) : mu;
+  const float *r_sd = from_z ? (in.sd_out ? in.sd_out : ws_sd) : sd;
+  const float *r_lsd = from_z ? ws_lsd : (MODE == kModeGQ ? (lsd ? lsd : (pl.mfma ? ws_lsd : nullptr)) : nullptr);
 
   RerankParams rp{};
-  rp.mu = mu; rp.sd = sd; rp.lsd = lsd; rp.cb = cb;
+  rp.mu = r_mu; rp.sd = r_sd; rp.lsd = r_lsd; rp.cb = cb;
+  rp.rowsum = reinterpret_cast<const double *>(ws + w.rowsum);
   rp.rec = reinterpret_cast<const Rec *>(ws + w.rec);
   rp.idx = idx; rp.zhat = zhat; rp.hdr = hdr;
   rp.fb_list = reinterpret_cast<int *>(ws + w.fb);
@@ -287,81 +354,83 @@ int run_argmax(const float *mu, const float *sd, const float *lsd, const float *
   rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
 
+  if (!pl.mfma) {
+    // dims outside {4, 8, 16, 32}: exact score of every code (gq_exhaustive_kernel)
+    if (from_z) {
+      PrepPlainParams pq{};
+      pq.z = in.z; pq.noise = in.noise; pq.zhat_noquant = in.zhat_noquant;
+      pq.mu = const_cast<float *>(r_mu); pq.sd = const_cast<float *>(r_sd); pq.lsd = ws_lsd;
+      pq.rows = rows; pq.dim = (int)dim; pq.lv_min = in.lv_min; pq.lv_max = in.lv_max; pq.omap = omap;
+      hipLaunchKernelGGL(prep_plain_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, st, pq);
+      const int rc = check_launch();
+      if (rc != GQHIP_OK) return rc;
+    }
+    if (hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
+    const int ex_blocks = (int)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL((gq_exhaustive_kernel<MODE>), dim3((unsigned)ex_blocks), dim3(256), 0, st, rp);
+    return check_launch();
+  }
+
+  // ---- launch 1: rows (+ zhat_noquant), operand images, bound sums, max|cb| partials, header -------------------
+  PrepParams pp{};
+  pp.z = in.z; pp.noise = in.noise; pp.zhat_noquant = in.zhat_noquant; pp.lv_min = in.lv_min; pp.lv_max = in.lv_max;
+  pp.mu = const_cast<float *>(r_mu); pp.sd = const_cast<float *>(r_sd);
+  pp.lsd = const_cast<float *>(from_z ? ws_lsd : lsd);
+  pp.lsd_out = (!from_z && MODE == kModeGQ && !lsd) ? ws_lsd : nullptr;
+  pp.rowsum = reinterpret_cast<double *>(ws + w.rowsum);
+  pp.rowimg = pl.bf16 ? reinterpret_cast<u32x4 *>(ws + w.rowimg) : nullptr;
+  pp.cb = cb;
+  pp.cbimg = pl.bf16 ? reinterpret_cast<u32x4 *>(ws + w.cbimg) : nullptr;
+  pp.hdr = hdr; pp.rows = rows; pp.n = (int)n; pp.tiles_total = pl.tiles_total;
+  pp.row_blocks = (int)((rows * dim + 255) / 256);
+  pp.beta = (float)beta; pp.omap = omap;
+  int rc = from_z ? launch_prep<MODE, true>(pp, (int)dim, st) : launch_prep<MODE, false>(pp, (int)dim, st);
+  if (rc != GQHIP_OK) return rc;
+
+  // ---- launch 2: the filter ---------------------------------------------------------------------------------
+  FilterParams f2{};   // second level of the cascade (tail kernel); unused behind the fp32 filter
   if (pl.bf16) {
-    SplitParams sp{};
-    sp.mu = mu; sp.sd = sd; sp.cb = cb;
-    sp.cbimg = reinterpret_cast<u32x4 *>(ws + w.cbimg); sp.rowimg = reinterpret_cast<u32x4 *>(ws + w.rowimg);
-    sp.rows = (int)rows; sp.n = (int)n; sp.tiles_total = pl.tiles_total; sp.beta = (float)beta;
     FilterBfParams fp{};
-    fp.cbimg = sp.cbimg; fp.rowimg = sp.rowimg;
+    fp.cbimg = pp.cbimg; fp.rowimg = pp.rowimg;
     fp.rec = reinterpret_cast<Rec *>(ws + w.rec);
     fp.rows = (int)rows; fp.n = (int)n;
     fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
-    fp.hdr = hdr; fp.absmax = cb_absmax;
-    fp.dbg = ws + w.mu;   // scratch rows area (unused by gq_argmax_f32); read by diagnostic builds only
-    if (need_absmax && hipMemsetAsync(&hdr->absmax, 0, sizeof(float), st) != hipSuccess) return check_launch();
-    int rc = launch_filter_bf16<MODE>(pl, fp, sp, (int)dim, st);
-    if (rc != GQHIP_OK) return rc;
-    if (need_absmax) launch_absmax();
-    launch_rerank<MODE>(rp, rows, st);
-    rc = check_launch();
+    fp.hdr = hdr;
+    fp.dbg = ws + w.rec2;   // diagnostic builds only (the cascade's records: unused until the tail kernel)
+    rc = launch_filter_bf16<MODE>(pl, fp, (int)dim, st);
     if (rc != GQHIP_OK) return rc;
     // Cascade: when more than kCascadeMin rows are undecided (ill-conditioned inputs: the split-bf16 margin is ~16x
-    // the fp32 one), they go through the fp32 MFMA filter + re-rank before the fp64 second stage.  Both launches
-    // read the list length on the device and return at once when it is short.
-    FilterParams f2{};
-    f2.mu = mu; f2.sd = sd; f2.cb = cb;
+    // the fp32 one), the tail kernel sends them through the fp32 MFMA filter + re-rank before the fp64 second stage.
+    f2.mu = r_mu; f2.sd = r_sd; f2.cb = cb;
     f2.rec = reinterpret_cast<Rec *>(ws + w.rec2);
     f2.rows = (int)rows; f2.n = (int)n; f2.beta = (float)beta;
     f2.nsplit = pl.nsplit2; f2.tiles_total = pl.tiles_total; f2.tiles_per_split = pl.tiles_per_split2;
-    f2.hdr = hdr; f2.absmax = 0.f; f2.dbg = nullptr;
+    f2.hdr = hdr; f2.dbg = nullptr;
     f2.row_list = rp.fb_list; f2.row_count = &hdr->fb_count; f2.min_count = kCascadeMin;
-    Plan p2 = pl;
-    p2.rt = 1; p2.rows_per_block = 128; p2.row_blocks = (int)((rows + 127) / 128); p2.nsplit = pl.nsplit2;
-    rc = launch_filter<MODE>(p2, f2, (int)dim, st, /*profile=*/false);
-    if (rc != GQHIP_OK) return rc;
-    RerankParams r2 = rp;
-    r2.rec = reinterpret_cast<const Rec *>(ws + w.rec2);
-    r2.nsplit = pl.nsplit2; r2.gt = pl.gt2; r2.ef_coeff = (float)(2 * dim + 4); r2.level = 2;
-    launch_rerank<MODE>(r2, rows, st);
-    rc = check_launch();
-    if (rc != GQHIP_OK) return rc;
-  } else if (pl.mfma) {
+  } else {
     FilterParams fp{};
-    fp.mu = mu; fp.sd = sd; fp.cb = cb;
+    fp.mu = r_mu; fp.sd = r_sd; fp.cb = cb;
     fp.rec = reinterpret_cast<Rec *>(ws + w.rec);
     fp.rows = (int)rows; fp.n = (int)n; fp.beta = (float)beta;
     fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
-    fp.hdr = hdr; fp.absmax = cb_absmax;
-    fp.dbg = ws + w.mu;   // scratch rows area (unused by gq_argmax_f32); read by diagnostic builds only
-    if (need_absmax && hipMemsetAsync(&hdr->absmax, 0, sizeof(float), st) != hipSuccess) return check_launch();
-    int rc = launch_filter<MODE>(pl, fp, (int)dim, st);
-    if (rc != GQHIP_OK) return rc;
-    if (need_absmax) launch_absmax();   // after the filter (it owns the header init), before the re-rank
-    launch_rerank<MODE>(rp, rows, st);
-    rc = check_launch();
+    fp.hdr = hdr;
+    fp.dbg = ws + w.spread;   // diagnostic builds only
+    rc = launch_filter<MODE>(pl, fp, (int)dim, st);
     if (rc != GQHIP_OK) return rc;
   }
-  if (pl.mfma) {
-    // rows the filter could not decide: fp64 second-stage filter + exact re-rank (usually none or a handful).
-    // One launch; on the device the list length picks the variant: short lists are spread over kSpreadSlices blocks
-    // per row, long ones take 8 rows per block.
-    const int64_t groups = (rows + kFallbackRows - 1) / kFallbackRows;
-    const int64_t sp_rows = rows < kSpreadRows ? rows : kSpreadRows;
-    int64_t fb_blocks = groups > sp_rows * kSpreadSlices ? groups : sp_rows * kSpreadSlices;
-    if (fb_blocks > 2048) fb_blocks = 2048;
-    switch (dim) {
-      case 4: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 4>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
-      case 8: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 8>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
-      case 16: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 16>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
-      default: hipLaunchKernelGGL((gq_fallback64_kernel<MODE, 32>), dim3((unsigned)fb_blocks), dim3(256), 0, st, rp); break;
-    }
-    return check_launch();
+
+  // ---- launch 3: exact re-rank of the candidates ----------------------------------------------------------------
+  rc = launch_rerank<MODE>(rp, rows, (int)dim, st);
+  if (rc != GQHIP_OK) return rc;
+
+  // ---- launch 4: the tail (returns at once when every row was decided) ------------------------------------------
+  RerankParams r2 = rp;
+  if (pl.bf16) {
+    r2.rec = reinterpret_cast<const Rec *>(ws + w.rec2);
+    r2.nsplit = pl.nsplit2; r2.gt = pl.gt2; r2.ef_coeff = (float)(2 * dim + 4);
   }
-  if (hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
-  const int ex_blocks = (int)(rows < 4096 ? rows : 4096);
-  hipLaunchKernelGGL((gq_exhaustive_kernel<MODE>), dim3((unsigned)ex_blocks), dim3(256), 0, st, rp);
-  return check_launch();
+  r2.level = 2;
+  return launch_tail<MODE>(r2, f2, (int)dim, st);
 }
 
 }  // namespace
@@ -405,17 +474,6 @@ int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim) {
   return ws_layout(rows < 1 ? 1 : rows, n, dim).total;
 }
 
-int gqhip_codebook_absmax(const float *cb, int64_t n, int64_t dim, float *absmax_out, void *stream) {
-  if (!cb || !absmax_out || n < 1 || dim < 1) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(absmax_out, 0, sizeof(float), st) != hipSuccess) return check_launch();
-  const long count = (long)n * dim;
-  int blocks = (int)((count + 256 * 16 - 1) / (256 * 16));
-  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, cb, count, absmax_out);
-  return check_launch();
-}
-
 int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out, int64_t dim,
                   int64_t rows, int64_t n, double beta, void *stream) {
   if (dim < 1 || rows < 0 || n < 1 || n > 0x7fffffff || rows > 0x7fffffff) return GQHIP_ERR_INVALID_ARG;
@@ -451,46 +509,36 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
 
 int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null, const float *cb,
                   int64_t *idx, float *zhat_or_null, int64_t dim, int64_t rows, int64_t n, double beta,
-                  float cb_absmax, void *workspace, int64_t workspace_bytes, void *stream) {
+                  void *workspace, int64_t workspace_bytes, void *stream) {
   OutMap om{};
-  om.mode = 0;
-  return run_argmax<kModeGQ>(mu, sd, logsd_or_null, cb, idx, zhat_or_null, dim, rows, n, beta, cb_absmax,
+  om.mode = 0; om.K = 1; om.L = 1; om.c = (int)dim;
+  return run_argmax<kModeGQ>(PrepInput{}, mu, sd, logsd_or_null, cb, idx, zhat_or_null, dim, rows, n, beta,
                              workspace, workspace_bytes, om, static_cast<hipStream_t>(stream));
 }
 
-int gq_quantize_z_f32(const float *z, const float *cb, int64_t *idx, float *zhat_or_null,
-                      float *mu_out_or_null, float *sd_out_or_null, int64_t B, int64_t L, int64_t c,
-                      int64_t dim, int64_t n, int layout, int grouping, double lv_min, double lv_max,
-                      double beta, float cb_absmax, void *workspace, int64_t workspace_bytes,
-                      void *stream) {
+int gq_quantize_z_f32(const float *z, const float *noise_or_null, const float *cb, int64_t *idx,
+                      float *zhat_or_null, float *zhat_noquant_or_null, float *mu_out_or_null,
+                      float *sd_out_or_null, int64_t B, int64_t L, int64_t c, int64_t dim, int64_t n, int layout,
+                      int grouping, double lv_min, double lv_max, double beta, void *workspace,
+                      int64_t workspace_bytes, void *stream) {
   if (!z || !cb || !idx || B < 0 || L < 1 || c < 1 || dim < 1 || dim > kMaxDim || c % dim != 0)
     return GQHIP_ERR_INVALID_ARG;
   if ((layout != GQHIP_LAYOUT_BCHW && layout != GQHIP_LAYOUT_BLC) ||
       (grouping != GQHIP_GROUP_STRIDED && grouping != GQHIP_GROUP_CONTIGUOUS))
     return GQHIP_ERR_INVALID_ARG;
+  if (zhat_noquant_or_null && !noise_or_null) return GQHIP_ERR_INVALID_ARG;
   const int64_t K = c / dim, rows = B * L * K;
   if (rows == 0) return GQHIP_OK;
   if (rows > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
-  const WsLayout w = ws_layout(rows, n, dim);
-  if (!workspace || workspace_bytes < w.total) return GQHIP_ERR_WORKSPACE;
-  char *ws = static_cast<char *>(workspace);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  PrepParams pp{};
-  pp.z = z;
-  pp.mu = mu_out_or_null ? mu_out_or_null : reinterpret_cast<float *>(ws + w.mu);
-  pp.sd = sd_out_or_null ? sd_out_or_null : reinterpret_cast<float *>(ws + w.sd);
-  pp.lsd = reinterpret_cast<float *>(ws + w.lsd);
-  pp.rows = rows; pp.dim = (int)dim; pp.K = (int)K; pp.L = (int)L; pp.c = (int)c;
-  pp.layout = layout; pp.grouping = grouping;
-  pp.lv_min = (float)lv_min; pp.lv_max = (float)lv_max;
-  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, st, pp);
-  int rc = check_launch();
-  if (rc != GQHIP_OK) return rc;
+  PrepInput in;
+  in.z = z; in.noise = noise_or_null; in.zhat_noquant = zhat_noquant_or_null;
+  in.lv_min = (float)lv_min; in.lv_max = (float)lv_max;
+  in.mu_out = mu_out_or_null; in.sd_out = sd_out_or_null;
   OutMap om{};
   om.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
   om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = grouping;
-  return run_argmax<kModeGQ>(pp.mu, pp.sd, pp.lsd, cb, idx, zhat_or_null, dim, rows, n, beta, cb_absmax,
-                             workspace, workspace_bytes, om, st);
+  return run_argmax<kModeGQ>(in, nullptr, nullptr, nullptr, cb, idx, zhat_or_null, dim, rows, n, beta, workspace,
+                             workspace_bytes, om, static_cast<hipStream_t>(stream));
 }
 
 int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B, int64_t L, int64_t K,
@@ -508,12 +556,11 @@ int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B, 
 }
 
 int vq_argmin_f32(const float *z, const float *emb, int64_t *idx, float *zq_or_null, int64_t dim,
-                  int64_t rows, int64_t n, float emb_absmax, void *workspace, int64_t workspace_bytes,
-                  void *stream) {
+                  int64_t rows, int64_t n, void *workspace, int64_t workspace_bytes, void *stream) {
   OutMap om{};
-  om.mode = 0;
-  return run_argmax<kModeVQ>(z, nullptr, nullptr, emb, idx, zq_or_null, dim, rows, n, 0.0, emb_absmax,
-                             workspace, workspace_bytes, om, static_cast<hipStream_t>(stream));
+  om.mode = 0; om.K = 1; om.L = 1; om.c = (int)dim;
+  return run_argmax<kModeVQ>(PrepInput{}, z, nullptr, nullptr, emb, idx, zq_or_null, dim, rows, n, 0.0, workspace,
+                             workspace_bytes, om, static_cast<hipStream_t>(stream));
 }
 
 int lfq_pack_f32(const float *x, int64_t *idx, float *q_or_null, int64_t rows, int64_t nbits,
@@ -876,6 +923,26 @@ int gq_indices_from_u16(const uint16_t *in, int64_t *idx, int64_t count, void *s
 int gqhip_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
+  if (g_prof_on && g_prof_pool.empty()) {   // callers that never reserve still get a (small) pool
+    for (int i = 0; i < 64; ++i) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess) break;
+      if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); break; }
+      g_prof_pool.emplace_back(a, b);
+    }
+  }
+  return GQHIP_OK;
+}
+
+int gqhip_profile_reserve(int pairs) {
+  if (pairs < 0) return GQHIP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  while ((int)g_prof_pool.size() < pairs) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return check_launch();
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return check_launch(); }
+    g_prof_pool.emplace_back(a, b);
+  }
   return GQHIP_OK;
 }
 
@@ -899,8 +966,10 @@ int gqhip_profile_collect(int *launches_host, double *total_ms_host) {
       total += ms;
       ++cnt;
     }
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &pr : ev) g_prof_pool.push_back(pr);   // recycled: the next profiled region creates nothing
   }
   if (launches_host) *launches_host = cnt;
   if (total_ms_host) *total_ms_host = total;
@@ -914,7 +983,7 @@ int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
   if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
   if (fallback_rows_host) *fallback_rows_host = h.fb_count;
   if (reranked_halftiles_host) *reranked_halftiles_host = (int64_t)h.reranked;
-  return GQHIP_OK;
+  return h.bar_timeout ? GQHIP_ERR_LAUNCH : GQHIP_OK;   // a tail-kernel grid barrier gave up (never expected)
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
 LIB_PATH = os.environ.get("GQHIP_LIB", os.path.join(_CSRC, "libgqhip.so"))  # GQHIP_LIB: diagnostic builds
 
+ABI_VERSION = 4
 GQHIP_LAYOUT = {"bchw": 0, "blc": 1}
 GQHIP_GROUP_STRIDED = 0
 GQHIP_GROUP_CONTIGUOUS = 1
@@ -34,16 +35,14 @@ _SIGNATURES = {
     "gqhip_set_filter": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_get_filter": (ctypes.c_int, []),
     "gqhip_debug_plan": (ctypes.c_int, [_i64, _i64, _i64, ctypes.POINTER(_i64)]),
-    "gqhip_codebook_absmax": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_scores_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double, _vp]),
-    "gq_argmax_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double,
-                                     ctypes.c_float, _vp, _i64, _vp]),
-    "gq_quantize_z_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+    "gq_argmax_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double, _vp, _i64, _vp]),
+    "gq_quantize_z_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
-                                         ctypes.c_double, ctypes.c_float, _vp, _i64, _vp]),
+                                         ctypes.c_double, _vp, _i64, _vp]),
     "gq_dequant_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
                                       ctypes.c_int, _vp]),
-    "vq_argmin_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _i64, _vp]),
+    "vq_argmin_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "lfq_pack_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "lfq_unpack_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "fsq_quantize_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _vp, _i64, _vp]),
@@ -70,6 +69,7 @@ _SIGNATURES = {
     "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "gq_indices_from_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "gqhip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "gqhip_profile_reserve": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "gqhip_debug_enable": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_debug_counters": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
@@ -104,7 +104,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.gqhip_abi_version() != 3:
+        if L.gqhip_abi_version() != ABI_VERSION:
             raise GqHipError("libgqhip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -134,27 +134,32 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 class Workspace:
-    """Caller-owned scratch, grown on demand and reused across calls."""
+    """Caller-owned scratch, grown on demand and reused across calls.  One workspace serves one stream at a time
+    (its header carries the per-call counters).  While a HIP graph is being captured the buffer is never replaced:
+    a captured graph has the pointer baked in, so growing it then -- or after the capture, by an eager call with a
+    bigger shape -- would leave the graph writing into freed memory; size it with a warm-up call first
+    (``reserve``), and a capture that would need to grow raises instead."""
 
     def __init__(self) -> None:
         self.buf: Optional[torch.Tensor] = None
+        self._pinned = False      # True once a graph capture has used this buffer: it must never be replaced
+
+    def reserve(self, rows: int, n: int, dim: int, device) -> None:
+        self.get(rows, n, dim, device)
 
     def get(self, rows: int, n: int, dim: int, device) -> Tuple[int, int]:
         need = lib().gqhip_workspace_bytes(rows, n, dim)
         if need < 0:
             raise GqHipError(f"unsupported shape rows={rows} n={n} dim={dim}")
+        capturing = torch.cuda.is_current_stream_capturing()
         if self.buf is None or self.buf.numel() < need or self.buf.device != device:
+            if capturing or self._pinned:
+                raise GqHipError("workspace would have to grow during / after a HIP graph capture that uses it: "
+                                 "run a warm-up call of the largest shape before capturing, or use a separate Workspace")
             self.buf = torch.empty(need, dtype=torch.uint8, device=device)
+        if capturing:
+            self._pinned = True
         return self.buf.data_ptr(), self.buf.numel()
-
-
-def codebook_absmax(cb: torch.Tensor) -> float:
-    cb = _dev(cb, torch.float32, "codebook")
-    out = torch.zeros(1, dtype=torch.float32, device=cb.device)
-    with torch.cuda.device(cb.device):
-        _check(lib().gqhip_codebook_absmax(cb.data_ptr(), cb.shape[0], cb.shape[1], out.data_ptr(), _stream()),
-               "gqhip_codebook_absmax")
-    return float(out.item())
 
 
 def gq_scores(mu, sd, cb, out, beta: float = 1.0) -> None:
@@ -171,8 +176,7 @@ def gq_scores(mu, sd, cb, out, beta: float = 1.0) -> None:
                                    float(beta), _stream()), "gq_scores_f32")
 
 
-def gq_argmax(mu, sd, cb, beta: float = 1.0, logsd=None, absmax: float = 0.0, ws: Optional[Workspace] = None,
-              want_zhat: bool = True):
+def gq_argmax(mu, sd, cb, beta: float = 1.0, logsd=None, ws: Optional[Workspace] = None, want_zhat: bool = True):
     """Fused score+argmax+gather on (mu, sd[, log sd]) rows -> (idx int64 [rows], zhat [rows, dim])."""
     mu, sd, cb = (_dev(t, torch.float32, n) for t, n in ((mu, "mu"), (sd, "std"), (cb, "codebook")))
     logsd = None if logsd is None else _dev(logsd, torch.float32, "logsd")
@@ -186,14 +190,14 @@ def gq_argmax(mu, sd, cb, beta: float = 1.0, logsd=None, absmax: float = 0.0, ws
     with torch.cuda.device(mu.device):
         wptr, wbytes = ws.get(rows, n, dim, mu.device)
         _check(lib().gq_argmax_f32(mu.data_ptr(), sd.data_ptr(), _ptr(logsd), cb.data_ptr(), idx.data_ptr(),
-                                   _ptr(zhat), dim, rows, n, float(beta), float(absmax), wptr, wbytes, _stream()),
-               "gq_argmax_f32")
+                                   _ptr(zhat), dim, rows, n, float(beta), wptr, wbytes, _stream()), "gq_argmax_f32")
     return idx, zhat
 
 
 def gq_quantize_z(z, cb, dim: int, layout: str, grouping: int, lv_range=(-30.0, 20.0), beta: float = 1.0,
-                  absmax: float = 0.0, ws: Optional[Workspace] = None, return_operands: bool = False):
-    """Module-level fused quantiser on the encoder output z (see gqhip.h)."""
+                  ws: Optional[Workspace] = None, return_operands: bool = False, noise=None):
+    """Module-level fused quantiser on the encoder output z (see gqhip.h).  ``noise`` (same shape as the returned
+    zhat): the first launch also writes ``zhat_noquant = mu + noise * sd`` (gaussian.py:121), returned as a third value."""
     z, cb = _dev(z, torch.float32, "z"), _dev(cb, torch.float32, "codebook")
     n = cb.shape[0]
     if layout == "bchw":
@@ -211,19 +215,28 @@ def gq_quantize_z(z, cb, dim: int, layout: str, grouping: int, lv_range=(-30.0, 
     else:
         idx = torch.empty((B, L, K), dtype=torch.int64, device=dev)
         zhat = torch.empty((B, L, c), dtype=torch.float32, device=dev)
+    noquant = None
+    if noise is not None:
+        noise = _dev(noise, torch.float32, "noise")
+        if tuple(noise.shape) != tuple(zhat.shape):
+            raise GqHipError(f"noise must have the shape of zhat {tuple(zhat.shape)}, got {tuple(noise.shape)}")
+        noquant = torch.empty_like(zhat)
     mu_o = sd_o = None
     if return_operands:
         mu_o = torch.empty(rows, dim, dtype=torch.float32, device=dev)
         sd_o = torch.empty(rows, dim, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         wptr, wbytes = ws.get(max(rows, 1), n, dim, dev)
-        _check(lib().gq_quantize_z_f32(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), zhat.data_ptr(), _ptr(mu_o),
-                                       _ptr(sd_o), B, L, c, dim, n, GQHIP_LAYOUT[layout], grouping,
-                                       float(lv_range[0]), float(lv_range[1]), float(beta), float(absmax),
+        _check(lib().gq_quantize_z_f32(z.data_ptr(), _ptr(noise), cb.data_ptr(), idx.data_ptr(), zhat.data_ptr(),
+                                       _ptr(noquant), _ptr(mu_o), _ptr(sd_o), B, L, c, dim, n, GQHIP_LAYOUT[layout],
+                                       grouping, float(lv_range[0]), float(lv_range[1]), float(beta),
                                        wptr, wbytes, _stream()), "gq_quantize_z_f32")
+    out = (idx, zhat)
     if return_operands:
-        return idx, zhat, mu_o, sd_o
-    return idx, zhat
+        out = out + (mu_o, sd_o)
+    if noise is not None:
+        out = out + (noquant,)
+    return out
 
 
 def gq_dequant(idx, cb, dim: int, layout: str, grouping: int):
@@ -240,7 +253,7 @@ def gq_dequant(idx, cb, dim: int, layout: str, grouping: int):
     return zhat
 
 
-def vq_argmin(z, emb, absmax: float = 0.0, ws: Optional[Workspace] = None):
+def vq_argmin(z, emb, ws: Optional[Workspace] = None):
     z, emb = _dev(z, torch.float32, "z"), _dev(emb, torch.float32, "embedding")
     rows, dim = z.shape
     n = emb.shape[0]
@@ -250,7 +263,7 @@ def vq_argmin(z, emb, absmax: float = 0.0, ws: Optional[Workspace] = None):
     with torch.cuda.device(z.device):
         wptr, wbytes = ws.get(max(rows, 1), n, dim, z.device)
         _check(lib().vq_argmin_f32(z.data_ptr(), emb.data_ptr(), idx.data_ptr(), zq.data_ptr(), dim, rows, n,
-                                   float(absmax), wptr, wbytes, _stream()), "vq_argmin_f32")
+                                   wptr, wbytes, _stream()), "vq_argmin_f32")
     return idx, zq
 
 
@@ -499,6 +512,11 @@ def indices_from_u16(u16):
 
 def profile_enable(on: bool) -> None:
     lib().gqhip_profile_enable(1 if on else 0)
+
+
+def profile_reserve(pairs: int) -> None:
+    """Pre-create event pairs so that profiled launches create nothing (call outside the timed region)."""
+    _check(lib().gqhip_profile_reserve(int(pairs)), "gqhip_profile_reserve")
 
 
 def profile_collect() -> Tuple[int, float]:

@@ -81,8 +81,11 @@ class StepRecord:
     """Layout of one rank's per-step record: int32 words =
     [ per-image metrics as fp32 bits (bs * n_metrics) | indices as uint16 pairs ]."""
 
-    def __init__(self, bs: int, tokens_per_image: int, n_metrics: int) -> None:
+    def __init__(self, bs: int, tokens_per_image: int, n_metrics: int, check_range: bool = False) -> None:
+        """``check_range``: validate 0 <= index < 2^16 on every pack (a device->host sync: eval drivers set it, the
+        benchmark's timed loop does not -- its codebook has exactly 2^16 entries)."""
         self.bs, self.tokens, self.n_metrics = bs, tokens_per_image, n_metrics
+        self.check_range = check_range
         self.metric_words = bs * n_metrics
         self.index_words = (bs * tokens_per_image + 1) // 2
         self.words = self.metric_words + self.index_words
@@ -93,6 +96,11 @@ class StepRecord:
         rec = torch.empty(self.words, dtype=torch.int32, device=dev)
         rec[: self.metric_words] = metrics.reshape(-1).to(torch.float32).view(torch.int32)
         flat = indices.reshape(-1)
+        if flat.numel() != self.bs * self.tokens or metrics.numel() != self.metric_words:
+            raise ValueError(f"StepRecord.pack: got {flat.numel()} indices / {metrics.numel()} metrics, layout is "
+                             f"{self.bs} x {self.tokens} / {self.metric_words}")
+        if self.check_range and flat.numel() and (int(flat.max()) >= 65536 or int(flat.min()) < 0):
+            raise ValueError("StepRecord.pack: the uint16 wire format needs 0 <= index < 65536")
         if flat.numel() % 2:
             flat = torch.cat([flat, flat.new_zeros(1)])
         u16 = flat.to(torch.int32)  # values < 65536
@@ -124,11 +132,40 @@ def gather_step(rec: torch.Tensor, world: int, always_collective: bool = False) 
     return out.reshape(world, -1)
 
 
-def psnr_zero_mean(x: torch.Tensor, x_rec: torch.Tensor) -> torch.Tensor:
-    """get_psnr(zero_mean=True) of pit/evaluations/psnr.py:17-35, per image."""
-    a, b = (x + 1) * 127.5, (x_rec + 1) * 127.5
-    mse = torch.mean((a - b) ** 2, dim=[1, 2, 3])
+def get_psnr(x_input: torch.Tensor, x_recon: torch.Tensor, zero_mean: bool = False, is_video: bool = False) -> torch.Tensor:
+    """pit/evaluations/psnr.py:17-35: PSNR per item on the [0, 255] scale; ``zero_mean``: inputs in [-1, 1]
+    (eval.py:165 calls it that way), else in [0, 1].  Same op order as the reference (golden g12_psnr)."""
+    if zero_mean:
+        a, b = (x_input + 1) * 127.5, (x_recon + 1) * 127.5
+    else:
+        a, b = x_input * 255, x_recon * 255
+    mse = torch.mean((a - b) ** 2, dim=[1, 2, 3, 4] if is_video else [1, 2, 3])
     return 20 * torch.log10(255.0 / torch.sqrt(mse))
+
+
+def psnr_zero_mean(x: torch.Tensor, x_rec: torch.Tensor) -> torch.Tensor:
+    """get_psnr(zero_mean=True), per image."""
+    return get_psnr(x, x_rec, zero_mean=True)
+
+
+def cal_ent(hist: torch.Tensor):
+    """eval.py:137-141 (dead code there): codebook usage (fraction of entries hit at least once)
+    and entropy in bits of the usage histogram, with the reference's ``+ 1e-5`` inside the log.  Returns
+    (usage, entropy) as 0-d tensors on hist's device."""
+    hist = hist.to(torch.float32)
+    unused = torch.sum((hist == 0).to(dtype=torch.float32)) / hist.shape[0]
+    p = hist / torch.sum(hist)
+    ent = -torch.sum(p * torch.log2(p + 1e-5))
+    return 1 - unused, ent
+
+
+def codebook_usage(indices: torch.Tensor, n_codes: int):
+    """Histogram (HIP kernel, eval.py:127,152-154's all_hist) + cal_ent of a batch of indices on the device."""
+    from . import _lib
+
+    hist = _lib.index_histogram(indices.contiguous(), n_codes)
+    usage, ent = cal_ent(hist)
+    return hist, usage, ent
 
 
 @torch.no_grad()
@@ -137,7 +174,7 @@ def evaluate_sharded(model, images_for, n_images: int, bs: int, rank: int, world
     """The reference eval loop for this path: each rank encodes/decodes its shard, one gather per
     step, rank 0 returns indices + PSNR in dataset order.  ``images_for(ids) -> [len(ids),3,H,W]``."""
     batches = shard_batches(n_images, world, rank, bs)
-    layout = StepRecord(bs, tokens_per_image, n_metrics=1)
+    layout = StepRecord(bs, tokens_per_image, n_metrics=1, check_range=True)
     gathered = []
     for ids in batches:
         x = images_for(ids).to(device, non_blocking=True)

@@ -33,8 +33,18 @@ class FSQQuantizer(nn.Module):
         with torch.no_grad():
             zq, idx = _lib.fsq_quantize(zf.detach().reshape(-1, c).contiguous(), self._levels)
         zq = zq.reshape(b, l, c)
-        # round_ste: value of the rounded branch, gradient of the bounded branch (fsq.py:6-9, :37-38)
-        zhat = zq if not zf.requires_grad else zf * 0 + zq
+        if zf.requires_grad and torch.is_grad_enabled():
+            # round_ste (fsq.py:6-9, :30-38): the VALUE is the rounded branch (the kernel's zq), the GRADIENT is that of
+            # bounded_z / half_width = (tanh(z + shift) * half_l - offset) / half_width, recomputed here in torch
+            eps = 1e-3
+            lev = self.levels.to(zf.device)
+            half_l = (lev - 1) * (1 + eps) / 2
+            offset = torch.where(lev % 2 == 0, 0.5, 0.0)
+            shift = (offset / half_l).atanh()
+            soft = ((zf + shift).tanh() * half_l - offset) / (lev // 2)
+            zhat = soft + (zq - soft).detach()
+        else:
+            zhat = zq
         indices = idx.reshape(b, l, 1)
         if self.format == "bchw":
             zhat = zhat.transpose(1, 2).reshape(b, c, h, w)

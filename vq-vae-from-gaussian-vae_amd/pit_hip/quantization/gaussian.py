@@ -68,8 +68,7 @@ class _GaussianQuantBase(nn.Module):
         if backend not in ("hip", "cuda", "torch"):
             raise ValueError(f"unknown backend {backend!r}")
         self.backend = backend
-        self._ws = _lib.Workspace()
-        self._absmax = float(self.prior_samples.abs().max())  # host-side once; passed to every call
+        self._ws = _lib.Workspace()   # scratch only: every call rebuilds what it derives from the codebook
 
     # the reference's "cuda" call sequence on rows (gaussian.py:124-133 / :289-298)
     def _compat_rows(self, mu: torch.Tensor, std: torch.Tensor, dim: int):
@@ -112,7 +111,35 @@ class GaussianQuantRegularizer(_GaussianQuantBase):
         self.format, self.group = format, group
         self._setup(n_samples, group, seed, beta, backend, logvar_range, tolerance, lam_factor, (1e-3, 1e3))
 
+    def _forward_fused(self, z):
+        """Eval branch (gaussian.py:120-160) as ONE call: chunk / clamp / exp, the group permutes, zhat_noquant, the
+        rows x n score matrix, arg-max and gather all happen inside libgqhip's four launches.  A channels_last z
+        (what the NHWC conv stack hands over) is read, and zhat / indices / zhat_noquant are written, in that memory
+        layout directly: NHWC memory of [B, C, h, w] IS the "blc" layout with L = h * w, so nothing is transposed."""
+        z = z.float()
+        if self.format == "bchw":
+            b, c2, h, w = z.shape
+            shape_n = (b, c2 // 2, h, w)
+            if not z.is_contiguous() and z.is_contiguous(memory_format=torch.channels_last):
+                zmem = z.permute(0, 2, 3, 1).reshape(b, h * w, c2)   # a view of the same memory
+                # one draw of the size of mu (advances the generator like gaussian.py:121)
+                noise = torch.randn((b, h * w, c2 // 2), dtype=torch.float32, device=z.device)
+                ind, zhat, noq = _lib.gq_quantize_z(zmem, self.prior_samples, self.group, "blc", _lib.GQHIP_GROUP_STRIDED,
+                                                    self.logvar_range, self.beta, self._ws, noise=noise)
+                as_bchw = lambda t: t.view(b, h, w, -1).permute(0, 3, 1, 2)   # logical [B, C, h, w], NHWC memory
+                return as_bchw(zhat), {"indices": as_bchw(ind), "zhat_noquant": as_bchw(noq)}
+        else:
+            b, l, c2 = z.shape
+            shape_n = (b, l, c2 // 2)
+        noise = torch.randn(shape_n, dtype=torch.float32, device=z.device)
+        indices, zhat, zhat_noquant = _lib.gq_quantize_z(z, self.prior_samples, self.group, self.format,
+                                                         _lib.GQHIP_GROUP_STRIDED, self.logvar_range, self.beta,
+                                                         self._ws, noise=noise)
+        return zhat, {"indices": indices, "zhat_noquant": zhat_noquant}
+
     def forward(self, z):
+        if not self.training and self.backend != "cuda":
+            return self._forward_fused(z)
         z = z.float()
         if self.format == "bchw":
             b, c2, h, w = z.shape
@@ -140,22 +167,17 @@ class GaussianQuantRegularizer(_GaussianQuantBase):
                     "bits-max": kl2_max, "lam": torch.zeros_like(kl_loss) + self.lam}
             return zhat, info
 
+        # backend "cuda": the reference's own call sequence (score matrix -> argmax -> index_select)
         zhat_noquant = mu + torch.randn_like(mu) * std  # consumes RNG in eval, like gaussian.py:121
         k = c // self.group
-        if self.backend == "cuda":
-            mu_r = mu.reshape(b, l, self.group, k).permute(0, 1, 3, 2).reshape(-1, self.group)
-            std_r = std.reshape(b, l, self.group, k).permute(0, 1, 3, 2).reshape(-1, self.group)
-            zq, ind = self._compat_rows(mu_r.contiguous(), std_r.contiguous(), self.group)
-            zhat = zq.reshape(b, l, k, self.group).permute(0, 1, 3, 2).reshape(b, l, c).float()
-            indices = ind.reshape(b, l, k)
-            if self.format == "bchw":
-                zhat = zhat.transpose(1, 2).reshape(b, c, h, w)
-                indices = indices.transpose(1, 2).reshape(b, k, h, w)
-        else:
-            indices, zhat = _lib.gq_quantize_z(z, self.prior_samples, self.group, self.format,
-                                               _lib.GQHIP_GROUP_STRIDED, self.logvar_range, self.beta,
-                                               self._absmax, self._ws)
+        mu_r = mu.reshape(b, l, self.group, k).permute(0, 1, 3, 2).reshape(-1, self.group)
+        std_r = std.reshape(b, l, self.group, k).permute(0, 1, 3, 2).reshape(-1, self.group)
+        zq, ind = self._compat_rows(mu_r.contiguous(), std_r.contiguous(), self.group)
+        zhat = zq.reshape(b, l, k, self.group).permute(0, 1, 3, 2).reshape(b, l, c).float()
+        indices = ind.reshape(b, l, k)
         if self.format == "bchw":
+            zhat = zhat.transpose(1, 2).reshape(b, c, h, w)
+            indices = indices.transpose(1, 2).reshape(b, k, h, w)
             zhat_noquant = zhat_noquant.transpose(1, 2).reshape(b, c, h, w)
         return zhat, {"indices": indices, "zhat_noquant": zhat_noquant}
 
@@ -211,8 +233,7 @@ class GaussianQuantRegularizer2(_GaussianQuantBase):
         else:
             # rows are already "position-major, channel-last": one BLC image of L = #positions
             ind, zq = _lib.gq_quantize_z(z2.contiguous()[None], self.prior_samples, self.dim, "blc",
-                                         _lib.GQHIP_GROUP_CONTIGUOUS, self.logvar_range, self.beta, self._absmax,
-                                         self._ws)
+                                         _lib.GQHIP_GROUP_CONTIGUOUS, self.logvar_range, self.beta, self._ws)
             zhat, indices = zq[0], ind[0]
         zhat = self._restore(zhat, z_shape)
         indices = self._restore(indices, z_shape)
