@@ -174,8 +174,9 @@ def test_vq_lfq_512_shapes():
 
 def test_engine_end_to_end_full_config():
     """x -> encode -> indices -> dequant/decode on the GPU vs the reference's CPU end-to-end golden.
-    Tolerances (fp32, different conv/GN/SDPA kernels): |z_enc diff| <= 2e-3, recon max-abs <= 5e-2 and
-    PSNR(gpu recon, cpu recon) >= 40 dB; indices equal except where the reference's top-2 gap < 1e-2."""
+    Gates (fp32, different conv/GN/SDPA kernels): |z_enc diff| <= 5e-5; at most 2 of 1024 indices differ end to end and
+    only where the reference's top-2 gap < 1e-3 (golden z through the GPU quantiser: none, or gap < 1e-4);
+    reconstruction max-abs <= 5e-3 when the indices agree and PSNR(gpu recon, cpu recon) >= 60 dB."""
     from pit_hip.models.autoencoder import AutoencodingEngine
 
     unet = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=256, in_channels=3, out_ch=3, ch=128,
@@ -197,35 +198,41 @@ def test_engine_end_to_end_full_config():
         z, ind = vae.quant(x)
         rec = vae.dequant(ind)
         z2, rec2, log = vae(x)
-    assert float((z_enc.cpu() - torch.from_numpy(d["z_enc"])).abs().max()) <= 2e-3
+    dz = float((z_enc.cpu() - torch.from_numpy(d["z_enc"])).abs().max())
+    assert dz <= 5e-5, dz                     # measured 3-4e-6 (fp32 conv rounding); 2e-3 in round 1 was far too loose
     got, want = ind.cpu().numpy(), d["indices"]
     diff = _rows_from_bchw(got) != _rows_from_bchw(want)
-    assert diff.mean() < 0.02 and np.all(d["gap"][diff] < 1e-2), (diff.sum(), d["gap"][diff])
+    # GPU encoder + GPU quantiser vs the reference end to end: what README/DESIGN claim is "equal"; the gate allows the
+    # encoder's rounding to flip at most 2 of the 1024 rows, and only where the reference's own top-2 gap is < 1e-3
+    print(f"e2e 256 NCHW: |dz| {dz:.2e}, {int(diff.sum())} of 1024 indices differ"
+          f"{' (gaps ' + str(d['gap'][diff]) + ')' if diff.any() else ''}")
+    assert diff.sum() <= 2 and np.all(d["gap"][diff] < 1e-3), (diff.sum(), d["gap"][diff])
     ref = torch.from_numpy(d["x_rec"].astype(np.float32))
-    same = ~torch.from_numpy(diff.reshape(1, 1, 32, 32))
-    if bool(same.all()):
-        assert float((rec.cpu() - ref).abs().max()) <= 5e-2
+    if not diff.any():
+        assert float((rec.cpu() - ref).abs().max()) <= 5e-3    # the golden is stored in fp16 (ulp 4.9e-4 at |x| ~ 1)
     mse = float(((rec.cpu() - ref) ** 2).mean())
-    assert 10 * np.log10(4.0 / max(mse, 1e-20)) >= 40.0
+    assert 10 * np.log10(4.0 / max(mse, 1e-20)) >= 60.0
     # two separate forward passes: the conv libraries' split-K kernels are not bitwise reproducible, so the second pass
     # may differ at rounding level (and an index only at a near-tie)
-    assert torch.allclose(z, z2, atol=1e-4) or float((log["indices"] != ind).float().mean()) < 0.005
-    assert float((log["indices"] != ind).float().mean()) < 0.005
-    assert torch.allclose(rec, rec2, atol=1e-2)
-    # the bench configuration: channels_last conv stack (NHWC fused kernels) -- same tolerances
+    assert float((z2 - z).abs().max()) <= 1e-4 or int((log["indices"] != ind).sum()) <= 2
+    assert int((log["indices"] != ind).sum()) <= 2
+    assert torch.allclose(rec, rec2, atol=1e-3)
+    # the bench configuration: channels_last conv stack (NHWC fused kernels, Winograd encoder) -- same gate
     vae_cl = vae.to(memory_format=torch.channels_last)
     with torch.no_grad():
         z_cl, ind_cl = vae_cl.quant(x.contiguous(memory_format=torch.channels_last))
         rec_cl = vae_cl.dequant(ind_cl)
     diff_cl = _rows_from_bchw(ind_cl.cpu().numpy()) != _rows_from_bchw(want)
-    assert diff_cl.mean() < 0.02 and np.all(d["gap"][diff_cl] < 1e-2)
+    print(f"e2e 256 channels_last: {int(diff_cl.sum())} of 1024 indices differ")
+    assert diff_cl.sum() <= 2 and np.all(d["gap"][diff_cl] < 1e-3), (diff_cl.sum(), d["gap"][diff_cl])
     mse_cl = float(((rec_cl.cpu() - ref) ** 2).mean())
-    assert 10 * np.log10(4.0 / max(mse_cl, 1e-20)) >= 40.0
+    assert 10 * np.log10(4.0 / max(mse_cl, 1e-20)) >= 60.0
     vae = vae_cl.to(memory_format=torch.contiguous_format)
-    # golden z_enc fed straight to the GPU quantiser: indices must match the reference (rounding ties aside)
+    # golden z_enc fed straight to the GPU quantiser: no conv rounding in between, so the indices must be the
+    # reference's (a row may differ only where its top-2 gap is below the 1-ulp libm difference of exp / log: < 1e-4)
     zhat, info = vae.regularization(torch.from_numpy(d["z_enc"]).to(DEV))
     diff2 = _rows_from_bchw(info["indices"].cpu().numpy()) != _rows_from_bchw(want)
-    assert diff2.mean() < 2e-3 and np.all(d["gap"][diff2] < 1e-4)
+    assert diff2.sum() == 0 or np.all(d["gap"][diff2] < 1e-4), (diff2.sum(), d["gap"][diff2])
 
 
 def test_histogram_and_u16_wire_format():
@@ -265,7 +272,7 @@ def test_eval_loop_single_rank_on_gpu():
     with torch.no_grad():
         _, ind = vae.quant(images_for([0, 1, 2, 3]).to(DEV))
     # (a second forward pass of the conv stack: equal up to the conv libraries' non-reproducibility at near-ties)
-    assert float((out["indices"][:4].cpu() != ind.reshape(4, -1).cpu()).float().mean()) < 0.02
+    assert int((out["indices"][:4].cpu() != ind.reshape(4, -1).cpu()).sum()) <= 2
 
 
 def test_smoke_entry():

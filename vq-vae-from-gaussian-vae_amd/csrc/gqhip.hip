@@ -72,11 +72,14 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   pl.bf16 = pl.mfma && want_bf16_filter();
   static const int env_waves = getenv("GQHIP_BF16_WAVES") ? atoi(getenv("GQHIP_BF16_WAVES")) : 0;
   pl.waves = pl.bf16 ? (env_waves == 4 ? 4 : 8) : 4;
+  // experiment: one wave per SIMD carrying four row tiles (same 512 rows per block, half the LDS operand reads per row)
+  static const int env_rt4 = getenv("GQHIP_BF16_RT4") ? atoi(getenv("GQHIP_BF16_RT4")) : 0;
+  if (pl.bf16 && env_rt4 == 1 && dim == 16 && rows >= 8192) { pl.waves = 4; pl.rt = 4; }
   pl.rows_per_block = 32 * pl.waves * pl.rt;
   pl.row_blocks = (int)((rows + pl.rows_per_block - 1) / pl.rows_per_block);
   // 4-wave blocks: ~2 blocks per CU on 256 CUs; 8-wave blocks: one per CU.  Splits in multiples of 8 so that
   // blockIdx % 8 (XCD) == split % 8.
-  const int target = env_blocks > 0 ? env_blocks : (pl.waves == 8 ? 256 : 512);
+  const int target = env_blocks > 0 ? env_blocks : ((pl.waves == 8 || pl.rt == 4) ? 256 : 512);
   int s = (target + pl.row_blocks - 1) / (pl.row_blocks > 0 ? pl.row_blocks : 1);
   s = ((s + 7) / 8) * 8;
   static const int env_nsplit = getenv("GQHIP_NSPLIT") ? atoi(getenv("GQHIP_NSPLIT")) : 0;
@@ -88,11 +91,12 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   // tiles per LDS chunk: 16 at dim 16 with one block per CU (2 x 64 KiB of LDS, half the chunk barriers: +1-2 %)
   static const int env_ct = getenv("GQHIP_BF16_CT") ? atoi(getenv("GQHIP_BF16_CT")) : 0;
   pl.ct = dim == 32 ? 4 : ((dim == 16 && pl.waves == 8 && env_ct != 8) ? 16 : 8);
+
   static const int env_bgt = getenv("GQHIP_BF16_GT") ? atoi(getenv("GQHIP_BF16_GT")) : 0;
   // split-bf16: the tracker's VALU work overlaps the bf16 MFMAs, so the finest candidate (one tile half =
   // 16 codes) is free in the filter and halves / quarters the exact re-rank work
   // (dim 4: two MFMAs per tile, the epilogue dominates -> the coarse 64-code candidate keeps the tracker cheap)
-  pl.gt = pl.bf16 ? (dim == 4 ? 4 : ((pl.waves == 4 && (env_bgt == 2 || env_bgt == 4)) ? env_bgt : 1)) : (dim <= 8 ? 4 : 2);
+  pl.gt = pl.bf16 ? (dim == 4 ? 4 : (((pl.waves == 4 || dim == 16) && (env_bgt == 2 || env_bgt == 4)) ? env_bgt : 1)) : (dim <= 8 ? 4 : 2);
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   pl.gt2 = dim <= 8 ? 4 : 2;
@@ -211,6 +215,7 @@ int launch_rerank(const RerankParams &rp, int64_t rows, int dim, hipStream_t st)
     case 232: GQ_RR(32, 32); break;
     case 404: GQ_RR(64, 4); break;
     case 408: GQ_RR(64, 8); break;
+    case 416: GQ_RR(64, 16); break;
     default: return GQHIP_ERR_INVALID_ARG;
   }
 #undef GQ_RR
@@ -236,11 +241,19 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, hipStr
     else if (pl.gt == 1) GQ_LAUNCH_BF1(NV, R, C, 1, 4);                                                   \
     else GQ_LAUNCH_BF1(NV, R, C, 4, 4);                                                                   \
   } while (0)
-  if (pl.rt == 2) {
+  if (pl.rt == 4) {          // experiment (GQHIP_BF16_RT4=1): dim 16 only
+    if (pl.gt == 2) GQ_LAUNCH_BF1(2, 4, 8, 2, 4);
+    else GQ_LAUNCH_BF1(2, 4, 8, 1, 4);
+  } else if (pl.rt == 2) {
     switch (dim) {
       case 4: GQ_LAUNCH_BF(0, 2, 8); break;
       case 8: GQ_LAUNCH_BF(1, 2, 8); break;
-      case 16: if (pl.ct == 16) GQ_LAUNCH_BF1(2, 2, 16, 1, 8); else GQ_LAUNCH_BF(2, 2, 8); break;
+      case 16:
+        if (pl.ct == 16 && pl.gt == 2) GQ_LAUNCH_BF1(2, 2, 16, 2, 8);
+        else if (pl.ct == 16 && pl.gt == 4) GQ_LAUNCH_BF1(2, 2, 16, 4, 8);
+        else if (pl.ct == 16) GQ_LAUNCH_BF1(2, 2, 16, 1, 8);
+        else GQ_LAUNCH_BF(2, 2, 8);
+        break;
       default: GQ_LAUNCH_BF(4, 2, 4); break;
     }
   } else {
@@ -269,7 +282,10 @@ int tail_grid(const void *kernel) {
   int cus = 0, nb = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) return 0;
-  const int grid = cus * (nb < 2 ? nb : 2);
+  static const int env_per_cu = getenv("GQHIP_TAIL_BLOCKS_PER_CU") ? atoi(getenv("GQHIP_TAIL_BLOCKS_PER_CU")) : 0;
+  int per_cu = nb < 2 ? nb : 2;
+  if (env_per_cu == 1) per_cu = 1;   // diagnostics
+  const int grid = cus * per_cu;
   cache[{dev, kernel}] = grid;
   return grid;
 }

@@ -46,9 +46,17 @@ class AutoencodingEngine(nn.Module):
         sd = torch.load(path, map_location="cpu")["state_dict"]
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
         missing, unexpected = self.load_state_dict(sd, strict=False)
+        self.invalidate_caches()
         print("Missing keys: ", missing)
         print(f"Restored from {path}")
         return missing, unexpected
+
+    def invalidate_caches(self) -> None:
+        """Drop the conv stack's weight-derived caches (see pit_hip.modules.unet.invalidate_caches): needed only after
+        weights were changed through ``param.data`` (no version bump), e.g. an EMA swap."""
+        from ..modules.unet import invalidate_caches
+
+        invalidate_caches(self)
 
     def get_input(self, batch: Dict) -> torch.Tensor:
         return batch[self.input_key]

@@ -146,6 +146,22 @@ def _wino_weights(conv: nn.Conv2d, f4: bool = False) -> torch.Tensor:
     return conv._wino_u
 
 
+def invalidate_caches(module: nn.Module) -> None:
+    """Drop every weight-derived cache under ``module`` (Winograd U matrices, the sub-pixel phase matrices, the fused
+    q/k/v matrix).  The caches are keyed on (data_ptr, _version, device), which follows ``load_state_dict``, optimizer
+    steps, ``.to()`` and any in-place op on the parameter -- but NOT writes through ``param.data`` (EMA weight swaps
+    typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
+    .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
+    for m in module.modules():
+        for attr in ("_wino_key", "_qkv_key", "_phase_key"):
+            if getattr(m, attr, None) is not None:
+                setattr(m, attr, None)
+
+
+def _drop_caches_after_load(module, incompatible_keys) -> None:
+    invalidate_caches(module)
+
+
 def mark_winograd(module: nn.Module, f4: bool = False) -> None:
     """Flag the stride-1, padding-1 3x3 convolutions of ``module`` for the Winograd path (see ``_conv``);
     ``f4``: F(4x4,3x3) where the spatial size allows it (decoder only: larger rounding error)."""
@@ -431,6 +447,7 @@ class Encoder(nn.Module):
                  use_linear_attn: bool = False, attn_type: str = "vanilla", padding_mode: str = "zeros",
                  **ignore_kwargs) -> None:
         super().__init__()
+        self.register_load_state_dict_post_hook(_drop_caches_after_load)
         if use_linear_attn:
             attn_type = "linear"
         self.ch, self.resolution, self.in_channels = ch, resolution, in_channels
@@ -458,6 +475,9 @@ class Encoder(nn.Module):
         if WINOGRAD_ENCODER:
             mark_winograd(self)   # F(2x2,3x3) only: the encoder's rounding decides indices
 
+    def invalidate_caches(self) -> None:
+        invalidate_caches(self)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = _match_layout(x, self.conv_in)
         h, pb = _conv(self.conv_in, x)
@@ -476,6 +496,7 @@ class Decoder(nn.Module):
                  tanh_out: bool = False, use_linear_attn: bool = False, attn_type: str = "vanilla",
                  padding_mode: str = "zeros", **ignore_kwargs) -> None:
         super().__init__()
+        self.register_load_state_dict_post_hook(_drop_caches_after_load)
         if use_linear_attn:
             attn_type = "linear"
         self.ch, self.resolution, self.in_channels = ch, resolution, in_channels
@@ -507,6 +528,9 @@ class Decoder(nn.Module):
 
     def get_last_layer(self, **kwargs) -> torch.Tensor:
         return self.conv_out.weight
+
+    def invalidate_caches(self) -> None:
+        invalidate_caches(self)
 
     def forward(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
         self.last_z_shape = z.shape
