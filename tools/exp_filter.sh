@@ -5,12 +5,7 @@ mkdir -p $OUT
 run() { echo "== $*" >> $OUT/kbench_variants.txt; env "$@" python tools/kbench.py --iters 100 2>/dev/null | grep rows= >> $OUT/kbench_variants.txt; }
 for rep in 1 2 3; do
   run A=default
+  run GQHIP_BF16_GT=1
   run GQHIP_BF16_GT=2
-  run GQHIP_BF16_GT=4
-  run GQHIP_BF16_RT4=1
-  run GQHIP_BF16_RT4=1 GQHIP_BF16_GT=2
-  run GQHIP_TAIL_BLOCKS_PER_CU=1
+  run GQHIP_BF16_GT=8
 done
-echo "== prep split" >> $OUT/kbench_variants.txt
-python tools/kbench.py --rows 256 --iters 50 2>/dev/null | grep rows= >> $OUT/kbench_variants.txt
-python tools/kbench.py --n 1024 --iters 50 2>/dev/null | grep rows= >> $OUT/kbench_variants.txt

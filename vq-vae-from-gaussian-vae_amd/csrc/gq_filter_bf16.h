@@ -100,7 +100,7 @@ __device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[BfLayout<NV>::N
 // waits and epilogues behind (measured per block with GQHIP_CLOCK_STAMPS: 104 / 149 us).  One block per CU also
 // halves the L2 -> LDS staging traffic (one chunk copy serves 8 waves).
 template <int NV, int RT, int CT, int GT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 || RT == 4) ? 1 : 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
   constexpr int NCV = BfLayout<NV>::NCV;      // code (and row) vectors per tile
   constexpr int TILE_Q = NCV * 64;            // 16-byte slots per tile
   constexpr int CHUNK_Q = CT * TILE_Q;

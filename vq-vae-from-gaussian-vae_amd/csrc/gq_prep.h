@@ -7,6 +7,7 @@
 //     otherwise the caller's (mu, sd[, lsd]) rows are used as they are.
 //   * the filter's row operands A = beta/2 - 1/(2 sd^2), B = mu / sd^2 (fp64, rounded once), split into two bf16
 //     terms and written as the row image of gq_filter_bf16.h;
+//   * the same A | B as fp32 rows (the re-rank's fp32 pre-filter evaluates the expansion with exactly these operands);
 //   * four per-row sums the re-rank's rounding bound is made of (so that no kernel after this one divides in fp64):
 //       S0 = sum 1/sd^2, S1 = sum |mu|/sd^2, S2 = sum mu^2/sd^2, S3 = sum |log sd|      (VQ: S1 = sum |z|).
 // Code blocks (the 256 blocks after the row blocks): the bf16 tile image of the codebook [n^2 | n] (h / l parts, in the
@@ -33,6 +34,7 @@ struct PrepParams {
   float *mu, *sd, *lsd;      // [rows, dim]
   float *lsd_out;            // !FROM_Z only, may be NULL
   double *rowsum;            // [rows, 4]
+  float *coef;               // [rows, 2, dim]: the fp32 filter coefficients A | B (the re-rank's pre-filter reads them)
   u32x4 *rowimg;             // [rows][NVEC][2] or NULL (fp32 filter: no images)
   const float *cb;           // [n, dim]
   u32x4 *cbimg;              // [tiles_total + CT][NVEC][2][32] or NULL
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   __shared__ __attribute__((aligned(16))) float s_mu[256], s_sd[256], s_lsd[256];
   __shared__ __attribute__((aligned(16))) unsigned short s_hi[RB][2 * DIM], s_lo[RB][2 * DIM];
   __shared__ double s_sum[256][4];
+  __shared__ __attribute__((aligned(16))) float s_coef[RB][2 * DIM];
   const long row0 = (long)blockIdx.x * RB;
   // element of the tile handled in phase 1: rows fastest for BCHW (consecutive l -> coalesced z reads), else dims fastest
   int lr, g;
@@ -187,6 +190,8 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   s_mu[lr * DIM + g] = m;
   s_sd[lr * DIM + g] = s;
   s_lsd[lr * DIM + g] = ls;
+  s_coef[lr][g] = cA;
+  s_coef[lr][DIM + g] = cB;
   unsigned ah, al, bh, bl;
   bf16_split(cA, ah, al);
   bf16_split(cB, bh, bl);
@@ -210,6 +215,12 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     } else if (MODE == kModeGQ && p.lsd_out) {
       p.lsd_out[e_out] = s_lsd[tid];
     }
+  }
+  {                                                  // A | B rows: 2 * DIM floats per row, contiguous for the tile
+    const float *flat = &s_coef[0][0];
+    const long base = row0 * 2 * DIM, lim = p.rows * 2 * DIM;
+    if (base + tid < lim) p.coef[base + tid] = flat[tid];
+    if (base + 256 + tid < lim) p.coef[base + 256 + tid] = flat[256 + tid];
   }
   if (tid < RB * 4 && row0 + tid / 4 < p.rows) {     // four sums per row, ascending dim order (deterministic)
     const int r = tid / 4, q = tid % 4;

@@ -68,6 +68,7 @@ struct RerankParams {
   const float *sd;    // [rows, dim]
   const float *lsd;   // [rows, dim] (NULL only on the exhaustive path: fp64 log of sd)
   const double *rowsum;  // [rows, 4] sums of gq_prep_kernel (bound of the re-rank)
+  const float *coef;     // [rows, 2, dim] fp32 filter coefficients A | B of gq_prep_kernel (pre-filter of the re-rank)
   const float *cb;    // [n, dim]
   const Rec *rec;     // [nsplit, rows]
   int64_t *idx;
@@ -81,7 +82,7 @@ struct RerankParams {
   int rows, n, dim;
   float beta;
   int nsplit;
-  int gt;             // tiles per candidate group (2 or 4) -- must match the filter's GT
+  int gt;             // tiles per candidate group -- must match the filter's GT
   float ef_coeff;     // filter error bound E_f = ef_coeff * 2^-24 * T  (fp32 filter: 2 dim + 4; split-bf16: 220 + 24 dim)
   int all_rows;       // exhaustive kernel: process every row (no filter ran)
   int stats;          // count re-ranked half-pairs (debug)
@@ -207,18 +208,19 @@ __device__ __forceinline__ void row_bound(const double *rs, double N1, int dim, 
   }
 }
 
-// The reference score with the row operands in registers (same operation order as ref_score_ops).
+// The reference score of a code row held in registers against row operands [mu | 2 sd^2 | log sd] in LDS (same
+// operation order as ref_score_ops: 8 strided accumulators, left-to-right combine).
 template <int DIM>
-__device__ __forceinline__ float ref_score_regs(const float (&n)[DIM], const float (&mu)[DIM], const float (&var2)[DIM],
-                                                const float (&lsd)[DIM], float beta) {
+__device__ __forceinline__ float ref_score_lds(const float (&n)[DIM], const float *ops, float beta) {
 #pragma clang fp contract(off)
   float acc[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = k < DIM ? ref_term(n[k], mu[k], var2[k], lsd[k], beta) : 0.0f;
+  for (int k = 0; k < 8; ++k) acc[k] = k < DIM ? ref_term(n[k], ops[k], ops[DIM + k], ops[2 * DIM + k], beta) : 0.0f;
 #pragma unroll
   for (int i0 = 8; i0 < DIM; i0 += 8)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = acc[k] + ref_term(n[i0 + k], mu[i0 + k], var2[i0 + k], lsd[i0 + k], beta);
+    for (int k = 0; k < 8; ++k)
+      acc[k] = acc[k] + ref_term(n[i0 + k], ops[i0 + k], ops[DIM + i0 + k], ops[2 * DIM + i0 + k], beta);
   float s = acc[0];
 #pragma unroll
   for (int k = 1; k < 8; ++k)
@@ -226,19 +228,31 @@ __device__ __forceinline__ float ref_score_regs(const float (&n)[DIM], const flo
   return s;
 }
 
-// GROUP lanes per row, GROUP = codes per candidate (16 * gt): a wave handles 64 / GROUP rows, each lane group
-// walks its row's candidate list one candidate (= GROUP codes, one per lane) at a time.  The kernel is a chain of
-// dependent memory round trips (records -> code rows -> result), so everything a row needs besides the records is in
-// flight at once: the row operands go to REGISTERS (every lane of a group loads its row's mu / sd / log sd as 16-byte
-// broadcast loads), the bound comes from the four sums of gq_prep_kernel (no fp64 division here), and at level 1 the
-// results of a block's consecutive rows leave through LDS as contiguous runs in the module layout.
+// The exact re-rank.  16 lanes per row (4 rows per wave, 16 per block); a candidate = one "half-group" of the filter
+// = the 16 codes of one lane half in each of `gt` consecutive tiles, so every lane owns `gt` codes per candidate.
+// The kernel is a chain of dependent memory round trips (records -> code rows -> result), so everything a row needs
+// besides the records is in flight at once: pass 1's operands A | B go to REGISTERS (16-byte broadcast loads), pass 2's
+// (mu, 2 sd^2, log sd) to a padded LDS record, the bound comes from the four sums of gq_prep_kernel (no fp64 division
+// here), and at level 1 the results of a block's 16 consecutive rows leave through LDS as contiguous
+// runs in the module layout.
+//
+// Two passes over the candidates' codes.  Pass 1 evaluates the filter expansion f^(j) = sum_i A_i n_ji^2 + B_i n_ji as a
+// plain fp32 FMA chain (2 dim FMAs, no division) and takes the group-wide maximum F.  Its error is that of the fp32 MFMA
+// filter, |f^ - f| <= E32 = (2 dim + 4) u T, so by the same argument as for the filter the reference's arg-max j* --
+// which IS among the candidates -- satisfies f^(j*) >= F - 2 (E32 + E_r).  Pass 2 therefore evaluates the reference's
+// own score (ref_term: one IEEE division per dimension) only for the codes with f^ >= F - 2.5 (E32 + E_r): one or two
+// per row instead of all 16 gt.  That makes coarse candidates (gt = 4: 64 codes) cheap here, and coarse candidates are
+// what keeps the tracker of the split-bf16 filter off its critical path.
+constexpr int kRerankLanes = 16;               // lanes per row
 constexpr int kCandPad = 3 * kMaxSplit + 17;   // odd-ish stride: the row slots of a wave start in different LDS banks
-template <int MODE, int GROUP, int DIM>
+template <int MODE, int DIM, int GT>
 __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vblock, const int nrows) {
+  constexpr int GROUP = kRerankLanes;
   constexpr int RPW = 64 / GROUP;            // rows per wave
   constexpr int RPB = 4 * RPW;               // rows per block
   constexpr int NSI = kMaxSplit / GROUP;     // record passes per lane (code splits <= kMaxSplit)
   __shared__ int cand[RPB][kCandPad];
+  __shared__ float s_ops[RPB][3 * DIM + 1];
   __shared__ float s_zhat[RPB][DIM + 1];
   __shared__ int s_best[RPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -249,7 +263,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   const long pos_c = live ? pos_raw : nrows - 1;                     // dead groups mirror the last row, write nothing
   const long row = p.level == 2 ? (long)p.fb_list[pos_c] : pos_c;
   const int gshift = grp * GROUP;
-  const unsigned long long glow = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+  const unsigned long long glow = (1ull << GROUP) - 1ull;
   auto group_bits = [&](bool c) { return (__ballot(c) >> gshift) & glow; };
 
   // ---- everything the row needs, issued together ---------------------------
@@ -269,39 +283,38 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
     const int s = k * GROUP + sub;
     if (s < p.nsplit) r[k] = p.rec[(long)s * p.rows + row];
   }
-  float mu[DIM], var2[DIM], lsd[DIM];
-  {
-#pragma clang fp contract(off)
-    const f32x4 *pm = reinterpret_cast<const f32x4 *>(p.mu + row * DIM);
+  float cA[DIM], cB[DIM];
+  auto load_row = [&](const float *src, float (&dst)[DIM]) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
-    for (int q = 0; q < DIM / 4; ++q) {
-      const f32x4 v = pm[q];
-      mu[4 * q] = v.x; mu[4 * q + 1] = v.y; mu[4 * q + 2] = v.z; mu[4 * q + 3] = v.w;
+    for (int k = 0; k < DIM / 4; ++k) {
+      const f32x4 v = q[k];
+      dst[4 * k] = v.x; dst[4 * k + 1] = v.y; dst[4 * k + 2] = v.z; dst[4 * k + 3] = v.w;
     }
+  };
+  load_row(p.coef + row * 2 * DIM, cA);          // pass 1's operands: registers (16-byte broadcast loads)
+  load_row(p.coef + row * 2 * DIM + DIM, cB);
+  // pass 2's operands (mu | 2 sd^2 | log sd; used for the one or two codes that survive pass 1): LDS, one padded
+  // record per row so that the four rows of a wave sit in different banks
+  float *ops = s_ops[slot];
+  for (int i = sub; i < DIM; i += GROUP) {
+#pragma clang fp contract(off)
+    ops[i] = p.mu[row * DIM + i];
     if constexpr (MODE == kModeGQ) {
-      const f32x4 *ps = reinterpret_cast<const f32x4 *>(p.sd + row * DIM);
-      const f32x4 *pl = reinterpret_cast<const f32x4 *>(p.lsd + row * DIM);
-#pragma unroll
-      for (int q = 0; q < DIM / 4; ++q) {
-        const f32x4 v = ps[q], w = pl[q];
-        var2[4 * q] = 2.0f * (v.x * v.x); var2[4 * q + 1] = 2.0f * (v.y * v.y);
-        var2[4 * q + 2] = 2.0f * (v.z * v.z); var2[4 * q + 3] = 2.0f * (v.w * v.w);
-        lsd[4 * q] = w.x; lsd[4 * q + 1] = w.y; lsd[4 * q + 2] = w.z; lsd[4 * q + 3] = w.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < DIM; ++i) var2[i] = lsd[i] = 0.0f;
+      const float sg = p.sd[row * DIM + i];
+      ops[DIM + i] = 2.0f * (sg * sg);
+      ops[2 * DIM + i] = p.lsd[row * DIM + i];
     }
   }
 
-  // ---- rounding bound E(r) -> margin --------------------------------------
+  // ---- rounding bounds -> margins --------------------------------------------
   const double u = 5.9604644775390625e-08;  // 2^-24
   const double N1 = (double)N1f;
   double T, G;
   row_bound<MODE>(rs, N1, DIM, p.beta, T, G);
-  const double Ef = (double)p.ef_coeff * u * T;
   const double Er = MODE == kModeGQ ? (DIM + 16.0) * u * G : 1e-12 * T;
-  const double margin = 2.5 * (Ef + Er) + 1e-30;
+  const double margin = 2.5 * ((double)p.ef_coeff * u * T + Er) + 1e-30;      // around the filter's row maximum
+  const float margin32 = (float)(2.5 * ((2.0 * DIM + 4.0) * u * T + Er) * 1.0000002 + 1e-30);   // around pass 1's F (rounded up)
   bool bad = !(N1 == N1) || N1 > 1e18 || !(T < 1e30) || !(G < 1e30) || !(margin < 1e30);
 
   float fmax = NEG_INF;
@@ -340,30 +353,98 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- exact scores of every code in the flagged groups (GROUP = 16*gt codes each, one per lane) ----
+  // this lane's code t (0 .. GT-1) of candidate id: lane half (id & 1) of tile (id >> 1) * GT + t
+  const int code_in_tile = (sub & 3) + 8 * (sub >> 2);
+  auto code_of = [&](int id, int t) { return ((id >> 1) * GT + t) * kTileCodes + code_in_tile + 4 * (id & 1); };
+  auto expansion = [&](const float (&n)[DIM]) {   // fp32 FMA chain, the fp32 filter's operands
+    float f = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      f = __builtin_fmaf(cA[i], n[i] * n[i], f);
+      f = __builtin_fmaf(cB[i], n[i], f);
+    }
+    return f;
+  };
+  const int wave_total = [&] {   // wave-uniform trip count
+    int t = total;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t = max(t, __shfl_xor(t, o));
+    return t;
+  }();
+
+  // ---- pass 1: the fp32 expansion of every code of every candidate.  Per lane: the best value with its code row
+  // (kept in registers: it is almost always the only code of this lane that pass 2 wants) and the runner-up value;
+  // per row: F = the maximum over the group's 16 lanes. ----
+  constexpr int UNR = GT * DIM <= 32 ? GT : (DIM >= 32 ? 1 : 32 / DIM);     // code rows in flight per lane (<= 32 registers)
+  float nb[DIM], fb = NEG_INF, fsecond = NEG_INF;
+  int codeb = -1;
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) nb[i] = 0.0f;
+  for (int e = 0; e < wave_total; ++e) {
+    if (e < total) {
+      const int id = cand[slot][e];
+#pragma unroll
+      for (int t0 = 0; t0 < GT; t0 += UNR) {
+        float n[UNR][DIM];
+#pragma unroll
+        for (int t = 0; t < UNR; ++t) {       // out-of-range codes read the last code row and are skipped below
+          const int code = code_of(id, t0 + t);
+          load_row(p.cb + (long)(code < p.n ? code : p.n - 1) * DIM, n[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < UNR; ++t) {
+          const int code = code_of(id, t0 + t);
+          float f = expansion(n[t]);
+          if (f != f) f = __builtin_inff();   // a NaN value: "keep everything" below
+          if (code < p.n) {
+            const bool better = f > fb || codeb < 0;
+            fsecond = __builtin_fmaxf(fsecond, better ? fb : f);
+            if (better) {
+              fb = f;
+              codeb = code;
+#pragma unroll
+              for (int i = 0; i < DIM; ++i) nb[i] = n[t][i];
+            }
+          }
+        }
+      }
+    }
+  }
+  float F = fb;
+#pragma unroll
+  for (int o = GROUP / 2; o > 0; o >>= 1) F = __builtin_fmaxf(F, __shfl_xor(F, o));
+  const float thr32 = F - margin32;
+  const bool keep_all = !(F < __builtin_inff()) || !(margin32 < 1e30f);
+
+  // ---- pass 2: the reference's own score for the codes inside the window ----
   double best_s = 0.0;
   int best_i = 0x7fffffff;
   bool have = false;
-  for (int e = 0; __any(e < total); ++e) {
-    if (e < total) {
-      const int id = cand[slot][e];
-      const int tile = (id >> 1) * p.gt + (sub >> 4);
-      const int code = tile * kTileCodes + (sub & 3) + 8 * ((sub & 15) >> 2) + 4 * (id & 1);
-      if (code < p.n) {
-        float n[DIM];
-        const f32x4 *pn = reinterpret_cast<const f32x4 *>(p.cb + (long)code * DIM);
-#pragma unroll
-        for (int q = 0; q < DIM / 4; ++q) {
-          const f32x4 v = pn[q];
-          n[4 * q] = v.x; n[4 * q + 1] = v.y; n[4 * q + 2] = v.z; n[4 * q + 3] = v.w;
-        }
-        double s;
-        if constexpr (MODE == kModeGQ) s = (double)ref_score_regs<DIM>(n, mu, var2, lsd, p.beta);
-        else s = vq_neg_dist(n, mu, DIM);
-        if (!have || better_d(s, code, best_s, best_i)) {
-          best_s = s;
-          best_i = code;
-          have = true;
+  auto exact = [&](const float (&n)[DIM], int code) {
+    double s;
+    if constexpr (MODE == kModeGQ) s = (double)ref_score_lds<DIM>(n, ops, p.beta);
+    else s = vq_neg_dist(n, ops, DIM);
+    if (!have || better_d(s, code, best_s, best_i)) {
+      best_s = s;
+      best_i = code;
+      have = true;
+    }
+  };
+  if (codeb >= 0 && (keep_all || !(fb < thr32))) exact(nb, codeb);
+  // a second code of the SAME lane inside the window (rare: a near-tie within one lane's few codes): go through
+  // this lane's codes again
+  if (__any(codeb >= 0 && (keep_all || !(fsecond < thr32)) && fsecond > NEG_INF)) {
+    for (int e = 0; e < wave_total; ++e) {
+      if (e < total && (keep_all || !(fsecond < thr32))) {
+        const int id = cand[slot][e];
+        for (int t = 0; t < GT; ++t) {
+          const int code = code_of(id, t);
+          if (code < p.n && code != codeb) {
+            float n[DIM];
+            load_row(p.cb + (long)code * DIM, n);
+            float f = expansion(n);
+            if (keep_all || !(f < thr32)) exact(n, code);   // a NaN value passes
+          }
         }
       }
     }
@@ -409,9 +490,11 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   }
 }
 
-template <int MODE, int GROUP, int DIM>
-__global__ __launch_bounds__(256) void gq_rerank_kernel(const RerankParams p) {
-  rerank_block<MODE, GROUP, DIM>(p, (int)blockIdx.x, p.rows);
+// (256, 4): at most 128 VGPRs, four blocks per CU -- the kernel lives on memory-level parallelism across waves
+// (dim 32 needs 2 x 32 coefficient registers alone: two blocks per CU there)
+template <int MODE, int DIM, int GT>
+__global__ __launch_bounds__(256, DIM >= 32 ? 2 : 4) void gq_rerank_kernel(const RerankParams p) {
+  rerank_block<MODE, DIM, GT>(p, (int)blockIdx.x, p.rows);
 }
 
 // Second-stage filter for the rows the fp32 filter could not decide (fallback list).

@@ -19,7 +19,6 @@ namespace gqhip {
 template <int MODE, int DIM>
 __global__ __launch_bounds__(256, 1) void gq_tail_kernel(const RerankParams p, const FilterParams f2) {
   constexpr int GT2 = DIM <= 8 ? 4 : 2;      // tiles per candidate group of the fp32 filter
-  constexpr int GROUP2 = 16 * GT2;
   constexpr int CT2 = DIM == 32 ? 4 : 8;
   const int count_a = p.hdr->fb_count;       // final: written by the previous launch
   if (count_a == 0) return;
@@ -30,10 +29,10 @@ __global__ __launch_bounds__(256, 1) void gq_tail_kernel(const RerankParams p, c
       __syncthreads();
     }
     grid_barrier(p.hdr, gridDim.x);
-    constexpr int RPB = 4 * (64 / GROUP2);
+    constexpr int RPB = 4 * (64 / kRerankLanes);
     const int nvb_r = (count_a + RPB - 1) / RPB;
     for (int vb = blockIdx.x; vb < nvb_r; vb += gridDim.x) {
-      rerank_block<MODE, GROUP2, DIM>(p, vb, count_a);
+      rerank_block<MODE, DIM, GT2>(p, vb, count_a);
       __syncthreads();
     }
     grid_barrier(p.hdr, gridDim.x);

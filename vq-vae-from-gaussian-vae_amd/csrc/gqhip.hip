@@ -18,6 +18,7 @@
 #include "gq_filter_bf16.h"
 #include "gq_prep.h"
 #include "gq_rerank.h"
+#include "gq_scores.h"
 #include "gq_tail.h"
 
 using namespace gqhip;
@@ -72,14 +73,11 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   pl.bf16 = pl.mfma && want_bf16_filter();
   static const int env_waves = getenv("GQHIP_BF16_WAVES") ? atoi(getenv("GQHIP_BF16_WAVES")) : 0;
   pl.waves = pl.bf16 ? (env_waves == 4 ? 4 : 8) : 4;
-  // experiment: one wave per SIMD carrying four row tiles (same 512 rows per block, half the LDS operand reads per row)
-  static const int env_rt4 = getenv("GQHIP_BF16_RT4") ? atoi(getenv("GQHIP_BF16_RT4")) : 0;
-  if (pl.bf16 && env_rt4 == 1 && dim == 16 && rows >= 8192) { pl.waves = 4; pl.rt = 4; }
   pl.rows_per_block = 32 * pl.waves * pl.rt;
   pl.row_blocks = (int)((rows + pl.rows_per_block - 1) / pl.rows_per_block);
   // 4-wave blocks: ~2 blocks per CU on 256 CUs; 8-wave blocks: one per CU.  Splits in multiples of 8 so that
   // blockIdx % 8 (XCD) == split % 8.
-  const int target = env_blocks > 0 ? env_blocks : ((pl.waves == 8 || pl.rt == 4) ? 256 : 512);
+  const int target = env_blocks > 0 ? env_blocks : (pl.waves == 8 ? 256 : 512);
   int s = (target + pl.row_blocks - 1) / (pl.row_blocks > 0 ? pl.row_blocks : 1);
   s = ((s + 7) / 8) * 8;
   static const int env_nsplit = getenv("GQHIP_NSPLIT") ? atoi(getenv("GQHIP_NSPLIT")) : 0;
@@ -93,10 +91,17 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   pl.ct = dim == 32 ? 4 : ((dim == 16 && pl.waves == 8 && env_ct != 8) ? 16 : 8);
 
   static const int env_bgt = getenv("GQHIP_BF16_GT") ? atoi(getenv("GQHIP_BF16_GT")) : 0;
-  // split-bf16: the tracker's VALU work overlaps the bf16 MFMAs, so the finest candidate (one tile half =
-  // 16 codes) is free in the filter and halves / quarters the exact re-rank work
-  // (dim 4: two MFMAs per tile, the epilogue dominates -> the coarse 64-code candidate keeps the tracker cheap)
-  pl.gt = pl.bf16 ? (dim == 4 ? 4 : (((pl.waves == 4 || dim == 16) && (env_bgt == 2 || env_bgt == 4)) ? env_bgt : 1)) : (dim <= 8 ? 4 : 2);
+  // Candidate granularity of the split-bf16 filter: GT tiles per half-group.  The tracker's top-4 insert (12 VALU) runs
+  // once per GT tiles, and VALU issue is what the loop is short of (two waves per SIMD: ~83 % of the issue slots at GT 1),
+  // so coarse candidates make the filter faster (measured at config 2: GT 1 162 us, 2 157, 4 153); the re-rank's fp32
+  // pre-filter makes their 16 GT codes cheap to go through.  GT 1 / 2 / 8: diagnostics (2 and 8: dim 16, RT 2 only).
+  if (pl.bf16) {
+    pl.gt = 4;
+    if (env_bgt == 1 && dim != 4) pl.gt = 1;
+    if ((env_bgt == 2 || env_bgt == 8) && dim == 16 && pl.waves == 8 && pl.rt == 2 && pl.ct == 16) pl.gt = env_bgt;
+  } else {
+    pl.gt = dim <= 8 ? 4 : 2;
+  }
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   pl.gt2 = dim <= 8 ? 4 : 2;
@@ -109,7 +114,7 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WsLayout {
-  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, rowsum, cbimg, rowimg, total;
+  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, rowsum, coef, cbimg, rowimg, total;
 };
 
 WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
@@ -127,6 +132,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.sd = off;  off += align256(4 * rows * dim);
   w.lsd = off; off += align256(4 * rows * dim);
   w.rowsum = off; off += pl.mfma ? align256(8 * 4 * rows) : 0;
+  w.coef = off; off += pl.mfma ? align256(4 * 2 * rows * dim) : 0;
   // split-bf16 operand images: 2*NV vectors of 16 B per (code, half) / (row, half), NV = dim / 8
   const int64_t nvec = dim == 4 ? 2 : dim / 4;
   w.cbimg = off;  off += pl.bf16 ? align256((int64_t)(pl.tiles_total + pl.ct) * nvec * 64 * 16) : 0;
@@ -199,23 +205,22 @@ int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t s
   return check_launch();
 }
 
-// re-rank: GROUP = codes per candidate = lanes per row (16 * gt); DIM in registers
+// re-rank: 16 lanes per row, 16 rows per block; row operands (DIM) and the first candidate's GT code rows in registers
 template <int MODE>
 int launch_rerank(const RerankParams &rp, int64_t rows, int dim, hipStream_t st) {
-#define GQ_RR(G, D)                                                                                     \
-  hipLaunchKernelGGL((gq_rerank_kernel<MODE, G, D>), dim3((unsigned)((rows + (256 / G) - 1) / (256 / G))), \
-                     dim3(256), 0, st, rp)
-  const int key = rp.gt * 100 + dim;
-  switch (key) {
-    case 104: GQ_RR(16, 4); break;
-    case 108: GQ_RR(16, 8); break;
-    case 116: GQ_RR(16, 16); break;
-    case 132: GQ_RR(16, 32); break;
-    case 216: GQ_RR(32, 16); break;
-    case 232: GQ_RR(32, 32); break;
-    case 404: GQ_RR(64, 4); break;
-    case 408: GQ_RR(64, 8); break;
-    case 416: GQ_RR(64, 16); break;
+  const dim3 grid((unsigned)((rows + 15) / 16));
+#define GQ_RR(D, G) hipLaunchKernelGGL((gq_rerank_kernel<MODE, D, G>), grid, dim3(256), 0, st, rp)
+  switch (dim * 100 + rp.gt) {
+    case 404: GQ_RR(4, 4); break;
+    case 801: GQ_RR(8, 1); break;
+    case 804: GQ_RR(8, 4); break;
+    case 1601: GQ_RR(16, 1); break;
+    case 1602: GQ_RR(16, 2); break;
+    case 1604: GQ_RR(16, 4); break;
+    case 1608: GQ_RR(16, 8); break;
+    case 3201: GQ_RR(32, 1); break;
+    case 3202: GQ_RR(32, 2); break;
+    case 3204: GQ_RR(32, 4); break;
     default: return GQHIP_ERR_INVALID_ARG;
   }
 #undef GQ_RR
@@ -241,15 +246,13 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, hipStr
     else if (pl.gt == 1) GQ_LAUNCH_BF1(NV, R, C, 1, 4);                                                   \
     else GQ_LAUNCH_BF1(NV, R, C, 4, 4);                                                                   \
   } while (0)
-  if (pl.rt == 4) {          // experiment (GQHIP_BF16_RT4=1): dim 16 only
-    if (pl.gt == 2) GQ_LAUNCH_BF1(2, 4, 8, 2, 4);
-    else GQ_LAUNCH_BF1(2, 4, 8, 1, 4);
-  } else if (pl.rt == 2) {
+  if (pl.rt == 2) {
     switch (dim) {
       case 4: GQ_LAUNCH_BF(0, 2, 8); break;
       case 8: GQ_LAUNCH_BF(1, 2, 8); break;
       case 16:
         if (pl.ct == 16 && pl.gt == 2) GQ_LAUNCH_BF1(2, 2, 16, 2, 8);
+        else if (pl.ct == 16 && pl.gt == 8) GQ_LAUNCH_BF1(2, 2, 16, 8, 8);
         else if (pl.ct == 16 && pl.gt == 4) GQ_LAUNCH_BF1(2, 2, 16, 4, 8);
         else if (pl.ct == 16) GQ_LAUNCH_BF1(2, 2, 16, 1, 8);
         else GQ_LAUNCH_BF(2, 2, 8);
@@ -356,6 +359,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   RerankParams rp{};
   rp.mu = r_mu; rp.sd = r_sd; rp.lsd = r_lsd; rp.cb = cb;
   rp.rowsum = reinterpret_cast<const double *>(ws + w.rowsum);
+  rp.coef = reinterpret_cast<const float *>(ws + w.coef);
   rp.rec = reinterpret_cast<const Rec *>(ws + w.rec);
   rp.idx = idx; rp.zhat = zhat; rp.hdr = hdr;
   rp.fb_list = reinterpret_cast<int *>(ws + w.fb);
@@ -394,6 +398,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   pp.lsd = const_cast<float *>(from_z ? ws_lsd : lsd);
   pp.lsd_out = (!from_z && MODE == kModeGQ && !lsd) ? ws_lsd : nullptr;
   pp.rowsum = reinterpret_cast<double *>(ws + w.rowsum);
+  pp.coef = reinterpret_cast<float *>(ws + w.coef);
   pp.rowimg = pl.bf16 ? reinterpret_cast<u32x4 *>(ws + w.rowimg) : nullptr;
   pp.cb = cb;
   pp.cbimg = pl.bf16 ? reinterpret_cast<u32x4 *>(ws + w.cbimg) : nullptr;
@@ -496,6 +501,31 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
   if (rows == 0) return GQHIP_OK;
   if (!mu || !sd || !cb || !out) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // Default: the score matrix on the fp32 matrix cores (gq_scores.h; HBM-write bound).  GQHIP_SCORES=direct: the
+  // per-pair restatement of the CUDA kernel's formula (VALU bound, ~3x slower).  Non-finite beta, dims outside
+  // {4, 8, 16, 32}: per-pair kernels.
+  static const bool env_direct = getenv("GQHIP_SCORES") && getenv("GQHIP_SCORES")[0] == 'd';
+  if (!env_direct && (dim == 4 || dim == 8 || dim == 16 || dim == 32) && beta == beta && n >= 32) {
+    ScoresParams sp{};
+    sp.mu = mu; sp.sd = sd; sp.cb = cb; sp.out = out; sp.rows = (int)rows; sp.n = (int)n; sp.beta = beta;
+    sp.tiles_total = (int)((n + kTileCodes - 1) / kTileCodes);
+    constexpr int RT = 2;
+    const int row_blocks = (int)((rows + 128 * RT - 1) / (128 * RT));
+    int s = (512 + row_blocks - 1) / row_blocks;      // ~2 blocks per CU; splits in multiples of 8 (XCD = blockIdx % 8)
+    s = ((s + 7) / 8) * 8;
+    if (s > sp.tiles_total) s = sp.tiles_total;
+    if (s < 1) s = 1;
+    sp.tiles_per_split = (sp.tiles_total + s - 1) / s;
+    sp.nsplit = (sp.tiles_total + sp.tiles_per_split - 1) / sp.tiles_per_split;
+    const dim3 grid((unsigned)(row_blocks * sp.nsplit));
+    switch (dim) {
+      case 4: hipLaunchKernelGGL((gq_scores_mfma_kernel<4, RT, 8>), grid, dim3(256), 0, st, sp); break;
+      case 8: hipLaunchKernelGGL((gq_scores_mfma_kernel<8, RT, 8>), grid, dim3(256), 0, st, sp); break;
+      case 16: hipLaunchKernelGGL((gq_scores_mfma_kernel<16, RT, 8>), grid, dim3(256), 0, st, sp); break;
+      default: hipLaunchKernelGGL((gq_scores_mfma_kernel<32, RT, 4>), grid, dim3(256), 0, st, sp); break;
+    }
+    return check_launch();
+  }
   const int cpt = 1;   // codes per thread of gq_scores_kernel (CPT there)
   const unsigned gx = (unsigned)((n + 256 * cpt - 1) / (256 * cpt));
   constexpr int ROWS = 16;
