@@ -9,6 +9,10 @@ cp "$SRC/SUMMARY.txt" "$SRC/STEADY_STATE.txt" "$DST/"
 cp "$(find "$SRC/bench_trace" -name '*kernel_stats.csv' | head -1)" "$DST/bench_kernel_stats.csv"
 cp "$(find "$SRC/kbench_trace" -name '*kernel_stats.csv' | head -1)" "$DST/kbench_kernel_stats.csv"
 cp "$(find "$SRC/kbench_fp32_trace" -name '*kernel_stats.csv' | head -1)" "$DST/kbench_fp32_kernel_stats.csv"
+if [ -d "$SRC/variants_trace" ]; then   # compat score op, VQ / LFQ at 512x512, module-level call (tools/kbench_variants.py)
+  cp "$(find "$SRC/variants_trace" -name '*kernel_stats.csv' | head -1)" "$DST/variants_kernel_stats.csv"
+  grep -h -E "^(compat|vq_|lfq_|gq_)" "$SRC/variants_stdout.txt" > "$DST/variants_lines.txt" || true
+fi
 for C in FETCH_SIZE WRITE_SIZE; do
   # keep only the gqhip kernels' rows (small, what bench.py reads)
   f=$(find "$SRC/pmc_$C" -name '*counter_collection.csv' | head -1)
