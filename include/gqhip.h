@@ -189,19 +189,31 @@ int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t 
  * (tiles = B * H/2 * W/2, H and W even); after the 16 GEMMs M[k] = V[k] x U[k] (U = G g G^T, [16, Cin, Cout]) the
  * output transform writes y [B, H, W, Cout] = A^T M A.  16 instead of 36 multiplies per 2x2 outputs. */
 int wino_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
-int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+/* `mscale` (all three output transforms): y = mscale * (A^T M A) (+ bias, + res): 1 for fp32 operands, the inverse of
+ * the operands' power-of-two scales behind wino_in_nhwc_f16x3. */
+int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream);
+
+/* The input transforms (tile = 2: F(2x2,3x3), 4: F(4x4,3x3)) writing the operand of ONE fp16 GEMM with fp32 accumulation
+ * whose K axis carries the three products of two-term fp16 splits: V3 [16|36, tiles, 3C] fp16 = [h | h | l] of
+ * (B^T d B) * scale, to be multiplied by U3 [16|36, 3C, Cout] fp16 = [U_h ; U_l ; U_h]: the products h U_h + h U_l + l U_h
+ * carry 22-bit operands (error 2.5-2.9e-7 of sum |a||b| measured -- the level of hipBLASLt's own fp32 GEMM, which is a
+ * split-bf16 emulation on gfx950 -- at 1.2-2.5x its speed).  `scale`: a power of two with |V| * scale < 65504 (the
+ * caller derives it from the GroupNorm that feeds the convolution: |SiLU(GN(x))| <= sqrt(n - 1) max|gamma| + max|beta|). */
+int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
+                       void *stream);
 
 /* Winograd F(4x4, 3x3): V [36, tiles, C] of the 6x6 input tiles (tiles = B * H/4 * W/4, H and W multiples of 4) and
  * y [B, H, W, Cout] from M [36, tiles, Cout]; U = G g G^T is [36, Cin, Cout].  36 multiplies per 16 outputs and 2.25x
  * (instead of 4x) the activation in V / M, at ~10x the rounding error of F(2x2,3x3): the decoder's convolutions. */
 int wino4_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
-int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream);
 
 /* Output transform (tile = 2: F(2x2,3x3), M [16, tiles, C]; tile = 4: F(4x4,3x3), M [36, tiles, C]) with the ResnetBlock's
  * tail fused in (pit/modules/unet.py:149-153): y = A^T M A + bias[c] (+ res, may be NULL), plus the GroupNorm statistics of y
  * (stats_out as add_bias_stats_f32) for the block that follows.  Needs (C/groups) % 4 == 0, 256 % (C/4) == 0. */
 int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or_null, float *y, double *stats_out,
-                          int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups, int tile, void *stream);
+                          int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups, int tile, float mscale,
+                          void *stream);
 
 /* NHWC only.  GroupNorm statistics alone (the first pass of gn_silu_f32): stats_out[2*(b*groups+g)] = sum, [+1] = sum of
  * squares of x (+ pre_bias[c]) over the group, fp64, zeroed here. */
@@ -223,12 +235,23 @@ int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, 
  * padding-1 2x2 convolution of the LOW-resolution input with the four phase kernels stacked along the output channels
  * (phase (a, b) = sums of the 3x3 taps that fall on the same source pixel); y [B, 2H, 2W, C] NHWC,
  * y[b][2i+a][2j+b'][c] = src[b][i+a][j+b'][(2a+b')*C + c].  2.25x fewer conv flops than upsampling first. */
-int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C,
+                            const float *mscale_dev_or_null, void *stream);
 
 /* The 2x2 patches (padding 1) of an NHWC tensor x [B, H, W, C] as GEMM rows: A [B*(H+1)*(W+1), 4*C],
  * A[(b,p,q)][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c] (zero outside).  A x Wmat [4C, 4*Cout] is the `src` of
  * upconv_shuffle_nhwc_f32 (the phase convolution as one hipBLASLt GEMM). */
 int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
+
+/* The same patches as the operand of ONE fp16 GEMM whose K axis carries the three products of two-term fp16 splits (see
+ * wino_in_nhwc_f16x3): A3 [B*(H+1)*(W+1), 3 * 4C] fp16 = [h | h | l] of x * scales_dev[0], times Wmat3 [3 * 4C, 4*Cout] =
+ * [W_h; W_l; W_h] of Wmat * u_scale; upconv_shuffle_nhwc_f32 multiplies by mscale_dev = scales_dev + 1.  The scales are
+ * DEVICE floats produced by f16_scales_from_gn_stats from the GroupNorm statistics [2 * n_bg] (sum, sum of squares per
+ * (image, group)) that the producer of x left behind: bound = sqrt(max sum of squares) >= max|x| rigorously, no host sync. */
+int upconv_im2col_nhwc_f16x3(const float *x, void *A3, int64_t B, int64_t H, int64_t W, int64_t C,
+                             const float *scales_dev, void *stream);
+int f16_scales_from_gn_stats(const double *stats, int64_t n_bg, double amp, double u_scale, float *scales_out,
+                             void *stream);
 
 /* ---- index wire format / usage histogram ----------------------------------- */
 int gq_index_histogram(const int64_t *idx, int64_t count, int64_t n,

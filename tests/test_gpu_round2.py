@@ -324,3 +324,105 @@ def test_weight_caches_follow_data_writes_after_invalidate():
     assert float((y1 - y0).abs().max()) > 1e-3          # the weights did change the output
     scale = float(ref.abs().max())
     assert float((y1 - ref).abs().max()) <= 2e-4 * max(scale, 1.0), (float((y1 - ref).abs().max()), scale)
+
+
+def test_winograd_f16x3_gemm_is_as_accurate_as_the_fp32_gemm():
+    """The Winograd GEMMs as one fp16 GEMM over a K axis carrying the three products of two-term fp16 splits
+    (wino_in_nhwc_f16x3 + torch.bmm(out_dtype=fp32)): against an fp64 convolution the error must be no worse than
+    1.5x the library's fp32-GEMM route (itself a split-bf16 emulation on gfx950), for both tile sizes, incl. inputs near
+    the bound the scale is derived from and a 1e4x larger one (the power-of-two scales are exact)."""
+    import torch.nn.functional as F
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(5)
+    for cin, cout, H, W, amp in ((256, 256, 16, 24, 1.0), (512, 512, 8, 8, 1.0), (128, 128, 32, 32, 30.0), (128, 256, 16, 16, 1e-3)):
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+        x = (amp * torch.randn(2, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
+        bound = float(x.abs().max())
+        with torch.no_grad():
+            ref = F.conv2d(x.double(), conv.weight.double(), None, 1, 1)
+            scale = float(ref.abs().mean())
+            for f4 in (False, True):
+                Uw = U._wino_weights(conv, f4)
+                u3, us = U._wino_weights_f16(conv, f4)
+                assert u3.dtype == torch.float16 and tuple(u3.shape) == (Uw.shape[0], 3 * cin, cout)
+                y32 = _lib.wino_conv3x3(x, Uw)
+                for b in (bound, bound * 1e4):
+                    y16 = _lib.wino_conv3x3(x, Uw, f16=(u3, us, b))
+                    assert torch.isfinite(y16).all()
+                    e32 = float((y32.double() - ref).abs().max()) / scale
+                    e16 = float((y16.double() - ref).abs().max()) / scale
+                    print(f"F({4 if f4 else 2},3) {cin}->{cout} amp {amp:g} bound x{b / bound:g}: fp32 GEMM {e32:.2e}, f16x3 {e16:.2e}")
+                    assert e16 <= 1.5 * e32 + 1e-7, (e16, e32)
+                # fused tail (bias + residual + statistics) goes through the same scale
+                res = torch.randn_like(y32)
+                y_a, st_a = _lib.wino_conv3x3(x, Uw, residual=res, bias=conv.bias, stats_groups=32)
+                y_b, st_b = _lib.wino_conv3x3(x, Uw, residual=res, bias=conv.bias, stats_groups=32, f16=(u3, us, bound))
+                assert float((y_a - y_b).abs().max()) <= 4e-3 * scale if f4 else 4e-4 * scale
+                assert torch.allclose(st_a, st_b, rtol=1e-4, atol=1e-2)
+
+
+def test_gn_act_bound_is_a_bound_and_unet_agrees_with_fp32_gemms():
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(6)
+    norm = torch.nn.GroupNorm(32, 128, eps=1e-6).to(DEV)
+    with torch.no_grad():
+        norm.weight.mul_(3.0).add_(torch.randn(128, device=DEV))
+        norm.bias.add_(torch.randn(128, device=DEV))
+    x = torch.randn(2, 128, 16, 16, device=DEV)
+    x[0, 5, 3, 3] = 1e4                                  # one outlier: the worst case of the bound
+    with torch.no_grad():
+        y = U._norm_act(norm, x.contiguous(memory_format=torch.channels_last))
+    assert float(y.abs().max()) <= U._gn_act_bound(norm, x) and y._act_bound == U._gn_act_bound(norm, x)
+    cfg = dict(ch=128, out_ch=3, in_channels=3, resolution=64, z_channels=16, double_z=True, ch_mult=[1, 2, 4, 4],
+               num_res_blocks=2, attn_resolutions=[8], dropout=0.0)
+    dec = U.Decoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
+    enc = U.Encoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
+    z = torch.randn(2, 16, 8, 8).to(DEV).contiguous(memory_format=torch.channels_last)
+    img = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    outs = []
+    with torch.no_grad():
+        for flag in (True, False):
+            U.WINOGRAD_F16X3 = flag
+            outs.append((dec(z).float(), enc(img).float()))
+    U.WINOGRAD_F16X3 = True
+    d_dec = float((outs[0][0] - outs[1][0]).abs().max()) / max(1.0, float(outs[1][0].abs().max()))
+    d_enc = float((outs[0][1] - outs[1][1]).abs().max())
+    print(f"f16x3 vs fp32 GEMMs: decoder rel diff {d_dec:.2e}, encoder z abs diff {d_enc:.2e}")
+    assert d_dec <= 2e-5 and d_enc <= 2e-5
+
+
+def test_subpixel_upconv_f16x3_matches_fp32_route():
+    """Upsample (nearest x2 + conv3x3) through the fp16 x 3 GEMM with device-side scales from the GroupNorm statistics:
+    same accuracy against an fp64 reference as the fp32-GEMM route, also when the tensor carries a huge outlier (the
+    bound is rigorous: sqrt of the group's sum of squares)."""
+    import torch.nn.functional as F
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(8)
+    for ch, H, W, outlier in ((256, 16, 16, 0.0), (512, 8, 12, 0.0), (128, 32, 32, 3e4)):
+        up = U.Upsample(ch).eval().to(DEV).to(memory_format=torch.channels_last)
+        x = torch.randn(2, ch, H, W)
+        if outlier:
+            x[1, 7, 3, 5] = outlier
+        x = x.to(DEV).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), up.conv.weight.double(), None, 1, 1)
+            scale = float(ref.abs().mean())
+            U.WINOGRAD_F16X3 = False
+            y32, b32 = up(x)
+            U.WINOGRAD_F16X3 = True
+            xs = x.clone(memory_format=torch.channels_last)
+            xs._gn_stats = (_lib.gn_stats(xs, 32), 32)
+            y16, b16 = up(xs)
+            sc = _lib.f16_scales(xs._gn_stats[0], 1.0, up._phase_weights_f16()[1]).cpu()
+        assert torch.isfinite(y16).all() and b16 is b32
+        e32 = float((y32.double() - ref).abs().max()) / scale
+        e16 = float((y16.double() - ref).abs().max()) / scale
+        vs = float(sc[0])
+        assert vs == 2.0 ** round(np.log2(vs)) and float(x.abs().max()) * vs <= 32768.0      # a power of two, in range
+        print(f"upconv {ch} {H}x{W} outlier {outlier:g}: fp32 GEMM {e32:.2e}, f16x3 {e16:.2e}, v_scale 2^{int(np.log2(vs))}")
+        assert e16 <= 1.5 * e32 + 1e-7

@@ -318,8 +318,34 @@ __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__res
 //   V[k][tile][c] = (B^T d B)[k]     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
 //   y[2x2]        = A^T m A          A^T = [1 1 1 0; 0 1 -1 -1]
 // One thread per (tile, channel quad); tiles = B * (H/2) * (W/2), H and W even.
-__global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restrict__ x, float *__restrict__ V, int H, int W,
-                                                           int C4, long tiles, long total) {
+// Where a transformed value goes.  F16X3 = false: V [k][tile][C] fp32.  F16X3 = true: the operand of ONE fp16 GEMM with
+// fp32 accumulation whose K axis carries the three split products (v = h + l, two-term fp16 split of v * scale):
+// V3 [k][tile][3C] fp16 = [ h | h | l ], to be multiplied by U3 [k][3C][Cout] = [ U_h ; U_l ; U_h ] (unet._wino_weights_f16):
+// V3 U3 = h U_h + h U_l + l U_h, error ~3 * 2^-22 per product -- the level of hipBLASLt's own fp32 (split-bf16) GEMM, at
+// 2-2.5x its speed (tools/bmm_bf16x3.py).  `scale` is a power of two chosen by the caller so that |v * scale| < 65504.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <bool F16X3>
+__device__ __forceinline__ void wino_store_v(void *V, int k, long tiles, long tile, int C4, int q, f32x4 v, float scale) {
+  if constexpr (F16X3) {
+    v = v * scale;
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (_Float16)v[e];
+      l[e] = (_Float16)(v[e] - (float)h[e]);
+    }
+    f16x4 *row = reinterpret_cast<f16x4 *>(V) + ((long)k * tiles + tile) * (3 * C4);
+    row[q] = h;
+    row[C4 + q] = h;
+    row[2 * C4 + q] = l;
+  } else {
+    reinterpret_cast<f32x4 *>(V)[((long)k * tiles + tile) * C4 + q] = v;
+  }
+}
+
+template <bool F16X3>
+__global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restrict__ x, void *__restrict__ V, int H, int W,
+                                                           int C4, long tiles, long total, float scale) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int q = (int)(t % C4);
     const long tile = t / C4;
@@ -345,14 +371,12 @@ __global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restri
       w[2][j] = d[2][j] - d[1][j];
       w[3][j] = d[1][j] - d[3][j];
     }
-    f32x4 *o = reinterpret_cast<f32x4 *>(V) + tile * C4 + q;
-    const long plane = tiles * C4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {   // (B^T d) B
-      o[(4 * i + 0) * plane] = w[i][0] - w[i][2];
-      o[(4 * i + 1) * plane] = w[i][1] + w[i][2];
-      o[(4 * i + 2) * plane] = w[i][2] - w[i][1];
-      o[(4 * i + 3) * plane] = w[i][1] - w[i][3];
+      wino_store_v<F16X3>(V, 4 * i + 0, tiles, tile, C4, q, w[i][0] - w[i][2], scale);
+      wino_store_v<F16X3>(V, 4 * i + 1, tiles, tile, C4, q, w[i][1] + w[i][2], scale);
+      wino_store_v<F16X3>(V, 4 * i + 2, tiles, tile, C4, q, w[i][2] - w[i][1], scale);
+      wino_store_v<F16X3>(V, 4 * i + 3, tiles, tile, C4, q, w[i][1] - w[i][3], scale);
     }
   }
 }
@@ -429,8 +453,9 @@ __global__ __launch_bounds__(256) void wino_in_gn_nhwc_kernel(const float *__res
   }
 }
 
+// `mscale`: M came out of a GEMM on scaled operands (the f16x3 path): y = mscale * (A^T M A); 1 otherwise (a power of two).
 __global__ __launch_bounds__(256) void wino_out_nhwc_kernel(const float *__restrict__ M, float *__restrict__ y, int H, int W,
-                                                            int C4, long tiles, long total) {
+                                                            int C4, long tiles, long total, float mscale) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int q = (int)(t % C4);
     const long tile = t / C4;
@@ -454,8 +479,8 @@ __global__ __launch_bounds__(256) void wino_out_nhwc_kernel(const float *__restr
     f32x4 *o = reinterpret_cast<f32x4 *>(y) + ((b * H + 2 * th) * W + 2 * tw) * C4 + q;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      o[(long)i * W * C4] = u[i][0] + u[i][1] + u[i][2];
-      o[(long)i * W * C4 + C4] = u[i][1] - u[i][2] - u[i][3];
+      o[(long)i * W * C4] = (u[i][0] + u[i][1] + u[i][2]) * mscale;
+      o[(long)i * W * C4 + C4] = (u[i][1] - u[i][2] - u[i][3]) * mscale;
     }
   }
 }
@@ -481,8 +506,9 @@ __device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&o)[4]) {
   o[3] = d12 + 8.f * d34 + m[5];
 }
 
-__global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restrict__ x, float *__restrict__ V, int H, int W,
-                                                            int C4, long tiles, long total) {
+template <bool F16X3>
+__global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restrict__ x, void *__restrict__ V, int H, int W,
+                                                            int C4, long tiles, long total, float scale) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int q = (int)(t % C4);
     const long tile = t / C4;
@@ -506,14 +532,12 @@ __global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restr
 #pragma unroll
       for (int i = 0; i < 6; ++i) w[i][j] = o[i];
     }
-    f32x4 *out = reinterpret_cast<f32x4 *>(V) + tile * C4 + q;
-    const long plane = tiles * C4;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {   // (B^T d) B, row by row
       f32x4 o[6];
       wino4_bt(w[i], o);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) out[(6 * i + j) * plane] = o[j];
+      for (int j = 0; j < 6; ++j) wino_store_v<F16X3>(V, 6 * i + j, tiles, tile, C4, q, o[j], scale);
     }
   }
 }
@@ -586,7 +610,7 @@ __global__ __launch_bounds__(256) void wino4_in_gn_nhwc_kernel(const float *__re
 }
 
 __global__ __launch_bounds__(256) void wino4_out_nhwc_kernel(const float *__restrict__ M, float *__restrict__ y, int H, int W,
-                                                             int C4, long tiles, long total) {
+                                                             int C4, long tiles, long total, float mscale) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int q = (int)(t % C4);
     const long tile = t / C4;
@@ -612,7 +636,7 @@ __global__ __launch_bounds__(256) void wino4_out_nhwc_kernel(const float *__rest
       f32x4 o[4];
       wino4_at(u[i], o);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) out[((long)i * W + j) * C4] = o[j];
+      for (int j = 0; j < 4; ++j) out[((long)i * W + j) * C4] = o[j] * mscale;
     }
   }
 }
@@ -624,7 +648,7 @@ template <int T>
 __global__ __launch_bounds__(256) void wino_out_res_nhwc_kernel(const float *__restrict__ M, const float *__restrict__ res,
                                                                 const float *__restrict__ bias, float *__restrict__ y,
                                                                 double *__restrict__ stats, int H, int W, int C4,
-                                                                int cpg, long tiles, int slabs) {
+                                                                int cpg, long tiles, int slabs, float mscale) {
   constexpr int NI = T + 2;   // transform size (4 or 6)
   __shared__ double red[2 * 64];
   const int groups = 4 * C4 / cpg, lanes = 256 / C4;
@@ -672,7 +696,7 @@ __global__ __launch_bounds__(256) void wino_out_res_nhwc_kernel(const float *__r
 #pragma unroll
       for (int j = 0; j < T; ++j) {
         const long off = pix0 + ((long)i * W + j) * C4;
-        f32x4 v = o[j] + pb;
+        f32x4 v = o[j] * mscale + pb;
         if (res) v = v + reinterpret_cast<const f32x4 *>(res)[off];
         reinterpret_cast<f32x4 *>(y)[off] = v;
         s += (v.x + v.y) + (v.z + v.w);
@@ -689,8 +713,14 @@ __global__ __launch_bounds__(256) void wino_out_res_nhwc_kernel(const float *__r
 
 // im2col of the 2x2 phase convolution (padding 1) of an NHWC tensor: A[b][p][q][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c]
 // (zero outside), p in [0, H], q in [0, W].  One thread per (patch position, tap, channel quad).
-__global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__restrict__ x, float *__restrict__ A,
-                                                                 int H, int W, int C4, long total) {
+// F16X3: the patches as the operand of ONE fp16 GEMM over a K axis carrying the three products of two-term fp16 splits
+// (see wino_store_v): A3 [rows][3 * 4C] fp16 = [h | h | l] of x * scales[0]; the scale lives in DEVICE memory
+// (f16_scales_from_stats_kernel derives it from the GroupNorm statistics the producer left behind: no host sync).
+template <bool F16X3>
+__global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__restrict__ x, void *__restrict__ A,
+                                                                 int H, int W, int C4, long total,
+                                                                 const float *__restrict__ scales) {
+  const float scale = F16X3 ? scales[0] : 1.0f;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int q4 = (int)(t % C4);
     long r = t / C4;
@@ -703,7 +733,53 @@ __global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__
     const int sy = p + (tap >> 1) - 1, sx = q + (tap & 1) - 1;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q4];
-    reinterpret_cast<f32x4 *>(A)[t] = v;
+    if constexpr (F16X3) {
+      v = v * scale;
+      f16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (_Float16)v[e];
+        l[e] = (_Float16)(v[e] - (float)h[e]);
+      }
+      const long row = t / (4L * C4);                 // patch position
+      const int col = (int)(t % (4L * C4));           // (tap, channel quad) within the 4C patch
+      f16x4 *o = reinterpret_cast<f16x4 *>(A) + row * (12L * C4) + col;
+      o[0] = h;
+      o[4 * C4] = h;
+      o[8 * C4] = l;
+    } else {
+      reinterpret_cast<f32x4 *>(A)[t] = v;
+    }
+  }
+}
+
+// scales[0] = v_scale = the largest power of two with amp * bound * v_scale <= 32768, bound = sqrt(max over (image,
+// group) of the sum of squares) >= max|x| (rigorous: the L2 norm of a group bounds its largest element), from the
+// GroupNorm statistics [2 * n_bg] (sum, sum of squares) the producer of x left behind; scales[1] = 1 / (v_scale * u_scale),
+// the factor that takes the GEMM result back.  One wave.
+__global__ __launch_bounds__(64) void f16_scales_from_stats_kernel(const double *__restrict__ stats, int n_bg, float amp,
+                                                                   float u_scale, float *__restrict__ scales) {
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n_bg; i += 64) {
+    const double ss = stats[2 * i + 1];
+    m = (ss != ss) ? __builtin_inf() : (ss > m ? ss : m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_xor(m, o);
+    m = other > m ? other : m;
+  }
+  if (threadIdx.x == 0) {
+    const double bound = sqrt(m) * (double)amp;
+    int e = 14;                                        // never scale UP by more than 2^14
+    if (bound > 0.0 && bound < 1e300) {
+      int eb;
+      (void)frexp(32768.0 / bound, &eb);               // 32768 / bound = f * 2^eb, f in [0.5, 1)
+      e = eb - 1 < 14 ? eb - 1 : 14;
+    }
+    const float vs = (float)ldexp(1.0, e);
+    scales[0] = vs;
+    scales[1] = (float)(1.0 / ((double)vs * (double)u_scale));
   }
 }
 
@@ -711,8 +787,11 @@ __global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__
 // (a, b) = (oy & 1, ox & 1) are 2x2 convolutions of the LOW-resolution input (weights = sums of the 3x3 taps that fall
 // on the same source pixel); one conv computes all four as 4*C output channels on an (H+1) x (W+1) grid (padding 1),
 //   y[b][2i+a][2j+b'][c] = src[b][i+a][j+b'][(2a+b')*C + c].   NHWC, one thread per (output pixel, channel quad).
+// `mscale_dev` (device pointer or NULL): y = *mscale_dev * src (the f16x3 GEMM's result on scaled operands).
 __global__ __launch_bounds__(256) void upconv_shuffle_nhwc_kernel(const float *__restrict__ src, float *__restrict__ y,
-                                                                  int H, int W, int C4, long total) {
+                                                                  int H, int W, int C4, long total,
+                                                                  const float *__restrict__ mscale_dev) {
+  const float mscale = mscale_dev ? *mscale_dev : 1.0f;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int q = (int)(t % C4);
     long p = t / C4;
@@ -722,7 +801,7 @@ __global__ __launch_bounds__(256) void upconv_shuffle_nhwc_kernel(const float *_
     const long b = p / (2 * H);
     const int a = oy & 1, bb = ox & 1;
     const long sp = (b * (H + 1) + (oy >> 1) + a) * (W + 1) + (ox >> 1) + bb;   // source pixel
-    reinterpret_cast<f32x4 *>(y)[t] = reinterpret_cast<const f32x4 *>(src)[sp * (4L * C4) + (2 * a + bb) * C4 + q];
+    reinterpret_cast<f32x4 *>(y)[t] = reinterpret_cast<const f32x4 *>(src)[sp * (4L * C4) + (2 * a + bb) * C4 + q] * mscale;
   }
 }
 

@@ -745,8 +745,28 @@ int wino_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, 
   const long tiles = (long)(B * (H / 2) * (W / 2)), total = tiles * (C / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(wino_in_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, V,
-                     (int)H, (int)W, (int)(C / 4), tiles, total);
+  hipLaunchKernelGGL(wino_in_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     (void *)V, (int)H, (int)W, (int)(C / 4), tiles, total, 1.0f);
+  return check_launch();
+}
+
+int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
+                       void *stream) {
+  if ((tile != 2 && tile != 4) || B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 ||
+      !(scale > 0.f))
+    return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !V3) return GQHIP_ERR_INVALID_ARG;
+  const long tiles = (long)(B * (H / tile) * (W / tile)), total = tiles * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tile == 4)
+    hipLaunchKernelGGL(wino4_in_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, V3, (int)H, (int)W,
+                       (int)(C / 4), tiles, total, scale);
+  else
+    hipLaunchKernelGGL(wino_in_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, V3, (int)H, (int)W,
+                       (int)(C / 4), tiles, total, scale);
   return check_launch();
 }
 
@@ -807,7 +827,7 @@ int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, 
   return wino_in_gn_nhwc_f32_impl(4, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, stream);
 }
 
-int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
+int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream) {
   if (B < 0 || H < 2 || W < 2 || H % 2 || W % 2 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!M || !y) return GQHIP_ERR_INVALID_ARG;
@@ -815,7 +835,7 @@ int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W,
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(wino_out_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), M, y,
-                     (int)H, (int)W, (int)(C / 4), tiles, total);
+                     (int)H, (int)W, (int)(C / 4), tiles, total, mscale);
   return check_launch();
 }
 
@@ -826,12 +846,12 @@ int wino4_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W,
   const long tiles = (long)(B * (H / 4) * (W / 4)), total = tiles * (C / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(wino4_in_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, V,
-                     (int)H, (int)W, (int)(C / 4), tiles, total);
+  hipLaunchKernelGGL(wino4_in_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     (void *)V, (int)H, (int)W, (int)(C / 4), tiles, total, 1.0f);
   return check_launch();
 }
 
-int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
+int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream) {
   if (B < 0 || H < 4 || W < 4 || H % 4 || W % 4 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!M || !y) return GQHIP_ERR_INVALID_ARG;
@@ -839,12 +859,13 @@ int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(wino4_out_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), M, y,
-                     (int)H, (int)W, (int)(C / 4), tiles, total);
+                     (int)H, (int)W, (int)(C / 4), tiles, total, mscale);
   return check_launch();
 }
 
 int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or_null, float *y, double *stats_out,
-                          int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups, int tile, void *stream) {
+                          int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups, int tile, float mscale,
+                          void *stream) {
   if ((tile != 2 && tile != 4) || B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 ||
       groups < 1 || C % groups != 0)
     return GQHIP_ERR_INVALID_ARG;
@@ -862,10 +883,10 @@ int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or
   const dim3 grid((unsigned)(B * slabs));
   if (tile == 4)
     hipLaunchKernelGGL((wino_out_res_nhwc_kernel<4>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
-                       (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs);
+                       (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs, mscale);
   else
     hipLaunchKernelGGL((wino_out_res_nhwc_kernel<2>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
-                       (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs);
+                       (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs, mscale);
   return check_launch();
 }
 
@@ -876,12 +897,34 @@ int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64
   const long total = (long)(B * (H + 1) * (W + 1) * 4 * (C / 4));
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(upconv_im2col_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     A, (int)H, (int)W, (int)(C / 4), total);
+  hipLaunchKernelGGL(upconv_im2col_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, (void *)A, (int)H, (int)W, (int)(C / 4), total, (const float *)nullptr);
   return check_launch();
 }
 
-int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
+int upconv_im2col_nhwc_f16x3(const float *x, void *A3, int64_t B, int64_t H, int64_t W, int64_t C,
+                             const float *scales_dev, void *stream) {
+  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !A3 || !scales_dev) return GQHIP_ERR_INVALID_ARG;
+  const long total = (long)(B * (H + 1) * (W + 1) * 4 * (C / 4));
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(upconv_im2col_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, A3, (int)H, (int)W, (int)(C / 4), total, scales_dev);
+  return check_launch();
+}
+
+int f16_scales_from_gn_stats(const double *stats, int64_t n_bg, double amp, double u_scale, float *scales_out,
+                             void *stream) {
+  if (!stats || !scales_out || n_bg < 1 || n_bg > 0x7fffffff || !(amp > 0.0) || !(u_scale > 0.0)) return GQHIP_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(f16_scales_from_stats_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), stats, (int)n_bg,
+                     (float)amp, (float)u_scale, scales_out);
+  return check_launch();
+}
+
+int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C,
+                            const float *mscale_dev_or_null, void *stream) {
   if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!src || !y) return GQHIP_ERR_INVALID_ARG;
@@ -889,7 +932,7 @@ int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, in
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(upconv_shuffle_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     src, y, (int)H, (int)W, (int)(C / 4), total);
+                     src, y, (int)H, (int)W, (int)(C / 4), total, mscale_dev_or_null);
   return check_launch();
 }
 

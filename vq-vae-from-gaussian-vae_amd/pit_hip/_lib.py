@@ -8,6 +8,7 @@ tensor is not on a HIP device the call raises.
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 import subprocess
 from typing import Optional, Tuple
@@ -53,16 +54,20 @@ _SIGNATURES = {
     "gn_apply_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp]),
     "wino_in_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "wino4_in_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
-    "wino4_out_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
-    "wino_out_res_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _vp]),
+    "wino4_out_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
+    "wino_out_res_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
+                                              ctypes.c_float, _vp]),
+    "wino_in_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
     "wino4_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                              ctypes.c_int, _vp]),
-    "wino_out_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "wino_out_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "upconv_im2col_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
-    "upconv_shuffle_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "upconv_shuffle_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "upconv_im2col_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "f16_scales_from_gn_stats": (ctypes.c_int, [_vp, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "upsample2x_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
@@ -405,13 +410,16 @@ def gn_stats(x, groups: int, pre_bias=None):
     return stats
 
 
-def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0):
+def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0, f16=None):
     """3x3 stride-1 padding-1 convolution of a channels_last fp32 HIP tensor by Winograd F(2x2, 3x3):
     U [16, Cin, Cout] = G g G^T (see unet._wino_weights).  Returns [B, Cout, H, W] channels_last, no bias.
     ``gn`` = (gamma, beta, groups, eps, silu, stats, pre_bias): the convolution's input is SiLU(GroupNorm(x + pre_bias)),
     applied inside the input transform (the normalised tensor is never materialised).
     ``stats_groups`` > 0: the output transform also adds bias[c] (+ ``residual``) and returns
-    (y, GroupNorm statistics of y) -- the tail of a ResnetBlock, or conv1 + the statistics norm2 needs, in one pass."""
+    (y, GroupNorm statistics of y) -- the tail of a ResnetBlock, or conv1 + the statistics norm2 needs, in one pass.
+    ``f16`` = (U3, u_scale, x_bound): run the 16 / 36 GEMMs as ONE fp16 batched GEMM with fp32 accumulation over a K axis
+    that carries the three products of two-term fp16 splits (see gqhip.h:wino_in_nhwc_f16x3): U3 [T, 3 Cin, Cout] fp16 =
+    [U_h; U_l; U_h] of U * u_scale, x_bound >= max|x| (guarantees the scaled transform stays inside fp16's range)."""
     if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 4 or x.shape[2] % 2 or x.shape[3] % 2:
         raise GqHipError("wino_conv3x3 needs a dense channels_last fp32 HIP tensor, C % 4 == 0, even H and W")
     B, C, H, W = x.shape
@@ -421,18 +429,31 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0)
         raise GqHipError("F(4x4,3x3) needs H, W multiples of 4")
     t = 4 if f4 else 2
     tiles = B * (H // t) * (W // t)
-    V = torch.empty((U.shape[0], tiles, C), dtype=x.dtype, device=x.device)
     L = lib()
+    mscale = 1.0
     with torch.cuda.device(x.device):
-        if gn is not None:
-            gamma, beta, groups, eps, silu, stats, pre_bias = gn
-            _check((L.wino4_in_gn_nhwc_f32 if f4 else L.wino_in_gn_nhwc_f32)(
-                x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(), V.data_ptr(), B, H, W, C,
-                groups, float(eps), 1 if silu else 0, _stream()), "wino_in_gn_nhwc_f32")
+        if f16 is not None and gn is None:
+            U3, u_scale, x_bound = f16
+            # |B^T d B| <= amp * max|d| (amp = squared max abs row sum of B^T: 100 for F(4x4,3x3), 4 for F(2x2,3x3))
+            amp = 100.0 if f4 else 4.0
+            v_scale = 2.0 ** math.floor(math.log2(32768.0 / (amp * max(float(x_bound), 1e-30))))
+            v_scale = min(v_scale, 2.0 ** 14)
+            V = torch.empty((U.shape[0], tiles, 3 * C), dtype=torch.float16, device=x.device)
+            _check(L.wino_in_nhwc_f16x3(x.data_ptr(), V.data_ptr(), B, H, W, C, t, float(v_scale), _stream()),
+                   "wino_in_nhwc_f16x3")
+            M = torch.bmm(V, U3, out_dtype=torch.float32)     # ONE fp16 GEMM per tile position, fp32 accumulate
+            mscale = 1.0 / (v_scale * u_scale)
         else:
-            _check((L.wino4_in_nhwc_f32 if f4 else L.wino_in_nhwc_f32)(x.data_ptr(), V.data_ptr(), B, H, W, C, _stream()),
-                   "wino_in_nhwc_f32")
-        M = torch.bmm(V, U)                                   # 16 / 36 GEMMs [tiles, Cin] x [Cin, Cout] (hipBLASLt)
+            V = torch.empty((U.shape[0], tiles, C), dtype=x.dtype, device=x.device)
+            if gn is not None:
+                gamma, beta, groups, eps, silu, stats, pre_bias = gn
+                _check((L.wino4_in_gn_nhwc_f32 if f4 else L.wino_in_gn_nhwc_f32)(
+                    x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(), V.data_ptr(), B, H, W, C,
+                    groups, float(eps), 1 if silu else 0, _stream()), "wino_in_gn_nhwc_f32")
+            else:
+                _check((L.wino4_in_nhwc_f32 if f4 else L.wino_in_nhwc_f32)(x.data_ptr(), V.data_ptr(), B, H, W, C, _stream()),
+                       "wino_in_nhwc_f32")
+            M = torch.bmm(V, U)                               # 16 / 36 GEMMs [tiles, Cin] x [Cin, Cout] (hipBLASLt)
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         if stats_groups:
             if (residual is not None and (image_layout(residual) != 1 or tuple(residual.shape) != tuple(y.shape))) \
@@ -440,33 +461,55 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0)
                 raise GqHipError("fused Winograd tail needs a channels_last residual of the output shape and a GroupNorm-compatible C")
             stats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device)
             _check(L.wino_out_res_nhwc_f32(M.data_ptr(), _ptr(residual), _ptr(bias), y.data_ptr(), stats.data_ptr(),
-                                           B, H, W, cout, stats_groups, t, _stream()), "wino_out_res_nhwc_f32")
+                                           B, H, W, cout, stats_groups, t, float(mscale), _stream()), "wino_out_res_nhwc_f32")
             return y, stats
-        _check((L.wino4_out_nhwc_f32 if f4 else L.wino_out_nhwc_f32)(M.data_ptr(), y.data_ptr(), B, H, W, cout, _stream()),
-               "wino_out_nhwc_f32")
+        _check((L.wino4_out_nhwc_f32 if f4 else L.wino_out_nhwc_f32)(M.data_ptr(), y.data_ptr(), B, H, W, cout,
+                                                                     float(mscale), _stream()), "wino_out_nhwc_f32")
     return y
 
 
-def upconv_im2col(x):
-    """2x2 patches (padding 1) of a channels_last fp32 HIP tensor [B, C, H, W] as GEMM rows [B*(H+1)*(W+1), 4C]."""
+def upconv_im2col(x, scales=None):
+    """2x2 patches (padding 1) of a channels_last fp32 HIP tensor [B, C, H, W] as GEMM rows [B*(H+1)*(W+1), 4C];
+    ``scales`` (device float[2] from f16_scales): the fp16 x 3 operand [rows, 12C] = [h | h | l] of x * scales[0] instead."""
     if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 4:
         raise GqHipError("upconv_im2col needs a dense channels_last fp32 HIP tensor with C % 4 == 0")
     B, C, H, W = x.shape
-    A = torch.empty((B * (H + 1) * (W + 1), 4 * C), dtype=x.dtype, device=x.device)
+    rows = B * (H + 1) * (W + 1)
     with torch.cuda.device(x.device):
-        _check(lib().upconv_im2col_nhwc_f32(x.data_ptr(), A.data_ptr(), B, H, W, C, _stream()), "upconv_im2col_nhwc_f32")
+        if scales is not None:
+            A = torch.empty((rows, 12 * C), dtype=torch.float16, device=x.device)
+            _check(lib().upconv_im2col_nhwc_f16x3(x.data_ptr(), A.data_ptr(), B, H, W, C, scales.data_ptr(), _stream()),
+                   "upconv_im2col_nhwc_f16x3")
+        else:
+            A = torch.empty((rows, 4 * C), dtype=x.dtype, device=x.device)
+            _check(lib().upconv_im2col_nhwc_f32(x.data_ptr(), A.data_ptr(), B, H, W, C, _stream()), "upconv_im2col_nhwc_f32")
     return A
 
 
-def upconv_shuffle(src, C: int):
-    """Pixel shuffle of the sub-pixel upsample+conv: src [B, 4C, H+1, W+1] channels_last -> [B, C, 2H, 2W]."""
+def f16_scales(stats, amp: float, u_scale: float):
+    """Device float[2] = (v_scale, 1 / (v_scale * u_scale)) for an fp16 x 3 GEMM whose activation operand x has the
+    GroupNorm statistics ``stats`` ([2 * n_bg] fp64: sum, sum of squares): v_scale = the largest power of two with
+    amp * sqrt(max sum of squares) * v_scale <= 32768.  Computed on the device (no sync)."""
+    if not (stats.is_cuda and stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() % 2 == 0):
+        raise GqHipError("f16_scales needs the fp64 statistics tensor of add_bias_stats / wino_conv3x3")
+    out = torch.empty(2, dtype=torch.float32, device=stats.device)
+    with torch.cuda.device(stats.device):
+        _check(lib().f16_scales_from_gn_stats(stats.data_ptr(), stats.numel() // 2, float(amp), float(u_scale),
+                                              out.data_ptr(), _stream()), "f16_scales_from_gn_stats")
+    return out
+
+
+def upconv_shuffle(src, C: int, scales=None):
+    """Pixel shuffle of the sub-pixel upsample+conv: src [B, 4C, H+1, W+1] channels_last -> [B, C, 2H, 2W];
+    ``scales``: multiply by scales[1] (the fp16 x 3 GEMM's result on scaled operands)."""
     if image_layout(src) != 1 or not src.is_cuda or src.dtype != torch.float32 or src.shape[1] != 4 * C or C % 4:
         raise GqHipError("upconv_shuffle needs a dense channels_last fp32 HIP tensor [B, 4C, H+1, W+1], C % 4 == 0")
     B, _, H1, W1 = src.shape
     y = torch.empty((B, C, 2 * (H1 - 1), 2 * (W1 - 1)), dtype=src.dtype, device=src.device,
                     memory_format=torch.channels_last)
     with torch.cuda.device(src.device):
-        _check(lib().upconv_shuffle_nhwc_f32(src.data_ptr(), y.data_ptr(), B, H1 - 1, W1 - 1, C, _stream()),
+        ms = None if scales is None else scales.data_ptr() + 4
+        _check(lib().upconv_shuffle_nhwc_f32(src.data_ptr(), y.data_ptr(), B, H1 - 1, W1 - 1, C, ms, _stream()),
                "upconv_shuffle_nhwc_f32")
     return y
 

@@ -13,6 +13,8 @@ this path (unet.py:342, :473) so the time-embedding projection is not created.
 """
 from __future__ import annotations
 
+import math
+
 from typing import Sequence
 
 import torch
@@ -56,8 +58,12 @@ def _norm_act(norm: nn.GroupNorm, x: torch.Tensor, act: bool = True, pre_bias=No
 
         st = getattr(x, "_gn_stats", None)   # left behind by the residual add that produced x (see _add)
         if st is not None and pre_bias is None and st[1] == norm.num_groups and _lib.image_layout(x) == 1:
-            return _lib.gn_apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act, st[0])
-        return _lib.gn_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=act, pre_bias=pre_bias)
+            y = _lib.gn_apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act, st[0])
+        else:
+            y = _lib.gn_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=act, pre_bias=pre_bias)
+        if WINOGRAD_F16X3:
+            y._act_bound = _gn_act_bound(norm, x)   # lets the Winograd GEMMs that consume y run as fp16 x 3 (see _f16_args)
+        return y
     y = norm(_materialize(x, pre_bias))
     return _silu(y) if act else y
 
@@ -66,6 +72,16 @@ def _defer_ok(x: torch.Tensor, conv: nn.Conv2d) -> bool:
     """Deferred-bias path: inference on HIP, NCHW fp32, zero padding, output HW % 4 == 0."""
     return (FUSED_GN and DEFER_BIAS and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
             and conv.bias is not None and conv.padding_mode == "zeros")
+
+
+def _f16_args(conv: nn.Conv2d, x: torch.Tensor, f4: bool):
+    """(U3, u_scale, bound) for _lib.wino_conv3x3's fp16 x 3 route, or None: needs a rigorous bound on |x| (left on the
+    tensor by _norm_act: every Winograd convolution of this UNet is fed by GroupNorm + swish)."""
+    bound = getattr(x, "_act_bound", None)
+    if not WINOGRAD_F16X3 or bound is None:
+        return None
+    u3, u_scale = _wino_weights_f16(conv, f4)
+    return u3, u_scale, bound
 
 
 def _conv(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
@@ -80,10 +96,11 @@ def _conv(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
             f4 = WINOGRAD_F4 and getattr(conv, "_gq_wino4", False) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0
             if want_stats and FUSED_WINO_TAIL and _lib.gn_nhwc_ok(conv.out_channels, GN_GROUPS):
                 # the consumer is a GroupNorm: add the bias here and leave the statistics with the output
-                y, stats = _lib.wino_conv3x3(x, _wino_weights(conv, f4), bias=conv.bias, stats_groups=GN_GROUPS)
+                y, stats = _lib.wino_conv3x3(x, _wino_weights(conv, f4), bias=conv.bias, stats_groups=GN_GROUPS,
+                                             f16=_f16_args(conv, x, f4))
                 y._gn_stats = (stats, GN_GROUPS)
                 return y, None
-            return _lib.wino_conv3x3(x, _wino_weights(conv, f4)), conv.bias
+            return _lib.wino_conv3x3(x, _wino_weights(conv, f4), f16=_f16_args(conv, x, f4)), conv.bias
         return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
     return conv(x), None
 
@@ -146,6 +163,34 @@ def _wino_weights(conv: nn.Conv2d, f4: bool = False) -> torch.Tensor:
     return conv._wino_u
 
 
+def _wino_weights_f16(conv: nn.Conv2d, f4: bool = False):
+    """(U3, u_scale): U = G g G^T scaled by a power of two into fp16's comfortable range and split into two fp16 terms,
+    stacked along K as [U_h; U_l; U_h] ([T, 3 Cin, Cout] fp16) -- the weight side of the f16x3 GEMM (gqhip.h:
+    wino_in_nhwc_f16x3).  Cached with (and keyed like) the fp32 U."""
+    U = _wino_weights(conv, f4)
+    if getattr(conv, "_wino_f16_key", None) != conv._wino_key:
+        amax = float(U.abs().max())
+        u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0
+        us = U * u_scale
+        h = us.half()
+        l = (us - h.float()).half()
+        conv._wino_u3 = torch.cat([h, l, h], 1).contiguous()
+        conv._wino_u_scale = u_scale
+        conv._wino_f16_key = conv._wino_key
+    return conv._wino_u3, conv._wino_u_scale
+
+
+def _gn_act_bound(norm: nn.GroupNorm, x: torch.Tensor) -> float:
+    """A rigorous bound on |SiLU(GroupNorm(x))|: a group of n elements has |(x - mean) / sqrt(var + eps)| <= sqrt(n - 1),
+    so |y| <= sqrt(n - 1) max|gamma| + max|beta| and |SiLU(y)| <= |y|.  (max|gamma|, max|beta| cached per weight.)"""
+    key = (norm.weight.data_ptr(), norm.weight._version, norm.bias.data_ptr(), norm.bias._version)
+    if getattr(norm, "_gb_key", None) != key:
+        norm._gb_max = (float(norm.weight.detach().abs().max()), float(norm.bias.detach().abs().max()))
+        norm._gb_key = key
+    n = (x.shape[1] // norm.num_groups) * x.shape[2] * x.shape[3]
+    return math.sqrt(max(n - 1, 1)) * norm._gb_max[0] + norm._gb_max[1]
+
+
 def invalidate_caches(module: nn.Module) -> None:
     """Drop every weight-derived cache under ``module`` (Winograd U matrices, the sub-pixel phase matrices, the fused
     q/k/v matrix).  The caches are keyed on (data_ptr, _version, device), which follows ``load_state_dict``, optimizer
@@ -153,7 +198,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
-        for attr in ("_wino_key", "_qkv_key", "_phase_key"):
+        for attr in ("_wino_key", "_wino_f16_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -196,6 +241,11 @@ WINOGRAD = True          # decoder 3x3 convs with >= WINOGRAD_MIN_CH channels: W
 WINOGRAD_MIN_CH = 128
 FUSED_WINO_TAIL = True   # Winograd output transform + bias + residual add + next GroupNorm's statistics in one pass
 WINOGRAD_F4 = True       # decoder: F(4x4,3x3) (36 GEMMs on 6x6 tiles) instead of F(2x2,3x3)
+# The 16 / 36 Winograd GEMMs as ONE fp16 batched GEMM with fp32 accumulation whose K axis carries the three products of
+# two-term fp16 splits of both operands (22-bit significands): measured error 2.5-2.9e-7 of sum|a||b| against 2.6-3.5e-7
+# for hipBLASLt's fp32 GEMM (itself a split-bf16 emulation on gfx950), at 1.2x (128 channels) to 2.5x (512) its speed
+# (tools/bmm_bf16x3.py).  False: the library's fp32 GEMM.
+WINOGRAD_F16X3 = True
 FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the F(2x2,3x3) input transform: correct, but no faster (every input
                          # pixel is activated by the four tiles that overlap it, the kernel stops being HBM-bound): off
 FUSED_WINO_GN_F4 = False # ... inside the F(4x4,3x3) input transform (2.25 tiles per pixel): also measured, 1 % slower: off
@@ -273,7 +323,8 @@ class ResnetBlock(nn.Module):
                     else:
                         gn, src = None, _norm_act(self.norm2, h, pre_bias=b1)
                     y, ostats = _lib.wino_conv3x3(src, _wino_weights(self.conv2, f4), gn=gn, residual=xs, bias=bias,
-                                                  stats_groups=GN_GROUPS)
+                                                  stats_groups=GN_GROUPS,
+                                                  f16=None if gn is not None else _f16_args(self.conv2, src, f4))
                     y._gn_stats = (ostats, GN_GROUPS)
                     return y
             h, bias = _conv(self.conv2, _norm_act(self.norm2, h, pre_bias=b1))
@@ -380,6 +431,20 @@ class Upsample(nn.Module):
             self._phase_key = key
         return self._phase_w
 
+    def _phase_weights_f16(self):
+        """([3 * 4Cin, 4Cout] fp16 = [W_h; W_l; W_h] of the phase matrix * u_scale, u_scale): weight side of the fp16 x 3 GEMM."""
+        wm = self._phase_weights()
+        if getattr(self, "_phase_f16_key", None) != self._phase_key:
+            amax = float(wm.abs().max())
+            u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0
+            ws = wm * u_scale
+            h = ws.half()
+            l = (ws - h.float()).half()
+            self._phase_w3 = torch.cat([h, l, h], 0).contiguous()
+            self._phase_u_scale = u_scale
+            self._phase_f16_key = self._phase_key
+        return self._phase_w3, self._phase_u_scale
+
     def forward(self, x: torch.Tensor):
         """Returns (y, pending_bias) -- see ``_conv``."""
         fast = (FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
@@ -393,9 +458,18 @@ class Upsample(nn.Module):
             from .. import _lib
 
             b, c, h, w = x.shape
-            full = torch.matmul(_lib.upconv_im2col(x), self._phase_weights())          # hipBLASLt fp32 GEMM
+            st = getattr(x, "_gn_stats", None)
+            if WINOGRAD_F16X3 and st is not None:
+                # the GEMM as fp16 x 3 over K (see WINOGRAD_F16X3); the activation's scale comes, on the device, from the
+                # GroupNorm statistics its producer left behind (sqrt of a group's sum of squares bounds its largest element)
+                w3, u_scale = self._phase_weights_f16()
+                scales = _lib.f16_scales(st[0], 1.0, u_scale)
+                full = torch.mm(_lib.upconv_im2col(x, scales), w3, out_dtype=torch.float32)
+            else:
+                scales = None
+                full = torch.matmul(_lib.upconv_im2col(x), self._phase_weights())      # hipBLASLt fp32 GEMM
             full = full.view(b, h + 1, w + 1, 4 * self.conv.out_channels).permute(0, 3, 1, 2)   # NHWC view
-            return _lib.upconv_shuffle(full, self.conv.out_channels), self.conv.bias
+            return _lib.upconv_shuffle(full, self.conv.out_channels, scales), self.conv.bias
         if fast:
             from .. import _lib
 
