@@ -201,6 +201,11 @@ int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W,
  * caller derives it from the GroupNorm that feeds the convolution: |SiLU(GN(x))| <= sqrt(n - 1) max|gamma| + max|beta|). */
 int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
                        void *stream);
+/* ... with the producer fused in (as wino_in_gn_nhwc_f32 / wino4_in_gn_nhwc_f32): the convolution's input is
+ * SiLU(GroupNorm(x + pre_bias)), never written. */
+int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                          const double *stats, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                          double eps, int apply_silu, int tile, float scale, void *stream);
 
 /* Winograd F(4x4, 3x3): V [36, tiles, C] of the 6x6 input tiles (tiles = B * H/4 * W/4, H and W multiples of 4) and
  * y [B, H, W, Cout] from M [36, tiles, Cout]; U = G g G^T is [36, Cin, Cout].  36 multiplies per 16 outputs and 2.25x

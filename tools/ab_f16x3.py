@@ -24,11 +24,17 @@ def timed(n=10):
         torch.cuda.synchronize(); te += ev[0].elapsed_time(ev[1]); td += ev[2].elapsed_time(ev[3])
     return te / n, td / n
 res = {}
-for flag in (False, True, False, True):
-    U.WINOGRAD_F16X3 = flag
-    te, td = timed()
-    res[flag] = run()
-    print(f"WINOGRAD_F16X3={flag}: encoder {te:.2f} ms, decoder {td:.2f} ms, sum {te + td:.2f} ms -> {16 / (te + td) * 1e3:.1f} img/s", flush=True)
-za, ia, ra = res[False]; zb, ib, rb = res[True]
+import itertools
+variants = [dict(WINOGRAD_F16X3=False), dict(WINOGRAD_F16X3=True), dict(WINOGRAD_F16X3=True, FUSED_WINO_GN_F4=True),
+            dict(WINOGRAD_F16X3=True, FUSED_WINO_GN=True), dict(WINOGRAD_F16X3=True, FUSED_WINO_GN=True, FUSED_WINO_GN_F4=True)]
+base = dict(WINOGRAD_F16X3=True, FUSED_WINO_GN=False, FUSED_WINO_GN_F4=False)
+for rep in range(2):
+    for v in variants:
+        for k, val in {**base, **v}.items():
+            setattr(U, k, val)
+        te, td = timed()
+        res[tuple(sorted(v.items()))] = run()
+        print(f"{v}: encoder {te:.2f} ms, decoder {td:.2f} ms, sum {te + td:.2f} ms -> {16 / (te + td) * 1e3:.1f} img/s", flush=True)
+za, ia, ra = res[tuple(sorted(variants[0].items()))]; zb, ib, rb = res[tuple(sorted(variants[-1].items()))]
 print(f"z max abs diff {float((za - zb).abs().max()):.2e}; indices differing {int((ia != ib).sum())} of {ia.numel()}; "
       f"recon max abs diff {float((ra - rb).abs().max()):.2e}")

@@ -385,13 +385,13 @@ __global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restri
 // the normalisation is applied to the 16 loaded values on the fly (statistics from gn_stats / add_bias_stats) and the
 // normalised tensor is never written: saves gn_apply's write and this kernel's read of it.  Zero padding applies to the
 // ACTIVATED tensor, so out-of-bounds taps stay exactly 0.
-template <int SILU>
+template <int SILU, bool F16X3>
 __global__ __launch_bounds__(256) void wino_in_gn_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta,
                                                               const float *__restrict__ pre_bias,
-                                                              const double *__restrict__ stats, float *__restrict__ V,
+                                                              const double *__restrict__ stats, void *__restrict__ V,
                                                               int H, int W, int C4, int cpg, double eps, long tiles,
-                                                              long total) {
+                                                              long total, float scale) {
   const int groups = 4 * C4 / cpg;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int q = (int)(t % C4);
@@ -441,14 +441,12 @@ __global__ __launch_bounds__(256) void wino_in_gn_nhwc_kernel(const float *__res
       w[2][j] = d[2][j] - d[1][j];
       w[3][j] = d[1][j] - d[3][j];
     }
-    f32x4 *o = reinterpret_cast<f32x4 *>(V) + tile * C4 + q;
-    const long plane = tiles * C4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      o[(4 * i + 0) * plane] = w[i][0] - w[i][2];
-      o[(4 * i + 1) * plane] = w[i][1] + w[i][2];
-      o[(4 * i + 2) * plane] = w[i][2] - w[i][1];
-      o[(4 * i + 3) * plane] = w[i][1] - w[i][3];
+      wino_store_v<F16X3>(V, 4 * i + 0, tiles, tile, C4, q, w[i][0] - w[i][2], scale);
+      wino_store_v<F16X3>(V, 4 * i + 1, tiles, tile, C4, q, w[i][1] + w[i][2], scale);
+      wino_store_v<F16X3>(V, 4 * i + 2, tiles, tile, C4, q, w[i][2] - w[i][1], scale);
+      wino_store_v<F16X3>(V, 4 * i + 3, tiles, tile, C4, q, w[i][1] - w[i][3], scale);
     }
   }
 }
@@ -544,13 +542,13 @@ __global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restr
 
 // wino4_in_nhwc_kernel with the producer fused in (see wino_in_gn_nhwc_kernel): every pixel is activated by the 2.25 tiles
 // that overlap it (4 with F(2x2,3x3), where the fusion brought nothing).
-template <int SILU>
+template <int SILU, bool F16X3>
 __global__ __launch_bounds__(256) void wino4_in_gn_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                                const float *__restrict__ beta,
                                                                const float *__restrict__ pre_bias,
-                                                               const double *__restrict__ stats, float *__restrict__ V,
+                                                               const double *__restrict__ stats, void *__restrict__ V,
                                                                int H, int W, int C4, int cpg, double eps, long tiles,
-                                                               long total) {
+                                                               long total, float scale) {
   const int groups = 4 * C4 / cpg;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int q = (int)(t % C4);
@@ -597,14 +595,12 @@ __global__ __launch_bounds__(256) void wino4_in_gn_nhwc_kernel(const float *__re
 #pragma unroll
       for (int i = 0; i < 6; ++i) w[i][j] = o[i];
     }
-    f32x4 *out = reinterpret_cast<f32x4 *>(V) + tile * C4 + q;
-    const long plane = tiles * C4;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       f32x4 o[6];
       wino4_bt(w[i], o);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) out[(6 * i + j) * plane] = o[j];
+      for (int j = 0; j < 6; ++j) wino_store_v<F16X3>(V, 6 * i + j, tiles, tile, C4, q, o[j], scale);
     }
   }
 }

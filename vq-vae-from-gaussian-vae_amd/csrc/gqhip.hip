@@ -785,11 +785,11 @@ int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64
   return check_launch();
 }
 
-static int wino_in_gn_nhwc_f32_impl(int tile, const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                        const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
-                        double eps, int apply_silu, void *stream) {
+static int wino_in_gn_impl(int tile, bool f16, const float *x, const float *gamma, const float *beta,
+                           const float *pre_bias_or_null, const double *stats, void *V, int64_t B, int64_t H, int64_t W,
+                           int64_t C, int64_t groups, double eps, int apply_silu, float scale, void *stream) {
   if (B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 || groups < 1 || C % groups != 0 ||
-      (C / groups) % 4 != 0)
+      (C / groups) % 4 != 0 || !(scale > 0.f))
     return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!x || !gamma || !beta || !stats || !V) return GQHIP_ERR_INVALID_ARG;
@@ -797,34 +797,38 @@ static int wino_in_gn_nhwc_f32_impl(int tile, const float *x, const float *gamma
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipStream_t st = static_cast<hipStream_t>(stream);
+#define GQ_WGN(K, S, F)                                                                                              \
+  hipLaunchKernelGGL((K<S, F>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, pre_bias_or_null, stats, V, \
+                     (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total, scale)
   if (tile == 4) {
-    if (apply_silu)
-      hipLaunchKernelGGL((wino4_in_gn_nhwc_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
-                         pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
-    else
-      hipLaunchKernelGGL((wino4_in_gn_nhwc_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
-                         pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
-    return check_launch();
+    if (apply_silu) { if (f16) GQ_WGN(wino4_in_gn_nhwc_kernel, 1, true); else GQ_WGN(wino4_in_gn_nhwc_kernel, 1, false); }
+    else { if (f16) GQ_WGN(wino4_in_gn_nhwc_kernel, 0, true); else GQ_WGN(wino4_in_gn_nhwc_kernel, 0, false); }
+  } else {
+    if (apply_silu) { if (f16) GQ_WGN(wino_in_gn_nhwc_kernel, 1, true); else GQ_WGN(wino_in_gn_nhwc_kernel, 1, false); }
+    else { if (f16) GQ_WGN(wino_in_gn_nhwc_kernel, 0, true); else GQ_WGN(wino_in_gn_nhwc_kernel, 0, false); }
   }
-  if (apply_silu)
-    hipLaunchKernelGGL((wino_in_gn_nhwc_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
-                       pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
-  else
-    hipLaunchKernelGGL((wino_in_gn_nhwc_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta,
-                       pre_bias_or_null, stats, V, (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total);
+#undef GQ_WGN
   return check_launch();
 }
 
 int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                         const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                         double eps, int apply_silu, void *stream) {
-  return wino_in_gn_nhwc_f32_impl(2, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, stream);
+  return wino_in_gn_impl(2, false, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, 1.0f, stream);
 }
 
 int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                          const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                          double eps, int apply_silu, void *stream) {
-  return wino_in_gn_nhwc_f32_impl(4, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, stream);
+  return wino_in_gn_impl(4, false, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, 1.0f, stream);
+}
+
+int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                          const double *stats, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                          double eps, int apply_silu, int tile, float scale, void *stream) {
+  if (tile != 2 && tile != 4) return GQHIP_ERR_INVALID_ARG;
+  return wino_in_gn_impl(tile, true, x, gamma, beta, pre_bias_or_null, stats, V3, B, H, W, C, groups, eps, apply_silu, scale,
+                         stream);
 }
 
 int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream) {

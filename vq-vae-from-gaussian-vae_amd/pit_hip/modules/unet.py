@@ -137,11 +137,12 @@ def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bia
                 stats = _lib.gn_stats(x, norm.num_groups, pre_bias)
             gn = (norm.weight, norm.bias, norm.num_groups, norm.eps, True, stats, pre_bias)
             U = _wino_weights(conv, f4)
+            f16 = (_wino_weights_f16(conv, f4) + (_gn_act_bound(norm, x),)) if WINOGRAD_F16X3 else None
             if want_stats and FUSED_WINO_TAIL and _lib.gn_nhwc_ok(conv.out_channels, GN_GROUPS):
-                y, ostats = _lib.wino_conv3x3(x, U, gn=gn, bias=conv.bias, stats_groups=GN_GROUPS)
+                y, ostats = _lib.wino_conv3x3(x, U, gn=gn, bias=conv.bias, stats_groups=GN_GROUPS, f16=f16)
                 y._gn_stats = (ostats, GN_GROUPS)
                 return y, None
-            return _lib.wino_conv3x3(x, U, gn=gn), conv.bias
+            return _lib.wino_conv3x3(x, U, gn=gn, f16=f16), conv.bias
     return _conv(conv, _norm_act(norm, x, pre_bias=pre_bias), want_stats)
 
 
@@ -320,11 +321,13 @@ class ResnetBlock(nn.Module):
                             stats = _lib.gn_stats(h, self.norm2.num_groups, b1)
                         gn = (self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, stats, b1)
                         src = h
+                        f16 = ((_wino_weights_f16(self.conv2, f4) + (_gn_act_bound(self.norm2, h),))
+                               if WINOGRAD_F16X3 else None)
                     else:
                         gn, src = None, _norm_act(self.norm2, h, pre_bias=b1)
+                        f16 = _f16_args(self.conv2, src, f4)
                     y, ostats = _lib.wino_conv3x3(src, _wino_weights(self.conv2, f4), gn=gn, residual=xs, bias=bias,
-                                                  stats_groups=GN_GROUPS,
-                                                  f16=None if gn is not None else _f16_args(self.conv2, src, f4))
+                                                  stats_groups=GN_GROUPS, f16=f16)
                     y._gn_stats = (ostats, GN_GROUPS)
                     return y
             h, bias = _conv(self.conv2, _norm_act(self.norm2, h, pre_bias=b1))
