@@ -201,6 +201,13 @@ int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W,
  * caller derives it from the GroupNorm that feeds the convolution: |SiLU(GN(x))| <= sqrt(n - 1) max|gamma| + max|beta|). */
 int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
                        void *stream);
+/* The 128-channel case (Cin = Cout = 128: the 256 x 256 level, where this GEMM is HBM-bound): V2 [16|36, tiles, 2C] fp16 =
+ * [h | l] only (4 instead of 6 bytes per element) and wino_gemm_c128_f16x2 forms the three products itself on
+ * v_mfma_f32_32x32x16_f16: M [P, tiles, 128] fp32 = V2 (x) U2t, U2t [P, 2, 128 n, 128 k] fp16 = (U_h^T, U_l^T) of U * u_scale.
+ * Same splits, same products, same accumulation type as the K-concatenated library GEMM. */
+int wino_in_nhwc_f16x2(const float *x, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
+                       void *stream);
+int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, int64_t tiles, void *stream);
 /* ... with the producer fused in (as wino_in_gn_nhwc_f32 / wino4_in_gn_nhwc_f32): the convolution's input is
  * SiLU(GroupNorm(x + pre_bias)), never written. */
 int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,

@@ -355,6 +355,14 @@ def test_winograd_f16x3_gemm_is_as_accurate_as_the_fp32_gemm():
                     e16 = float((y16.double() - ref).abs().max()) / scale
                     print(f"F({4 if f4 else 2},3) {cin}->{cout} amp {amp:g} bound x{b / bound:g}: fp32 GEMM {e32:.2e}, f16x3 {e16:.2e}")
                     assert e16 <= 1.5 * e32 + 1e-7, (e16, e32)
+                if cin == cout == 128:       # the HBM-bound case: [h | l] operand + libgqhip's own GEMM kernel
+                    u2t = conv._wino_u2t
+                    assert u2t is not None and tuple(u2t.shape) == (Uw.shape[0], 2, 128, 128)
+                    y_own = _lib.wino_conv3x3(x, Uw, f16=(u3, us, bound, u2t))
+                    y_lib = _lib.wino_conv3x3(x, Uw, f16=(u3, us, bound, None))
+                    e_own = float((y_own.double() - ref).abs().max()) / scale
+                    print(f"    own c128 GEMM: {e_own:.2e}; vs library f16x3 route max diff {float((y_own - y_lib).abs().max()):.2e}")
+                    assert e_own <= 1.5 * e32 + 1e-7
                 # fused tail (bias + residual + statistics) goes through the same scale
                 res = torch.randn_like(y32)
                 y_a, st_a = _lib.wino_conv3x3(x, Uw, residual=res, bias=conv.bias, stats_groups=32)

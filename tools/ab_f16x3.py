@@ -25,13 +25,14 @@ def timed(n=10):
     return te / n, td / n
 res = {}
 import itertools
-variants = [dict(WINOGRAD_F16X3=False), dict(WINOGRAD_F16X3=True), dict(WINOGRAD_F16X3=True, FUSED_WINO_GN_F4=True),
-            dict(WINOGRAD_F16X3=True, FUSED_WINO_GN=True), dict(WINOGRAD_F16X3=True, FUSED_WINO_GN=True, FUSED_WINO_GN_F4=True)]
-base = dict(WINOGRAD_F16X3=True, FUSED_WINO_GN=False, FUSED_WINO_GN_F4=False)
+variants = [dict(WINOGRAD_F16X3=False), dict(WINOGRAD_F16X3=True, WINOGRAD_C128_GEMM=False), dict(WINOGRAD_F16X3=True, WINOGRAD_C128_GEMM=True)]
+base = dict(WINOGRAD_F16X3=True, FUSED_WINO_GN=False, FUSED_WINO_GN_F4=False, WINOGRAD_C128_GEMM=True)
 for rep in range(2):
     for v in variants:
         for k, val in {**base, **v}.items():
             setattr(U, k, val)
+        from pit_hip.modules.unet import invalidate_caches
+        invalidate_caches(vae)
         te, td = timed()
         res[tuple(sorted(v.items()))] = run()
         print(f"{v}: encoder {te:.2f} ms, decoder {td:.2f} ms, sum {te + td:.2f} ms -> {16 / (te + td) * 1e3:.1f} img/s", flush=True)

@@ -324,9 +324,11 @@ __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__res
 // V3 U3 = h U_h + h U_l + l U_h, error ~3 * 2^-22 per product -- the level of hipBLASLt's own fp32 (split-bf16) GEMM, at
 // 2-2.5x its speed (tools/bmm_bf16x3.py).  `scale` is a power of two chosen by the caller so that |v * scale| < 65504.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-template <bool F16X3>
+// F16X3 = 2 ("f16x2"): V2 [k][tile][2C] = [ h | l ] only -- the operand of wino_gemm_c128_f16x2_kernel, which forms the
+// three products itself (4 instead of 6 bytes per element).
+template <int F16X3>
 __device__ __forceinline__ void wino_store_v(void *V, int k, long tiles, long tile, int C4, int q, f32x4 v, float scale) {
-  if constexpr (F16X3) {
+  if constexpr (F16X3 != 0) {
     v = v * scale;
     f16x4 h, l;
 #pragma unroll
@@ -334,16 +336,22 @@ __device__ __forceinline__ void wino_store_v(void *V, int k, long tiles, long ti
       h[e] = (_Float16)v[e];
       l[e] = (_Float16)(v[e] - (float)h[e]);
     }
-    f16x4 *row = reinterpret_cast<f16x4 *>(V) + ((long)k * tiles + tile) * (3 * C4);
-    row[q] = h;
-    row[C4 + q] = h;
-    row[2 * C4 + q] = l;
+    if constexpr (F16X3 == 2) {
+      f16x4 *row = reinterpret_cast<f16x4 *>(V) + ((long)k * tiles + tile) * (2 * C4);
+      row[q] = h;
+      row[C4 + q] = l;
+    } else {
+      f16x4 *row = reinterpret_cast<f16x4 *>(V) + ((long)k * tiles + tile) * (3 * C4);
+      row[q] = h;
+      row[C4 + q] = h;
+      row[2 * C4 + q] = l;
+    }
   } else {
     reinterpret_cast<f32x4 *>(V)[((long)k * tiles + tile) * C4 + q] = v;
   }
 }
 
-template <bool F16X3>
+template <int F16X3>
 __global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restrict__ x, void *__restrict__ V, int H, int W,
                                                            int C4, long tiles, long total, float scale) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restri
 // the normalisation is applied to the 16 loaded values on the fly (statistics from gn_stats / add_bias_stats) and the
 // normalised tensor is never written: saves gn_apply's write and this kernel's read of it.  Zero padding applies to the
 // ACTIVATED tensor, so out-of-bounds taps stay exactly 0.
-template <int SILU, bool F16X3>
+template <int SILU, int F16X3>
 __global__ __launch_bounds__(256) void wino_in_gn_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta,
                                                               const float *__restrict__ pre_bias,
@@ -504,7 +512,7 @@ __device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&o)[4]) {
   o[3] = d12 + 8.f * d34 + m[5];
 }
 
-template <bool F16X3>
+template <int F16X3>
 __global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restrict__ x, void *__restrict__ V, int H, int W,
                                                             int C4, long tiles, long total, float scale) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restr
 
 // wino4_in_nhwc_kernel with the producer fused in (see wino_in_gn_nhwc_kernel): every pixel is activated by the 2.25 tiles
 // that overlap it (4 with F(2x2,3x3), where the fusion brought nothing).
-template <int SILU, bool F16X3>
+template <int SILU, int F16X3>
 __global__ __launch_bounds__(256) void wino4_in_gn_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                                const float *__restrict__ beta,
                                                                const float *__restrict__ pre_bias,

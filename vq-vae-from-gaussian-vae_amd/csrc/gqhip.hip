@@ -20,6 +20,7 @@
 #include "gq_rerank.h"
 #include "gq_scores.h"
 #include "gq_tail.h"
+#include "gq_wino_gemm.h"
 
 using namespace gqhip;
 
@@ -745,28 +746,53 @@ int wino_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, 
   const long tiles = (long)(B * (H / 2) * (W / 2)), total = tiles * (C / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(wino_in_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+  hipLaunchKernelGGL(wino_in_nhwc_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      (void *)V, (int)H, (int)W, (int)(C / 4), tiles, total, 1.0f);
+  return check_launch();
+}
+
+static int wino_in_f16_impl(int vm, const float *x, void *V, int64_t B, int64_t H, int64_t W, int64_t C, int tile,
+                            float scale, void *stream) {
+  if ((tile != 2 && tile != 4) || B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 ||
+      !(scale > 0.f))
+    return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !V) return GQHIP_ERR_INVALID_ARG;
+  const long tiles = (long)(B * (H / tile) * (W / tile)), total = tiles * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define GQ_WIN(K, VM) \
+  hipLaunchKernelGGL(K<VM>, dim3((unsigned)blocks), dim3(256), 0, st, x, V, (int)H, (int)W, (int)(C / 4), tiles, total, scale)
+  if (tile == 4) { if (vm == 2) GQ_WIN(wino4_in_nhwc_kernel, 2); else GQ_WIN(wino4_in_nhwc_kernel, 1); }
+  else { if (vm == 2) GQ_WIN(wino_in_nhwc_kernel, 2); else GQ_WIN(wino_in_nhwc_kernel, 1); }
+#undef GQ_WIN
   return check_launch();
 }
 
 int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
                        void *stream) {
-  if ((tile != 2 && tile != 4) || B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 ||
-      !(scale > 0.f))
-    return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !V3) return GQHIP_ERR_INVALID_ARG;
-  const long tiles = (long)(B * (H / tile) * (W / tile)), total = tiles * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (tile == 4)
-    hipLaunchKernelGGL(wino4_in_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, V3, (int)H, (int)W,
-                       (int)(C / 4), tiles, total, scale);
-  else
-    hipLaunchKernelGGL(wino_in_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, V3, (int)H, (int)W,
-                       (int)(C / 4), tiles, total, scale);
+  return wino_in_f16_impl(1, x, V3, B, H, W, C, tile, scale, stream);
+}
+
+int wino_in_nhwc_f16x2(const float *x, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
+                       void *stream) {
+  return wino_in_f16_impl(2, x, V2, B, H, W, C, tile, scale, stream);
+}
+
+int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, int64_t tiles, void *stream) {
+  if (P < 1 || tiles < 0 || tiles > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
+  if (tiles == 0) return GQHIP_OK;
+  if (!V2 || !U2t || !M) return GQHIP_ERR_INVALID_ARG;
+  WinoGemmParams wp{};
+  wp.V2 = static_cast<const _Float16 *>(V2); wp.U2t = static_cast<const _Float16 *>(U2t); wp.M = M; wp.tiles = tiles;
+  // ~2048 rows per block (16 row tiles per wave): the 64 KiB of U^T a block stages cost 4 % of the bytes it streams
+  long rpb = 2048;
+  if (tiles < rpb) rpb = (tiles + 127) / 128 * 128;
+  wp.rows_per_block = (int)rpb;
+  wp.blocks_per_pos = (int)((tiles + rpb - 1) / rpb);
+  hipLaunchKernelGGL(wino_gemm_c128_f16x2_kernel, dim3((unsigned)(P * wp.blocks_per_pos)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), wp);
   return check_launch();
 }
 
@@ -801,11 +827,11 @@ static int wino_in_gn_impl(int tile, bool f16, const float *x, const float *gamm
   hipLaunchKernelGGL((K<S, F>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, pre_bias_or_null, stats, V, \
                      (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total, scale)
   if (tile == 4) {
-    if (apply_silu) { if (f16) GQ_WGN(wino4_in_gn_nhwc_kernel, 1, true); else GQ_WGN(wino4_in_gn_nhwc_kernel, 1, false); }
-    else { if (f16) GQ_WGN(wino4_in_gn_nhwc_kernel, 0, true); else GQ_WGN(wino4_in_gn_nhwc_kernel, 0, false); }
+    if (apply_silu) { if (f16) GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 1); else GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 0); }
+    else { if (f16) GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 1); else GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 0); }
   } else {
-    if (apply_silu) { if (f16) GQ_WGN(wino_in_gn_nhwc_kernel, 1, true); else GQ_WGN(wino_in_gn_nhwc_kernel, 1, false); }
-    else { if (f16) GQ_WGN(wino_in_gn_nhwc_kernel, 0, true); else GQ_WGN(wino_in_gn_nhwc_kernel, 0, false); }
+    if (apply_silu) { if (f16) GQ_WGN(wino_in_gn_nhwc_kernel, 1, 1); else GQ_WGN(wino_in_gn_nhwc_kernel, 1, 0); }
+    else { if (f16) GQ_WGN(wino_in_gn_nhwc_kernel, 0, 1); else GQ_WGN(wino_in_gn_nhwc_kernel, 0, 0); }
   }
 #undef GQ_WGN
   return check_launch();
@@ -850,7 +876,7 @@ int wino4_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W,
   const long tiles = (long)(B * (H / 4) * (W / 4)), total = tiles * (C / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(wino4_in_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+  hipLaunchKernelGGL(wino4_in_nhwc_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      (void *)V, (int)H, (int)W, (int)(C / 4), tiles, total, 1.0f);
   return check_launch();
 }

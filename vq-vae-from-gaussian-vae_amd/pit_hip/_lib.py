@@ -58,6 +58,8 @@ _SIGNATURES = {
     "wino_out_res_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
                                               ctypes.c_float, _vp]),
     "wino_in_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
+    "wino_in_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
+    "wino_gemm_c128_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "wino_in_gn_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -435,13 +437,25 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
     mscale = 1.0
     with torch.cuda.device(x.device):
         if f16 is not None:
-            U3, u_scale, x_bound = f16
+            U3, u_scale, x_bound = f16[:3]
             # |B^T d B| <= amp * max|d| (amp = squared max abs row sum of B^T: 100 for F(4x4,3x3), 4 for F(2x2,3x3))
             amp = 100.0 if f4 else 4.0
             v_scale = 2.0 ** math.floor(math.log2(32768.0 / (amp * max(float(x_bound), 1e-30))))
             v_scale = min(v_scale, 2.0 ** 14)
-            V = torch.empty((U.shape[0], tiles, 3 * C), dtype=torch.float16, device=x.device)
-            if gn is not None:     # x_bound then bounds SiLU(GroupNorm(x)), the tensor the transform actually sees
+            if gn is None and C == 128 and cout == 128 and len(f16) > 3 and f16[3] is not None:
+                # HBM-bound case: [h | l] operand (4 bytes per element) + our own GEMM kernel forming the three products
+                V = torch.empty((U.shape[0], tiles, 2 * C), dtype=torch.float16, device=x.device)
+                _check(L.wino_in_nhwc_f16x2(x.data_ptr(), V.data_ptr(), B, H, W, C, t, float(v_scale), _stream()),
+                       "wino_in_nhwc_f16x2")
+                M = torch.empty((U.shape[0], tiles, cout), dtype=torch.float32, device=x.device)
+                _check(L.wino_gemm_c128_f16x2(V.data_ptr(), f16[3].data_ptr(), M.data_ptr(), U.shape[0], tiles, _stream()),
+                       "wino_gemm_c128_f16x2")
+                V = None
+            else:
+                V = torch.empty((U.shape[0], tiles, 3 * C), dtype=torch.float16, device=x.device)
+            if V is None:
+                pass
+            elif gn is not None:     # x_bound then bounds SiLU(GroupNorm(x)), the tensor the transform actually sees
                 gamma, beta, groups, eps, silu, stats, pre_bias = gn
                 _check(L.wino_in_gn_nhwc_f16x3(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias),
                                                stats.data_ptr(), V.data_ptr(), B, H, W, C, groups, float(eps),
@@ -449,7 +463,8 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
             else:
                 _check(L.wino_in_nhwc_f16x3(x.data_ptr(), V.data_ptr(), B, H, W, C, t, float(v_scale), _stream()),
                        "wino_in_nhwc_f16x3")
-            M = torch.bmm(V, U3, out_dtype=torch.float32)     # ONE fp16 GEMM per tile position, fp32 accumulate
+            if V is not None:
+                M = torch.bmm(V, U3, out_dtype=torch.float32)     # ONE fp16 GEMM per tile position, fp32 accumulate
             mscale = 1.0 / (v_scale * u_scale)
         else:
             V = torch.empty((U.shape[0], tiles, C), dtype=x.dtype, device=x.device)

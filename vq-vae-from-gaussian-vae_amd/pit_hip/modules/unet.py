@@ -81,7 +81,7 @@ def _f16_args(conv: nn.Conv2d, x: torch.Tensor, f4: bool):
     if not WINOGRAD_F16X3 or bound is None:
         return None
     u3, u_scale = _wino_weights_f16(conv, f4)
-    return u3, u_scale, bound
+    return u3, u_scale, bound, (conv._wino_u2t if WINOGRAD_C128_GEMM else None)
 
 
 def _conv(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
@@ -176,6 +176,9 @@ def _wino_weights_f16(conv: nn.Conv2d, f4: bool = False):
         h = us.half()
         l = (us - h.float()).half()
         conv._wino_u3 = torch.cat([h, l, h], 1).contiguous()
+        # 128 -> 128 channels: (U_h^T, U_l^T) [T, 2, Cout, Cin] for wino_gemm_c128_f16x2 (k contiguous per output column)
+        conv._wino_u2t = (torch.stack([h, l], 1).transpose(2, 3).contiguous()
+                          if WINOGRAD_C128_GEMM and tuple(U.shape[1:]) == (128, 128) else None)
         conv._wino_u_scale = u_scale
         conv._wino_f16_key = conv._wino_key
     return conv._wino_u3, conv._wino_u_scale
@@ -247,6 +250,9 @@ WINOGRAD_F4 = True       # decoder: F(4x4,3x3) (36 GEMMs on 6x6 tiles) instead o
 # for hipBLASLt's fp32 GEMM (itself a split-bf16 emulation on gfx950), at 1.2x (128 channels) to 2.5x (512) its speed
 # (tools/bmm_bf16x3.py).  False: the library's fp32 GEMM.
 WINOGRAD_F16X3 = True
+# 128 -> 128-channel Winograd GEMMs (256 x 256 level: HBM-bound at K = N = 128) through libgqhip's own kernel on the
+# [h | l] operand (4 instead of 6 bytes per element of V): same splits and products as the library route
+WINOGRAD_C128_GEMM = True
 FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the F(2x2,3x3) input transform: correct, but no faster (every input
                          # pixel is activated by the four tiles that overlap it, the kernel stops being HBM-bound): off
 FUSED_WINO_GN_F4 = False # ... inside the F(4x4,3x3) input transform (2.25 tiles per pixel): also measured, 1 % slower: off
