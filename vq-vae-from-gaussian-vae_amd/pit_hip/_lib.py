@@ -324,9 +324,6 @@ def fsq_dequant(idx, levels):
     return zhat
 
 
-_gn_ws = {}
-
-
 def image_layout(x: torch.Tensor):
     """0 = NCHW contiguous, 1 = NHWC (torch channels_last) dense, None = neither (caller falls back)."""
     if x.dim() != 4:
@@ -350,10 +347,9 @@ def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True, pre_bias
         raise GqHipError("gn_silu needs a dense fp32 NCHW / channels_last HIP tensor")
     B, C = x.shape[0], x.shape[1]
     HW = x.shape[2] * x.shape[3]
-    key = (x.device, B * groups)
-    ws = _gn_ws.get(key)
-    if ws is None:
-        ws = _gn_ws[key] = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+    # statistics scratch: a fresh (stream-ordered, caching-allocator) tensor per call -- a process-global buffer would be
+    # shared by concurrent streams / models and baked into captured graphs
+    ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
     y = torch.empty_like(x)  # preserves the memory format
     with torch.cuda.device(x.device):
         _check(lib().gn_silu_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), y.data_ptr(), B, C, HW,
