@@ -16,6 +16,9 @@
 // 96 MFMAs per tile (4 column tiles x 8 k-steps x 3 products) against 32 KiB of HBM traffic: a quarter of the time the
 // memory system needs for it, so nothing about the MFMA schedule matters here.  D layout: lane (c, h), register r holds
 // row (r & 3) + 8 (r >> 2) + 4 h of the tile, column c of the column tile: a store of one register is two 128-byte runs.
+// (Measured alternative: operands swapped so that a lane owns a row and leaves 16-byte stores, 32 row-scattered pieces
+// per instruction: 564 vs 501 us at 36 x 65 536 tiles -- the 4-byte stores in full 128-byte runs are the better pattern.)
+// Alone the kernel runs at 4.8-5.0 TB/s (tools/wino_gemm_bench.py); the grid is one co-resident round of blocks.
 #pragma once
 #include "gq_common.h"
 

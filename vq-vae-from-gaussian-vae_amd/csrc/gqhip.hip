@@ -786,9 +786,17 @@ int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, i
   if (!V2 || !U2t || !M) return GQHIP_ERR_INVALID_ARG;
   WinoGemmParams wp{};
   wp.V2 = static_cast<const _Float16 *>(V2); wp.U2t = static_cast<const _Float16 *>(U2t); wp.M = M; wp.tiles = tiles;
-  // ~2048 rows per block (16 row tiles per wave): the 64 KiB of U^T a block stages cost 4 % of the bytes it streams
-  long rpb = 2048;
-  if (tiles < rpb) rpb = (tiles + 127) / 128 * 128;
+  // ONE round of co-resident blocks (2 per CU: 70 KiB of LDS, <= 256 VGPRs): the kernel is HBM-bound, so a partial last
+  // round would idle part of the chip for a whole block's duration (1152 blocks of 2048 rows = 2.25 rounds ran at 3.9 TB/s).
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n > 0 ? n : 256;
+  }();
+  long bpp = (2L * cus) / P;
+  if (bpp < 1) bpp = 1;
+  long rpb = ((tiles + bpp - 1) / bpp + 127) / 128 * 128;
+  if (rpb < 128) rpb = 128;
   wp.rows_per_block = (int)rpb;
   wp.blocks_per_pos = (int)((tiles + rpb - 1) / rpb);
   hipLaunchKernelGGL(wino_gemm_c128_f16x2_kernel, dim3((unsigned)(P * wp.blocks_per_pos)), dim3(256), 0,
