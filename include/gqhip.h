@@ -213,6 +213,10 @@ int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, i
 int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                           const double *stats, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                           double eps, int apply_silu, int tile, float scale, void *stream);
+/* ... writing the [h | l] operand of wino_gemm_c128_f16x2. */
+int wino_in_gn_nhwc_f16x2(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                          const double *stats, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                          double eps, int apply_silu, int tile, float scale, void *stream);
 
 /* Winograd F(4x4, 3x3): V [36, tiles, C] of the 6x6 input tiles (tiles = B * H/4 * W/4, H and W multiples of 4) and
  * y [B, H, W, Cout] from M [36, tiles, Cout]; U = G g G^T is [36, Cin, Cout].  36 multiplies per 16 outputs and 2.25x

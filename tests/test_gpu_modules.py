@@ -663,6 +663,8 @@ def test_winograd_with_fused_groupnorm_matches_unfused():
                 stats = _lib.gn_stats(x, 32, pre)
                 fused = _lib.wino_conv3x3(x, Uw, gn=(norm.weight, norm.bias, 32, 1e-6, True, stats, pre))
                 plain = _lib.wino_conv3x3(_lib.gn_silu(x, norm.weight, norm.bias, 32, 1e-6, silu=True, pre_bias=pre), Uw)
+                # same folded scale / shift and SiLU function (gq_aux.h:silu_f32); gn_silu sums its own statistics
+                # (atomics), so a last-bit difference of the scale is possible: the fp32 GEMM's own noise is the bound
                 tol = 2e-4 if f4 else 1e-5
                 assert torch.allclose(fused, plain, atol=tol, rtol=tol), float((fused - plain).abs().max())
 

@@ -3,6 +3,7 @@ the cascade inside the one-launch tail kernel, the fused NHWC forward, PSNR / us
 the FSQ straight-through gradient, the train branch on the device, and BASELINE configs[4]'s 512 x 512 inputs
 end to end (Winograd at H = 512, attention over 4096 tokens) against goldens captured from the reference."""
 import json
+import math
 import os
 
 import numpy as np
@@ -434,3 +435,65 @@ def test_subpixel_upconv_f16x3_matches_fp32_route():
         assert vs == 2.0 ** round(np.log2(vs)) and float(x.abs().max()) * vs <= 32768.0      # a power of two, in range
         print(f"upconv {ch} {H}x{W} outlier {outlier:g}: fp32 GEMM {e32:.2e}, f16x3 {e16:.2e}, v_scale 2^{int(np.log2(vs))}")
         assert e16 <= 1.5 * e32 + 1e-7
+
+
+def test_fused_groupnorm_transforms_bit_identical_on_the_f16_routes():
+    """GroupNorm + swish inside the Winograd input transform (unet.FUSED_WINO_GN / _F4) writes the same V as gn_apply
+    followed by the plain transform -- fp16 x 3 operand for the library GEMM and [h | l] operand for the own 128-channel
+    GEMM, F(2x2,3x3) and F(4x4,3x3), with and without a pending bias, image borders included (12 x 20 pixels)."""
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(14)
+    for cin, cout in ((128, 128), (256, 128)):
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+        conv._gq_wino = conv._gq_wino4 = True
+        norm = torch.nn.GroupNorm(32, cin, eps=1e-6).to(DEV)
+        with torch.no_grad():
+            norm.weight.normal_(); norm.bias.normal_()
+        x = (3 * torch.randn(3, cin, 12, 20)).to(DEV).contiguous(memory_format=torch.channels_last)
+        pb = torch.randn(cin).to(DEV)
+        with torch.no_grad():
+            for f4 in (False, True):
+                Uw = U._wino_weights(conv, f4)
+                f16 = U._f16_args_gn(conv, norm, x, f4)
+                assert (f16[3] is not None) == (cin == 128)          # the own GEMM's operand exists for 128 -> 128 only
+                for pre in (None, pb):
+                    stats = _lib.gn_stats(x, 32, pre)
+                    gn = (norm.weight, norm.bias, 32, 1e-6, True, stats, pre)
+                    fused = _lib.wino_conv3x3(x, Uw, gn=gn, f16=f16)
+                    if pre is None:    # same statistics tensor -> same folded scale / shift -> same bits
+                        xn = _lib.gn_apply(x, norm.weight, norm.bias, 32, 1e-6, True, stats)
+                        plain = _lib.wino_conv3x3(xn, Uw, f16=f16)
+                        assert torch.equal(fused, plain), (cin, f4, float((fused - plain).abs().max()))
+                    else:              # gn_silu sums its own statistics (atomics: last-bit differences are possible)
+                        xn = _lib.gn_silu(x, norm.weight, norm.bias, 32, 1e-6, silu=True, pre_bias=pre)
+                        plain = _lib.wino_conv3x3(xn, Uw, f16=f16)
+                        assert torch.allclose(fused, plain, atol=1e-5, rtol=1e-5), float((fused - plain).abs().max())
+                    ref = torch.nn.functional.conv2d(xn.double(), conv.weight.double(), None, 1, 1)
+                    assert float((fused.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_silu_is_accurate_and_finite_at_the_extremes():
+    """libgqhip's one SiLU (Newton-refined reciprocal): within 4e-7 relative of fp64 on ordinary inputs; -0 / x at the
+    ends of the range (e^-x overflows for x < -88.7: the IEEE quotient there is -0, and so is ours -- no NaN; where
+    1 + e^-x > 1e37 the reciprocal is subnormal and the result, of magnitude < 1e-35, is returned as -0)."""
+    from pit_hip import _lib
+
+    C = 128
+    vals = torch.tensor([-200.0, -100.0, -88.0, -87.0, -20.0, -1.0, -1e-30, 0.0, 1e-30, 1.0, 20.0, 88.0, 100.0, 3e4])
+    # GroupNorm with gamma = 0 returns beta: feed each value through as beta of channel group k
+    x = torch.randn(1, C, 4, 4).to(DEV).contiguous(memory_format=torch.channels_last)
+    for v in vals.tolist():
+        beta = torch.full((C,), v, device=DEV)
+        y = _lib.gn_silu(x, torch.zeros(C, device=DEV), beta, 32, 1e-6, silu=True)
+        want = v / (1.0 + math.exp(-v)) if v > -700 else 0.0
+        got = float(y.flatten()[0])
+        assert not math.isnan(got) and abs(got - want) <= 4e-7 * abs(want) + 1e-34, (v, got, want)
+    g = torch.Generator().manual_seed(3)
+    x = (4 * torch.randn(2, C, 16, 16, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _lib.gn_silu(x, torch.ones(C, device=DEV), torch.zeros(C, device=DEV), 32, 1e-6, silu=True)
+    xn = torch.nn.functional.group_norm(x.double(), 32, eps=1e-6)
+    ref = xn * torch.sigmoid(xn)
+    # the normalised value carries ~1e-7 of the un-normalised magnitude (fp32 fold of scale and shift): absolute floor
+    assert float(((y.double() - ref).abs() / (ref.abs() + 1.0)).max()) <= 5e-7

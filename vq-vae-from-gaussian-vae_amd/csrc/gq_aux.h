@@ -176,6 +176,19 @@ __global__ __launch_bounds__(256) void lfq_unpack_kernel(const int64_t *__restri
   q[t] = ((v >> (nbits - 1 - i)) & 1) ? 1.0f : -1.0f;
 }
 
+// x * sigmoid(x) = x / (1 + e^-x), the quotient by one Newton step on v_rcp_f32 (q = x r; q += (x - d q) r: within
+// half an ulp of the IEEE quotient up to a few units of 2^-24 of an ulp, at a third of the IEEE divide's instructions).
+// EVERY SiLU of libgqhip goes through this function, so the GroupNorm applied as its own pass and the one fused into
+// the Winograd input transforms produce identical bits.  d > 1e37 (x < -85.2; d = inf below -88.7): 1 / d is subnormal,
+// the result (|.| < 1e-35) is returned as x * 0 = -0 -- the divide gives -0 for d = inf too -- and never a NaN.
+__device__ __forceinline__ float silu_f32(float x) {
+  const float d = 1.0f + __expf(-x);
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float q = x * r;
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q, x), r, q);
+  return d > 1e37f ? q : q1;
+}
+
 // ---- NHWC (channels_last) variants: x[b][hw][c], the layout MIOpen's fp32 igemm kernels want ----
 // A block owns a slab of pixels of one image and ALL channels: thread -> channel quad q = tid % (C/4)
 // (4 consecutive channels of ONE group since cpg % 4 == 0), pixel lane = tid / (C/4).
@@ -239,10 +252,10 @@ __global__ __launch_bounds__(256) void gn_apply_nhwc_kernel(const float *__restr
   for (long p = lo + pl; p < hi; p += lanes) {
     f32x4 v = *reinterpret_cast<const f32x4 *>(xi + p * C) * a + sh;
     if (SILU) {
-      v.x = v.x / (1.0f + __expf(-v.x));
-      v.y = v.y / (1.0f + __expf(-v.y));
-      v.z = v.z / (1.0f + __expf(-v.z));
-      v.w = v.w / (1.0f + __expf(-v.w));
+      v.x = silu_f32(v.x);
+      v.y = silu_f32(v.y);
+      v.z = silu_f32(v.z);
+      v.w = silu_f32(v.w);
     }
     *reinterpret_cast<f32x4 *>(yo + p * C) = v;
   }
@@ -389,6 +402,20 @@ __global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restri
   }
 }
 
+// SiLU(GroupNorm(x)) of four channels: a, sh = the folded per-channel scale and shift.  The same arithmetic as
+// gn_apply_nhwc_kernel, so the fused transforms write bit-for-bit the V of the two-pass route.
+template <int SILU>
+__device__ __forceinline__ f32x4 gn_act(f32x4 v, f32x4 a, f32x4 sh) {
+  v = v * a + sh;
+  if (SILU) {
+    v.x = silu_f32(v.x);
+    v.y = silu_f32(v.y);
+    v.z = silu_f32(v.z);
+    v.w = silu_f32(v.w);
+  }
+  return v;
+}
+
 // Input transform with the producer fused in: the conv input is GroupNorm(+SiLU) of x (unet.py:140-142, :146-149), so
 // the normalisation is applied to the 16 loaded values on the fly (statistics from gn_stats / add_bias_stats) and the
 // normalised tensor is never written: saves gn_apply's write and this kernel's read of it.  Zero padding applies to the
@@ -427,19 +454,20 @@ __global__ __launch_bounds__(256) void wino_in_gn_nhwc_kernel(const float *__res
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        // no branch around the load: the 16 loads must all be in flight before the first activation (with the
+        // activation inside an `if` hipcc keeps 16 load -> wait -> compute rounds: measured 965 vs 765 us); taps outside
+        // the image read a clamped address and are zeroed afterwards
         const int sy = 2 * th - 1 + i, sx = 2 * tw - 1 + j;
-        d[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
-          f32x4 v = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q] * a + sh;
-          if (SILU) {   // x * sigmoid(x); v_rcp_f32 (1 ulp) instead of an IEEE divide: every input pixel is activated by
-                        // the four tiles that overlap it, so the activation is on this kernel's critical path
-            v.x = v.x * __builtin_amdgcn_rcpf(1.0f + __expf(-v.x));
-            v.y = v.y * __builtin_amdgcn_rcpf(1.0f + __expf(-v.y));
-            v.z = v.z * __builtin_amdgcn_rcpf(1.0f + __expf(-v.z));
-            v.w = v.w * __builtin_amdgcn_rcpf(1.0f + __expf(-v.w));
-          }
-          d[i][j] = v;
-        }
+        const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy), cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+        d[i][j] = reinterpret_cast<const f32x4 *>(x)[((b * H + cy) * W + cx) * C4 + q];
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sy = 2 * th - 1 + i, sx = 2 * tw - 1 + j;
+        const float inb = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? 1.f : 0.f;
+        d[i][j] = gn_act<SILU>(d[i][j], a, sh) * inb;
       }
     f32x4 w[4][4];
 #pragma unroll
@@ -586,18 +614,15 @@ __global__ __launch_bounds__(256) void wino4_in_gn_nhwc_kernel(const float *__re
       const int sx = 4 * tw - 1 + j;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
+        const int sy = 4 * th - 1 + i;   // branch-free: see wino_in_gn_nhwc_kernel
+        const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy), cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+        col[i] = reinterpret_cast<const f32x4 *>(x)[((b * H + cy) * W + cx) * C4 + q];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
         const int sy = 4 * th - 1 + i;
-        col[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
-          f32x4 v = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q] * a + sh;
-          if (SILU) {
-            v.x = v.x * __builtin_amdgcn_rcpf(1.0f + __expf(-v.x));
-            v.y = v.y * __builtin_amdgcn_rcpf(1.0f + __expf(-v.y));
-            v.z = v.z * __builtin_amdgcn_rcpf(1.0f + __expf(-v.z));
-            v.w = v.w * __builtin_amdgcn_rcpf(1.0f + __expf(-v.w));
-          }
-          col[i] = v;
-        }
+        const float inb = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? 1.f : 0.f;
+        col[i] = gn_act<SILU>(col[i], a, sh) * inb;
       }
       wino4_bt(col, o);
 #pragma unroll
@@ -926,10 +951,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
     f32x4 v = *reinterpret_cast<const f32x4 *>(xi + i);
     v = v * a + sh;
     if (SILU) {
-      v.x = v.x / (1.0f + __expf(-v.x));
-      v.y = v.y / (1.0f + __expf(-v.y));
-      v.z = v.z / (1.0f + __expf(-v.z));
-      v.w = v.w / (1.0f + __expf(-v.w));
+      v.x = silu_f32(v.x);
+      v.y = silu_f32(v.y);
+      v.z = silu_f32(v.z);
+      v.w = silu_f32(v.w);
     }
     *reinterpret_cast<f32x4 *>(yo + i) = v;
   }

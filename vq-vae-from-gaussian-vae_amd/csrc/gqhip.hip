@@ -819,7 +819,7 @@ int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64
   return check_launch();
 }
 
-static int wino_in_gn_impl(int tile, bool f16, const float *x, const float *gamma, const float *beta,
+static int wino_in_gn_impl(int tile, int f16, const float *x, const float *gamma, const float *beta,
                            const float *pre_bias_or_null, const double *stats, void *V, int64_t B, int64_t H, int64_t W,
                            int64_t C, int64_t groups, double eps, int apply_silu, float scale, void *stream) {
   if (B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 || groups < 1 || C % groups != 0 ||
@@ -835,12 +835,12 @@ static int wino_in_gn_impl(int tile, bool f16, const float *x, const float *gamm
   hipLaunchKernelGGL((K<S, F>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, pre_bias_or_null, stats, V, \
                      (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total, scale)
   if (tile == 4) {
-    if (apply_silu) { if (f16) GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 1); else GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 0); }
-    else { if (f16) GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 1); else GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 0); }
+#define GQ_WGN3(K, S) do { if (f16 == 2) GQ_WGN(K, S, 2); else if (f16 == 1) GQ_WGN(K, S, 1); else GQ_WGN(K, S, 0); } while (0)
+    if (apply_silu) GQ_WGN3(wino4_in_gn_nhwc_kernel, 1); else GQ_WGN3(wino4_in_gn_nhwc_kernel, 0);
   } else {
-    if (apply_silu) { if (f16) GQ_WGN(wino_in_gn_nhwc_kernel, 1, 1); else GQ_WGN(wino_in_gn_nhwc_kernel, 1, 0); }
-    else { if (f16) GQ_WGN(wino_in_gn_nhwc_kernel, 0, 1); else GQ_WGN(wino_in_gn_nhwc_kernel, 0, 0); }
+    if (apply_silu) GQ_WGN3(wino_in_gn_nhwc_kernel, 1); else GQ_WGN3(wino_in_gn_nhwc_kernel, 0);
   }
+#undef GQ_WGN3
 #undef GQ_WGN
   return check_launch();
 }
@@ -848,20 +848,28 @@ static int wino_in_gn_impl(int tile, bool f16, const float *x, const float *gamm
 int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                         const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                         double eps, int apply_silu, void *stream) {
-  return wino_in_gn_impl(2, false, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, 1.0f, stream);
+  return wino_in_gn_impl(2, 0, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, 1.0f, stream);
 }
 
 int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                          const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                          double eps, int apply_silu, void *stream) {
-  return wino_in_gn_impl(4, false, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, 1.0f, stream);
+  return wino_in_gn_impl(4, 0, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, 1.0f, stream);
 }
 
 int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                           const double *stats, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                           double eps, int apply_silu, int tile, float scale, void *stream) {
   if (tile != 2 && tile != 4) return GQHIP_ERR_INVALID_ARG;
-  return wino_in_gn_impl(tile, true, x, gamma, beta, pre_bias_or_null, stats, V3, B, H, W, C, groups, eps, apply_silu, scale,
+  return wino_in_gn_impl(tile, 1, x, gamma, beta, pre_bias_or_null, stats, V3, B, H, W, C, groups, eps, apply_silu, scale,
+                         stream);
+}
+
+int wino_in_gn_nhwc_f16x2(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                          const double *stats, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                          double eps, int apply_silu, int tile, float scale, void *stream) {
+  if (tile != 2 && tile != 4) return GQHIP_ERR_INVALID_ARG;
+  return wino_in_gn_impl(tile, 2, x, gamma, beta, pre_bias_or_null, stats, V2, B, H, W, C, groups, eps, apply_silu, scale,
                          stream);
 }
 

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "wino_gemm_c128_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "wino_in_gn_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
+    "wino_in_gn_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
@@ -438,11 +440,17 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
             amp = 100.0 if f4 else 4.0
             v_scale = 2.0 ** math.floor(math.log2(32768.0 / (amp * max(float(x_bound), 1e-30))))
             v_scale = min(v_scale, 2.0 ** 14)
-            if gn is None and C == 128 and cout == 128 and len(f16) > 3 and f16[3] is not None:
+            if C == 128 and cout == 128 and len(f16) > 3 and f16[3] is not None:
                 # HBM-bound case: [h | l] operand (4 bytes per element) + our own GEMM kernel forming the three products
                 V = torch.empty((U.shape[0], tiles, 2 * C), dtype=torch.float16, device=x.device)
-                _check(L.wino_in_nhwc_f16x2(x.data_ptr(), V.data_ptr(), B, H, W, C, t, float(v_scale), _stream()),
-                       "wino_in_nhwc_f16x2")
+                if gn is not None:
+                    gamma, beta, groups, eps, silu, stats, pre_bias = gn
+                    _check(L.wino_in_gn_nhwc_f16x2(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias),
+                                                   stats.data_ptr(), V.data_ptr(), B, H, W, C, groups, float(eps),
+                                                   1 if silu else 0, t, float(v_scale), _stream()), "wino_in_gn_nhwc_f16x2")
+                else:
+                    _check(L.wino_in_nhwc_f16x2(x.data_ptr(), V.data_ptr(), B, H, W, C, t, float(v_scale), _stream()),
+                           "wino_in_nhwc_f16x2")
                 M = torch.empty((U.shape[0], tiles, cout), dtype=torch.float32, device=x.device)
                 _check(L.wino_gemm_c128_f16x2(V.data_ptr(), f16[3].data_ptr(), M.data_ptr(), U.shape[0], tiles, _stream()),
                        "wino_gemm_c128_f16x2")

@@ -84,6 +84,15 @@ def _f16_args(conv: nn.Conv2d, x: torch.Tensor, f4: bool):
     return u3, u_scale, bound, (conv._wino_u2t if WINOGRAD_C128_GEMM else None)
 
 
+def _f16_args_gn(conv: nn.Conv2d, norm: nn.GroupNorm, x: torch.Tensor, f4: bool):
+    """_f16_args for a convolution whose GroupNorm + swish runs inside the input transform: the bound is that of the
+    activated tensor, which is never materialised."""
+    if not WINOGRAD_F16X3:
+        return None
+    u3, u_scale = _wino_weights_f16(conv, f4)
+    return u3, u_scale, _gn_act_bound(norm, x), (conv._wino_u2t if WINOGRAD_C128_GEMM else None)
+
+
 def _conv(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
     """Run ``conv`` and return (y, pending_bias).  ATen's MIOpen path adds the bias in a separate
     elementwise pass over the whole output; on the deferred path the conv runs bias-free and the
@@ -121,10 +130,8 @@ def _wino_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
 
 
 def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None, want_stats: bool = False):
-    """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  The GroupNorm(+SiLU) can be applied inside the Winograd
-    input transform so that the normalised tensor is never written (FUSED_WINO_GN / FUSED_WINO_GN_F4) -- measured:
-    no gain (every pixel is activated by the 4 / 2.25 tiles that overlap it and the transform stops being HBM-bound),
-    so both switches are off and the plain gn_silu -> transform sequence runs."""
+    """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  The GroupNorm(+SiLU) is applied inside the Winograd input
+    transform, so the normalised tensor is never written (FUSED_WINO_GN / FUSED_WINO_GN_F4)."""
     if _defer_ok(x, conv) and _wino_ok(conv, x) and _use_fused(x, norm):
         from .. import _lib
 
@@ -137,7 +144,7 @@ def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bia
                 stats = _lib.gn_stats(x, norm.num_groups, pre_bias)
             gn = (norm.weight, norm.bias, norm.num_groups, norm.eps, True, stats, pre_bias)
             U = _wino_weights(conv, f4)
-            f16 = (_wino_weights_f16(conv, f4) + (_gn_act_bound(norm, x),)) if WINOGRAD_F16X3 else None
+            f16 = _f16_args_gn(conv, norm, x, f4)
             if want_stats and FUSED_WINO_TAIL and _lib.gn_nhwc_ok(conv.out_channels, GN_GROUPS):
                 y, ostats = _lib.wino_conv3x3(x, U, gn=gn, bias=conv.bias, stats_groups=GN_GROUPS, f16=f16)
                 y._gn_stats = (ostats, GN_GROUPS)
@@ -253,9 +260,11 @@ WINOGRAD_F16X3 = True
 # 128 -> 128-channel Winograd GEMMs (256 x 256 level: HBM-bound at K = N = 128) through libgqhip's own kernel on the
 # [h | l] operand (4 instead of 6 bytes per element of V): same splits and products as the library route
 WINOGRAD_C128_GEMM = True
-FUSED_WINO_GN = False    # GroupNorm+SiLU applied inside the F(2x2,3x3) input transform: correct, but no faster (every input
-                         # pixel is activated by the four tiles that overlap it, the kernel stops being HBM-bound): off
-FUSED_WINO_GN_F4 = False # ... inside the F(4x4,3x3) input transform (2.25 tiles per pixel): also measured, 1 % slower: off
+# GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
+# written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
+# since the loads of a tile are issued ahead of the activations (branch-free borders): 53.4 -> 50.8 ms / step.
+FUSED_WINO_GN = True
+FUSED_WINO_GN_F4 = True
 # also in the encoder: measured perturbation of z 4.2e-6 vs the CPU reference (direct MIOpen convs: 3.4e-6), no index
 # change on the CPU golden nor on 16 384 rows against the direct-conv encoder (tools/encoder_winograd_check.py)
 WINOGRAD_ENCODER = True
@@ -327,8 +336,7 @@ class ResnetBlock(nn.Module):
                             stats = _lib.gn_stats(h, self.norm2.num_groups, b1)
                         gn = (self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, stats, b1)
                         src = h
-                        f16 = ((_wino_weights_f16(self.conv2, f4) + (_gn_act_bound(self.norm2, h),))
-                               if WINOGRAD_F16X3 else None)
+                        f16 = _f16_args_gn(self.conv2, self.norm2, h, f4)
                     else:
                         gn, src = None, _norm_act(self.norm2, h, pre_bias=b1)
                         f16 = _f16_args(self.conv2, src, f4)
