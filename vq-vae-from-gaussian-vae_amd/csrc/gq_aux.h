@@ -339,28 +339,30 @@ __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__res
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // F16X3 = 2 ("f16x2"): V2 [k][tile][2C] = [ h | l ] only -- the operand of wino_gemm_c128_f16x2_kernel, which forms the
 // three products itself (4 instead of 6 bytes per element).
-template <int F16X3>
-__device__ __forceinline__ void wino_store_v(void *V, int k, long tiles, long tile, int C4, int q, f32x4 v, float scale) {
+template <int F16X3, typename VEC>
+__device__ __forceinline__ void wino_store_v(void *V, int k, long tiles, long tile, int CV, int q, VEC v, float scale) {
+  constexpr int VW = sizeof(VEC) / sizeof(float);          // channels per thread (4, or 2 in the two-channel kernels)
+  typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
   if constexpr (F16X3 != 0) {
     v = v * scale;
-    f16x4 h, l;
+    hvec h, l;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VW; ++e) {
       h[e] = (_Float16)v[e];
       l[e] = (_Float16)(v[e] - (float)h[e]);
     }
     if constexpr (F16X3 == 2) {
-      f16x4 *row = reinterpret_cast<f16x4 *>(V) + ((long)k * tiles + tile) * (2 * C4);
+      hvec *row = reinterpret_cast<hvec *>(V) + ((long)k * tiles + tile) * (2 * CV);
       row[q] = h;
-      row[C4 + q] = l;
+      row[CV + q] = l;
     } else {
-      f16x4 *row = reinterpret_cast<f16x4 *>(V) + ((long)k * tiles + tile) * (3 * C4);
+      hvec *row = reinterpret_cast<hvec *>(V) + ((long)k * tiles + tile) * (3 * CV);
       row[q] = h;
-      row[C4 + q] = h;
-      row[2 * C4 + q] = l;
+      row[CV + q] = h;
+      row[2 * CV + q] = l;
     }
   } else {
-    reinterpret_cast<f32x4 *>(V)[((long)k * tiles + tile) * C4 + q] = v;
+    reinterpret_cast<VEC *>(V)[((long)k * tiles + tile) * CV + q] = v;
   }
 }
 
@@ -404,14 +406,12 @@ __global__ __launch_bounds__(256) void wino_in_nhwc_kernel(const float *__restri
 
 // SiLU(GroupNorm(x)) of four channels: a, sh = the folded per-channel scale and shift.  The same arithmetic as
 // gn_apply_nhwc_kernel, so the fused transforms write bit-for-bit the V of the two-pass route.
-template <int SILU>
-__device__ __forceinline__ f32x4 gn_act(f32x4 v, f32x4 a, f32x4 sh) {
+template <int SILU, typename VEC>
+__device__ __forceinline__ VEC gn_act(VEC v, VEC a, VEC sh) {
   v = v * a + sh;
   if (SILU) {
-    v.x = silu_f32(v.x);
-    v.y = silu_f32(v.y);
-    v.z = silu_f32(v.z);
-    v.w = silu_f32(v.w);
+#pragma unroll
+    for (int e = 0; e < (int)(sizeof(VEC) / sizeof(float)); ++e) v[e] = silu_f32(v[e]);
   }
   return v;
 }
@@ -524,7 +524,8 @@ __global__ __launch_bounds__(256) void wino_out_nhwc_kernel(const float *__restr
 // constants (up to 8) cost ~10x the rounding error of F(2x2,3x3): used in the decoder only.
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-__device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&o)[6]) {
+template <typename V>
+__device__ __forceinline__ void wino4_bt(const V (&d)[6], V (&o)[6]) {
   o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
   o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
   o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
@@ -532,8 +533,9 @@ __device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&o)[6]) {
   o[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
   o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
-__device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&o)[4]) {
-  const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+template <typename V>
+__device__ __forceinline__ void wino4_at(const V (&m)[6], V (&o)[4]) {
+  const V s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
   o[0] = m[0] + s12 + s34;
   o[1] = d12 + 2.f * d34;
   o[2] = s12 + 4.f * s34;
@@ -577,46 +579,49 @@ __global__ __launch_bounds__(256) void wino4_in_nhwc_kernel(const float *__restr
 }
 
 // wino4_in_nhwc_kernel with the producer fused in (see wino_in_gn_nhwc_kernel): every pixel is activated by the 2.25 tiles
-// that overlap it (4 with F(2x2,3x3), where the fusion brought nothing).
-template <int SILU, int F16X3>
+// that overlap it.  VW = channels per thread: with 4 the 36 x 4 values of a tile plus the activation's temporaries take
+// ~250 registers (two waves per SIMD, the activations' VALU time shows: 399 vs 304 us for the plain transform); with 2
+// (whenever a 256-thread block still spans whole pixels) twice the waves hide it.
+template <int SILU, int F16X3, int VW>
 __global__ __launch_bounds__(256) void wino4_in_gn_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                                const float *__restrict__ beta,
                                                                const float *__restrict__ pre_bias,
                                                                const double *__restrict__ stats, void *__restrict__ V,
-                                                               int H, int W, int C4, int cpg, double eps, long tiles,
+                                                               int H, int W, int CV, int cpg, double eps, long tiles,
                                                                long total, float scale) {
-  const int groups = 4 * C4 / cpg;
+  typedef float vec __attribute__((ext_vector_type(VW)));
+  const int groups = VW * CV / cpg;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const int q = (int)(t % C4);
-    const long tile = t / C4;
+    const int q = (int)(t % CV);
+    const long tile = t / CV;
     const int tw = (int)(tile % (W / 4));
     const long r = tile / (W / 4);
     const int th = (int)(r % (H / 4));
     const long b = r / (H / 4);
-    const int g = (4 * q) / cpg;
+    const int g = (VW * q) / cpg;
     const double n = (double)cpg * (double)H * (double)W;
     const double mean = stats[2 * (b * groups + g)] / n;
     double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const double rstd = 1.0 / sqrt(var + eps);
-    f32x4 a, sh;
+    vec a, sh;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = 4 * q + k;
+    for (int k = 0; k < VW; ++k) {
+      const int c = VW * q + k;
       const double pbk = pre_bias ? (double)pre_bias[c] : 0.0;
       a[k] = (float)(rstd * (double)gamma[c]);
       sh[k] = (float)((double)beta[c] + (pbk - mean) * rstd * (double)gamma[c]);
     }
-    f32x4 w[6][6];
+    vec w[6][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      f32x4 col[6], o[6];
+      vec col[6], o[6];
       const int sx = 4 * tw - 1 + j;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int sy = 4 * th - 1 + i;   // branch-free: see wino_in_gn_nhwc_kernel
         const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy), cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
-        col[i] = reinterpret_cast<const f32x4 *>(x)[((b * H + cy) * W + cx) * C4 + q];
+        col[i] = reinterpret_cast<const vec *>(x)[((b * H + cy) * W + cx) * CV + q];
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -630,10 +635,10 @@ __global__ __launch_bounds__(256) void wino4_in_gn_nhwc_kernel(const float *__re
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      f32x4 o[6];
+      vec o[6];
       wino4_bt(w[i], o);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) wino_store_v<F16X3>(V, 6 * i + j, tiles, tile, C4, q, o[j], scale);
+      for (int j = 0; j < 6; ++j) wino_store_v<F16X3>(V, 6 * i + j, tiles, tile, CV, q, o[j], scale);
     }
   }
 }
@@ -673,49 +678,66 @@ __global__ __launch_bounds__(256) void wino4_out_nhwc_kernel(const float *__rest
 // Output transform with the ResnetBlock's tail fused in (unet.py:149-153): y = A^T M A + bias[c] (+ res), and the GroupNorm
 // statistics of y for the block that follows (as add_bias_stats_nhwc_kernel).  A block owns a range of tiles of ONE
 // image; thread -> channel quad q = tid % C4 (one GroupNorm group), tile lane = tid / C4.  T = 2: F(2x2,3x3), 4: F(4x4,3x3).
-template <int T>
+// VW = channels per thread: 4 (16-byte accesses), or 2 for F(4x4,3x3) -- with 4 the 36 loads of M, the 24 intermediate
+// values and the 16 residual loads of a tile do not fit 256 registers, the residual is loaded late, one wave per SIMD
+// waits for it 16 times (585 us at 16 x 256 x 256 x 128, 3.9 TB/s); with 2 everything is in flight at once at two waves
+// per SIMD and an access of a wave is still whole 128-byte lines (64 lanes x 8 bytes = the 128 channels of a pixel).
+template <int T, int VW>
 __global__ __launch_bounds__(256) void wino_out_res_nhwc_kernel(const float *__restrict__ M, const float *__restrict__ res,
                                                                 const float *__restrict__ bias, float *__restrict__ y,
-                                                                double *__restrict__ stats, int H, int W, int C4,
+                                                                double *__restrict__ stats, int H, int W, int CV,
                                                                 int cpg, long tiles, int slabs, float mscale) {
+  typedef float vec __attribute__((ext_vector_type(VW)));
   constexpr int NI = T + 2;   // transform size (4 or 6)
   __shared__ double red[2 * 64];
-  const int groups = 4 * C4 / cpg, lanes = 256 / C4;
+  const int groups = VW * CV / cpg, lanes = 256 / CV;
   const long b = blockIdx.x / slabs;
   const int slab = blockIdx.x % slabs;
   const long tpi = (long)(H / T) * (W / T);           // tiles per image
   const long per = (tpi + slabs - 1) / slabs;
   const long lo = slab * per, hi = lo + per < tpi ? lo + per : tpi;
-  const int q = threadIdx.x % C4, tl = threadIdx.x / C4;
+  const int q = threadIdx.x % CV, tl = threadIdx.x / CV;
   if (threadIdx.x < 2 * groups) red[threadIdx.x] = 0.0;
   __syncthreads();
-  f32x4 pb = {0.f, 0.f, 0.f, 0.f};
-  if (bias) pb = reinterpret_cast<const f32x4 *>(bias)[q];
-  const long plane = tiles * C4;
+  vec pb = (vec)(0.f);
+  if (bias) pb = reinterpret_cast<const vec *>(bias)[q];
+  const long plane = tiles * CV;
   float s = 0.f, ss = 0.f;
   for (long ti = lo + tl; ti < hi; ti += lanes) {
     const int tw = (int)(ti % (W / T)), th = (int)(ti / (W / T));
-    const f32x4 *mi = reinterpret_cast<const f32x4 *>(M) + (b * tpi + ti) * C4 + q;
-    f32x4 u[T][NI];
+    const vec *mi = reinterpret_cast<const vec *>(M) + (b * tpi + ti) * CV + q;
+    const long pix0 = ((b * H + (long)T * th) * W + (long)T * tw) * CV + q;
+    vec r[T][T];
+    if (res) {   // wave-uniform; issued ahead of M so that nothing waits for it at the end
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) r[i][j] = reinterpret_cast<const vec *>(res)[pix0 + ((long)i * W + j) * CV];
+    } else {
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) r[i][j] = (vec)(0.f);
+    }
+    vec u[T][NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       if constexpr (T == 4) {
-        f32x4 col[6], o[4];
+        vec col[6], o[4];
 #pragma unroll
         for (int i = 0; i < 6; ++i) col[i] = mi[(6 * i + j) * plane];
         wino4_at(col, o);
 #pragma unroll
         for (int i = 0; i < 4; ++i) u[i][j] = o[i];
       } else {
-        const f32x4 m0 = mi[(0 + j) * plane], m1 = mi[(4 + j) * plane], m2 = mi[(8 + j) * plane], m3 = mi[(12 + j) * plane];
+        const vec m0 = mi[(0 + j) * plane], m1 = mi[(4 + j) * plane], m2 = mi[(8 + j) * plane], m3 = mi[(12 + j) * plane];
         u[0][j] = m0 + m1 + m2;
         u[1][j] = m1 - m2 - m3;
       }
     }
-    const long pix0 = ((b * H + (long)T * th) * W + (long)T * tw) * C4 + q;
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-      f32x4 o[T];
+      vec o[T];
       if constexpr (T == 4) {
         wino4_at(u[i], o);
       } else {
@@ -724,16 +746,21 @@ __global__ __launch_bounds__(256) void wino_out_res_nhwc_kernel(const float *__r
       }
 #pragma unroll
       for (int j = 0; j < T; ++j) {
-        const long off = pix0 + ((long)i * W + j) * C4;
-        f32x4 v = o[j] * mscale + pb;
-        if (res) v = v + reinterpret_cast<const f32x4 *>(res)[off];
-        reinterpret_cast<f32x4 *>(y)[off] = v;
-        s += (v.x + v.y) + (v.z + v.w);
-        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        const long off = pix0 + ((long)i * W + j) * CV;
+        vec v = o[j] * mscale + pb;
+        if (res) v = v + r[i][j];
+        reinterpret_cast<vec *>(y)[off] = v;
+        if constexpr (VW == 4) {
+          s += (v.x + v.y) + (v.z + v.w);
+          ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        } else {
+          s += v.x + v.y;
+          ss += v.x * v.x + v.y * v.y;
+        }
       }
     }
   }
-  const int g = (4 * q) / cpg;
+  const int g = (VW * q) / cpg;
   atomicAdd(&red[2 * g], (double)s);
   atomicAdd(&red[2 * g + 1], (double)ss);
   __syncthreads();

@@ -827,20 +827,32 @@ static int wino_in_gn_impl(int tile, int f16, const float *x, const float *gamma
     return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!x || !gamma || !beta || !stats || !V) return GQHIP_ERR_INVALID_ARG;
-  const long tiles = (long)(B * (H / tile) * (W / tile)), total = tiles * (C / 4);
+  // F(4x4,3x3) on an fp16 operand: two channels per thread (register pressure: see the kernel); 4 otherwise
+  const int vw = (tile == 4 && f16 != 0) ? 2 : 4;
+  const long tiles = (long)(B * (H / tile) * (W / tile)), total = tiles * (C / vw);
   long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
+  if (blocks > 32768) blocks = 32768;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define GQ_WGN(K, S, F)                                                                                              \
-  hipLaunchKernelGGL((K<S, F>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, pre_bias_or_null, stats, V, \
-                     (int)H, (int)W, (int)(C / 4), (int)(C / groups), eps, tiles, total, scale)
+#define GQ_WGN(K, ...)                                                                                                  \
+  hipLaunchKernelGGL((K<__VA_ARGS__>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, pre_bias_or_null, stats, \
+                     V, (int)H, (int)W, (int)(C / vw), (int)(C / groups), eps, tiles, total, scale)
   if (tile == 4) {
-#define GQ_WGN3(K, S) do { if (f16 == 2) GQ_WGN(K, S, 2); else if (f16 == 1) GQ_WGN(K, S, 1); else GQ_WGN(K, S, 0); } while (0)
-    if (apply_silu) GQ_WGN3(wino4_in_gn_nhwc_kernel, 1); else GQ_WGN3(wino4_in_gn_nhwc_kernel, 0);
+    if (apply_silu) {
+      if (f16 == 2) GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 2, 2); else if (f16 == 1) GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 1, 2);
+      else GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 0, 4);
+    } else {
+      if (f16 == 2) GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 2, 2); else if (f16 == 1) GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 1, 2);
+      else GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 0, 4);
+    }
   } else {
-    if (apply_silu) GQ_WGN3(wino_in_gn_nhwc_kernel, 1); else GQ_WGN3(wino_in_gn_nhwc_kernel, 0);
+    if (apply_silu) {
+      if (f16 == 2) GQ_WGN(wino_in_gn_nhwc_kernel, 1, 2); else if (f16 == 1) GQ_WGN(wino_in_gn_nhwc_kernel, 1, 1);
+      else GQ_WGN(wino_in_gn_nhwc_kernel, 1, 0);
+    } else {
+      if (f16 == 2) GQ_WGN(wino_in_gn_nhwc_kernel, 0, 2); else if (f16 == 1) GQ_WGN(wino_in_gn_nhwc_kernel, 0, 1);
+      else GQ_WGN(wino_in_gn_nhwc_kernel, 0, 0);
+    }
   }
-#undef GQ_WGN3
 #undef GQ_WGN
   return check_launch();
 }
@@ -922,16 +934,21 @@ int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(stats_out, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) return check_launch();
   const long tpi = (long)((H / tile) * (W / tile)), tiles = (long)B * tpi;
-  const int lanes = (int)(256 / (C / 4));
+  // F(4x4,3x3): two channels per thread (see the kernel) wherever a block still spans whole pixels
+  const int vw = (tile == 4 && 256 % (C / 2) == 0) ? 2 : 4;
+  const int lanes = (int)(256 / (C / vw));
   long slabs = (tpi + (long)lanes * 4 - 1) / ((long)lanes * 4);    // ~4 tiles per thread
   if (slabs > 1024) slabs = 1024;
   if (slabs < 1) slabs = 1;
   const dim3 grid((unsigned)(B * slabs));
-  if (tile == 4)
-    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<4>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
+  if (tile == 4 && vw == 2)
+    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<4, 2>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
+                       (int)W, (int)(C / 2), (int)cpg, tiles, (int)slabs, mscale);
+  else if (tile == 4)
+    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<4, 4>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
                        (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs, mscale);
   else
-    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<2>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
+    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<2, 4>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
                        (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs, mscale);
   return check_launch();
 }
