@@ -497,3 +497,82 @@ def test_silu_is_accurate_and_finite_at_the_extremes():
     ref = xn * torch.sigmoid(xn)
     # the normalised value carries ~1e-7 of the un-normalised magnitude (fp32 fold of scale and shift): absolute floor
     assert float(((y.double() - ref).abs() / (ref.abs() + 1.0)).max()) <= 5e-7
+
+
+def test_direct_conv3x3_matches_fp64_convolution():
+    """conv3x3_direct (implicit GEMM, fp16 x 3, GroupNorm + swish in the split pass, bias / residual / statistics in the
+    epilogue) against torch's fp64 convolution of the same activated tensor: error <= 6e-7 of sum |x||w| (three products
+    of 22-bit splits, fp32 accumulation over 9 Cin terms), image borders and several tiles per image included."""
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(21)
+    for cin, (B, H, W) in ((128, (2, 16, 64)), (256, (1, 8, 32)), (16, (3, 24, 32))):
+        conv = torch.nn.Conv2d(cin, 128, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+        norm = torch.nn.GroupNorm(4 if cin == 16 else 32, cin, eps=1e-6).to(DEV)
+        with torch.no_grad():
+            norm.weight.normal_(); norm.bias.normal_()
+            x = (2 * torch.randn(B, cin, H, W, device=DEV)).contiguous(memory_format=torch.channels_last)
+            res = torch.randn(B, 128, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+            wf, us = _lib.conv3_weights_f16(conv.weight)
+            groups = norm.num_groups
+            stats = _lib.gn_stats(x, groups)
+            gn = (norm.weight, norm.bias, groups, 1e-6, True, stats, None)
+            bound = U._gn_act_bound(norm, x)
+            xn = _lib.gn_apply(x, norm.weight, norm.bias, groups, 1e-6, True, stats).double()
+            sc = torch.nn.functional.conv2d(xn.abs(), conv.weight.double().abs(), None, 1, 1)
+            ref0 = torch.nn.functional.conv2d(xn, conv.weight.double(), None, 1, 1)
+            # (a) bias + residual + statistics
+            y, st = _lib.conv3x3_direct(x, wf, us, bound, gn=gn, residual=res, bias=conv.bias, stats_groups=32)
+            ref = ref0 + conv.bias.double()[None, :, None, None] + res.double()
+            assert float(((y.double() - ref).abs() / sc).max()) <= 6e-7
+            yd = y.double().permute(0, 2, 3, 1).reshape(B, H * W, 32, 4)
+            st_y = torch.stack([yd.sum((1, 3)), (yd ** 2).sum((1, 3))], -1).flatten()
+            assert torch.allclose(st, st_y, rtol=2e-6, atol=1e-3), float((st - st_y).abs().max())
+            # (b) nothing fused
+            y2 = _lib.conv3x3_direct(x, wf, us, bound, gn=gn)
+            assert float(((y2.double() - ref0).abs() / sc).max()) <= 6e-7
+            # (c) no normalisation: the plain split of x
+            y3 = _lib.conv3x3_direct(x, wf, us, float(x.abs().max()), bias=conv.bias)
+            ref3 = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), 1, 1)
+            sc3 = torch.nn.functional.conv2d(x.double().abs(), conv.weight.double().abs(), None, 1, 1)
+            assert float(((y3.double() - ref3).abs() / sc3).max()) <= 6e-7
+
+
+def test_direct_conv3x3_rejects_shapes_it_does_not_tile():
+    from pit_hip import _lib
+
+    conv = torch.nn.Conv2d(128, 128, 3, 1, 1).to(DEV)
+    wf, us = _lib.conv3_weights_f16(conv.weight)
+    for shape in ((1, 128, 12, 32), (1, 128, 8, 48), (1, 120, 8, 32)):
+        x = torch.randn(*shape, device=DEV).contiguous(memory_format=torch.channels_last)
+        with pytest.raises(_lib.GqHipError):
+            _lib.conv3x3_direct(x, wf, us, 10.0)
+    with pytest.raises(_lib.GqHipError):
+        _lib.conv3_weights_f16(torch.randn(64, 128, 3, 3, device=DEV))
+    L = _lib.lib()
+    x = torch.randn(1, 128, 8, 32, device=DEV).contiguous(memory_format=torch.channels_last)
+    xs = torch.empty(1, 8, 8, 32, 2, 16, dtype=torch.float16, device=DEV)
+    y = torch.empty_like(x)
+    S = torch.cuda.current_stream().cuda_stream
+    assert L.conv3x3_n128_f16x3(xs.data_ptr(), wf.data_ptr(), None, None, y.data_ptr(), None, 1, 12, 32, 128, 32, 1.0, S) != 0
+    assert L.conv3x3_n128_f16x3(None, wf.data_ptr(), None, None, y.data_ptr(), None, 1, 8, 32, 128, 32, 1.0, S) != 0
+    assert L.conv3_split_gn_f16(x.data_ptr(), None, None, None, None, xs.data_ptr(), 1, 8, 32, 120, 1, 0.0, 0, 1.0, S) != 0
+    assert L.conv3x3_n128_f16x3(xs.data_ptr(), wf.data_ptr(), None, None, y.data_ptr(), None, 0, 8, 32, 128, 32, 1.0, S) == 0
+
+
+def test_resnet_block_direct_and_winograd_routes_agree():
+    """The 128-channel ResnetBlock with the direct convolution on / off (Winograd F(2x2,3x3) then): same function."""
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(5)
+    blk = U.ResnetBlock(128, 128, 0.0).eval().to(DEV).to(memory_format=torch.channels_last)
+    U.mark_winograd(blk)
+    x = torch.randn(2, 128, 16, 32, device=DEV).contiguous(memory_format=torch.channels_last)
+    outs = []
+    with torch.no_grad():
+        for flag in (True, False):
+            U.DIRECT_CONV_N128 = flag
+            outs.append(blk(x))
+        U.DIRECT_CONV_N128 = True
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[1].abs().max())

@@ -1,0 +1,238 @@
+// gq_conv3.h -- direct 3x3 convolution (stride 1, zero padding 1), Cin -> 128 channels, NHWC, as an implicit GEMM on
+// v_mfma_f32_32x32x16_f16: the 128-channel convolutions of the 256 x 256 level (pit/modules/unet.py:142, :149).
+//
+// Why not Winograd here: at 128 channels the Winograd route is HBM-bound -- V and M (2.25x / 4x the activation each)
+// cross HBM twice: 6.4 GB per F(4x4,3x3) convolution of a 16 x 256 x 256 x 128 tensor, 10.7 GB with F(2x2,3x3) -- and no
+// fusion removes that: the transformed weights of all tile positions (2.4 MB with their fp16 split) do not fit a CU.
+// The direct form reads the activation once and writes the result once (1.6 GB with the residual); its 2.25x / 4x more
+// multiplies run on the matrix cores, which have the room (928 GFLOP of fp16 MFMA work per convolution).
+//
+// Numerics: the same fp16 x 3 scheme as the Winograd GEMMs (gq_wino_gemm.h): activation and weight are two-term fp16
+// splits (h + l, 22 bits) of the scaled fp32 values, the three products h W_h + h W_l + l W_h accumulate in fp32 --
+// without Winograd's transform amplification.
+//
+// Two kernels:
+//   conv3_split_gn_kernel   x fp32 NHWC -> SiLU(GroupNorm(x + pre_bias)) * scale, split, as
+//                           Xs [B][Cin/16][H][W][2][16] fp16 (chunk-major: a block's 34-pixel patch row of one 16-channel
+//                           chunk is 2176 contiguous bytes);
+//   conv3x3_n128_f16x3_kernel  block = 8 x 32 output pixels x 128 output channels, 4 waves (wave = 4 rows x 64 channels:
+//                           eight 32 x 32 accumulator tiles).  Per 16-channel chunk the 10 x 34-pixel patch (h and l
+//                           planes, 21.8 KB) is staged in LDS, double buffered, 32 bytes per pixel and plane with the two
+//                           16-byte halves swapped on odd groups of 8 pixels (any 16 consecutive pixels then hit 64
+//                           different banks with ds_read_b128); each of the 9 taps is one MFMA k-step whose A operand is
+//                           the patch shifted by (dy, dx) -- 8 LDS reads for 24 MFMAs per wave.  The weights, laid out in
+//                           operand order ([chunk][tap][column tile][plane][lane][8]), come straight from L2 into
+//                           registers, one k-step ahead: a wave's load is 1 KB contiguous.
+//                           Epilogue: * mscale + bias (+ residual), store, GroupNorm statistics of the result.
+#pragma once
+#include "gq_common.h"
+#include "gq_wino_gemm.h"
+
+namespace gqhip {
+
+constexpr int kC3TH = 8, kC3TW = 32;                  // output tile of a block
+constexpr int kC3PH = kC3TH + 2, kC3PW = kC3TW + 2;   // staged patch: 10 x 34 pixels
+constexpr int kC3Pix = kC3PH * kC3PW;                 // 340
+constexpr int kC3Plane = kC3Pix * 32;                 // bytes per plane: 16 channels x 2 bytes per pixel
+constexpr int kC3Pieces = kC3Pix * 4;                 // 16-byte pieces per chunk (2 planes x 2 halves per pixel)
+constexpr int kC3Loads = (kC3Pieces + 255) / 256;     // per thread and chunk: 6
+
+struct Conv3Params {
+  const _Float16 *Xs;   // [B][nch][H][W][2][16]
+  const _Float16 *Wf;   // [nch][9][4][2][64][8]
+  const float *bias;    // [128] or null
+  const float *res;     // [B][H][W][128] or null
+  float *y;             // [B][H][W][128]
+  double *stats;        // [B][groups][2] (sum, sum of squares) or null
+  int H, W, nch, cpg;   // cpg: channels per GroupNorm group of the output
+  int tiles_x, tiles_y;
+  long ntiles;          // B * tiles_y * tiles_x
+  long tiles_per_xcd;   // ceil(ntiles / 8)
+  float mscale;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_n128_f16x3_kernel(const Conv3Params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * kC3Plane];
+  __shared__ double red[2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  // consecutive tiles (shared halos, same weights) on the same XCD: workgroups go round-robin over the 8 XCDs
+  const long tile = (long)(blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const int tx = (int)(tile % p.tiles_x);
+  const long t2 = tile / p.tiles_x;
+  const int ty = (int)(t2 % p.tiles_y);
+  const long b = t2 / p.tiles_y;
+  const int y0 = ty * kC3TH, x0 = tx * kC3TW, H = p.H, W = p.W;
+  if (tid < 128) red[tid] = 0.0;
+
+  // ---- loader bookkeeping: piece j = tid + 256 i -> (patch row, pixel, plane, half) ----
+  int goff[kC3Loads], loff[kC3Loads];
+  unsigned inb = 0;
+#pragma unroll
+  for (int i = 0; i < kC3Loads; ++i) {
+    int j = tid + 256 * i;
+    const bool live = j < kC3Pieces;
+    j = live ? j : kC3Pieces - 1;
+    const int R = j / (4 * kC3PW), rem = j % (4 * kC3PW), px = rem >> 2, part = rem & 3;
+    const int gy = y0 - 1 + R, gx = x0 - 1 + px;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    goff[i] = (cy * W + cx) * 32 + part * 8;                    // halfs, within one (image, chunk) plane pair
+    const int q = R * kC3PW + px;
+    loff[i] = live ? (part >> 1) * kC3Plane + q * 32 + 16 * ((part & 1) ^ ((q >> 3) & 1)) : -1;
+    inb |= (unsigned)(in ? 1 : 0) << i;
+  }
+  const long chunk_stride = (long)H * W * 32;
+  const _Float16 *xb = p.Xs + b * p.nch * chunk_stride;
+  f16x8 st[kC3Loads];
+  auto issue = [&](int chunk) {
+    const _Float16 *src = xb + chunk * chunk_stride;
+#pragma unroll
+    for (int i = 0; i < kC3Loads; ++i) st[i] = *reinterpret_cast<const f16x8 *>(src + goff[i]);
+  };
+  auto commit = [&](int buf) {
+    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < kC3Loads; ++i)
+      if (loff[i] >= 0) *reinterpret_cast<f16x8 *>(&sA[buf][loff[i]]) = ((inb >> i) & 1) ? st[i] : zero;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      acc[rr][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // weights of k-step ks = chunk * 9 + tap, column tiles 2 wn and 2 wn + 1, planes h / l: 4 operands of 1 KB per wave
+  const f16x8 *wsrc = reinterpret_cast<const f16x8 *>(p.Wf) + (2 * wn) * 128 + lane;
+  f16x8 bq[4], bn[4];   // [2 j + plane]
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+    const f16x8 *s = wsrc + (long)ks * 512;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = s[k * 64];
+  };
+  const int nks = p.nch * 9;
+  load_b(0, bq);
+  issue(0);
+  commit(0);
+  __syncthreads();
+
+  for (int chunk = 0; chunk < p.nch; ++chunk) {
+    if (chunk + 1 < p.nch) issue(chunk + 1);
+    const unsigned char *A = sA[chunk & 1];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const int ks = chunk * 9 + tap;
+      load_b(ks + 1 < nks ? ks + 1 : ks, bn);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int q = (4 * wm + rr + dy) * kC3PW + c + dx;
+        const int off = q * 32 + 16 * (h ^ ((q >> 3) & 1));
+        const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + off);
+        const f16x8 al = *reinterpret_cast<const f16x8 *>(A + kC3Plane + off);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
+          acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j + 1], acc[rr][j], 0, 0, 0);
+          acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[2 * j], acc[rr][j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bq[k] = bn[k];
+      __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting the LDS reads of later taps (spills otherwise)
+    }
+    if (chunk + 1 < p.nch) commit((chunk + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: register r of lane (c, h) = pixel x0 + (r & 3) + 8 (r >> 2) + 4 h of row y0 + 4 wm + rr, channel
+  //      (2 wn + j) * 32 + c: a store of one register is two 128-byte runs ----
+  float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+  const long pix0 = ((b * H + y0 + 4 * wm) * W + x0 + 4 * h) * 128;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = (2 * wn + j) * 32 + c;
+    const float pb = p.bias ? p.bias[n] : 0.f;
+    // the 64 residual values of this column tile in flight at once (the operand registers of the main loop are free
+    // now): two exposed memory latencies per block instead of eight
+    float rv[4][16];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        rv[rr][r] = p.res ? p.res[pix0 + ((long)rr * W + (r & 3) + 8 * (r >> 2)) * 128 + n] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[rr][j][r] * p.mscale + pb + rv[rr][r];
+        p.y[pix0 + ((long)rr * W + (r & 3) + 8 * (r >> 2)) * 128 + n] = v;
+        s[j] += v;
+        ss[j] += v * v;
+      }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = ((2 * wn + j) * 32 + c) / p.cpg;
+      atomicAdd(&red[2 * g], (double)s[j]);
+      atomicAdd(&red[2 * g + 1], (double)ss[j]);
+    }
+    __syncthreads();
+    const int groups = 128 / p.cpg;
+    if (tid < 2 * groups) atomicAdd(&p.stats[2 * (b * groups) + tid], red[tid]);
+  }
+}
+
+// SiLU(GroupNorm(x + pre_bias)) * scale as the chunk-major two-term fp16 split the convolution kernel stages.
+// thread -> (pixel, 4 channels): lanes = 4 channel quads of a chunk (fastest) x 16 pixels; a wave writes 2 x 512 bytes
+// interleaved into one contiguous KiB.  `stats` null: no normalisation (plain split of x * scale).
+template <int SILU>
+__global__ __launch_bounds__(256) void conv3_split_gn_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta,
+                                                             const float *__restrict__ pre_bias,
+                                                             const double *__restrict__ stats, _Float16 *__restrict__ Xs,
+                                                             long HW, int C, int cpg, double eps, float scale, long total) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const int nch = C / 16, groups = C / cpg;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int within = (int)(t & 3), pl = (int)((t >> 2) & 15);
+    const long u = t >> 6;
+    const int chunk = (int)(u % nch);
+    const long pix = (u / nch) * 16 + pl;          // over B * HW
+    const long b = pix / HW, pi = pix % HW;
+    const int c0 = chunk * 16 + within * 4;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * C + c0);
+    if (stats) {
+      const int g = c0 / cpg;
+      const double n = (double)cpg * (double)HW;
+      const double mean = stats[2 * (b * groups + g)] / n;
+      double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = 1.0 / sqrt(var + eps);
+      f32x4 a, sh;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double pbk = pre_bias ? (double)pre_bias[c0 + k] : 0.0;
+        a[k] = (float)(rstd * (double)gamma[c0 + k]);
+        sh[k] = (float)((double)beta[c0 + k] + (pbk - mean) * rstd * (double)gamma[c0 + k]);
+      }
+      v = gn_act<SILU>(v, a, sh);
+    }
+    v = v * scale;
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (_Float16)v[e];
+      lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    }
+    _Float16 *dst = Xs + (((b * nch + chunk) * HW + pi) * 2) * 16 + within * 4;
+    *reinterpret_cast<f16x4 *>(dst) = hi;
+    *reinterpret_cast<f16x4 *>(dst + 16) = lo;
+  }
+}
+
+}  // namespace gqhip

@@ -21,6 +21,7 @@
 #include "gq_scores.h"
 #include "gq_tail.h"
 #include "gq_wino_gemm.h"
+#include "gq_conv3.h"
 
 using namespace gqhip;
 
@@ -883,6 +884,51 @@ int wino_in_gn_nhwc_f16x2(const float *x, const float *gamma, const float *beta,
   if (tile != 2 && tile != 4) return GQHIP_ERR_INVALID_ARG;
   return wino_in_gn_impl(tile, 2, x, gamma, beta, pre_bias_or_null, stats, V2, B, H, W, C, groups, eps, apply_silu, scale,
                          stream);
+}
+
+int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *beta_or_null, const float *pre_bias_or_null,
+                       const double *stats_or_null, void *Xs, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                       double eps, int apply_silu, float scale, void *stream) {
+  if (B < 0 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || (H * W) % 16 != 0 || !(scale > 0.f)) return GQHIP_ERR_INVALID_ARG;
+  if (stats_or_null && (groups < 1 || C % groups != 0 || (C / groups) % 4 != 0 || !gamma_or_null || !beta_or_null))
+    return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !Xs) return GQHIP_ERR_INVALID_ARG;
+  const long total = (long)(B * H * W * (C / 4));
+  long blocks = (total + 255) / 256;
+  if (blocks > 32768) blocks = 32768;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int cpg = stats_or_null ? (int)(C / groups) : 4;
+  if (apply_silu)
+    hipLaunchKernelGGL(conv3_split_gn_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma_or_null, beta_or_null,
+                       pre_bias_or_null, stats_or_null, static_cast<_Float16 *>(Xs), (long)(H * W), (int)C, cpg, eps, scale, total);
+  else
+    hipLaunchKernelGGL(conv3_split_gn_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma_or_null, beta_or_null,
+                       pre_bias_or_null, stats_or_null, static_cast<_Float16 *>(Xs), (long)(H * W), (int)C, cpg, eps, scale, total);
+  return check_launch();
+}
+
+int conv3x3_n128_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
+                       double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t groups_out,
+                       float mscale, void *stream) {
+  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 16 || Cin % 16 != 0 || H * W > (1 << 24))
+    return GQHIP_ERR_INVALID_ARG;
+  if (stats_out_or_null && (groups_out < 1 || groups_out > 32 || 128 % groups_out != 0)) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!Xs || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
+    return check_launch();
+  Conv3Params cp{};
+  cp.Xs = static_cast<const _Float16 *>(Xs); cp.Wf = static_cast<const _Float16 *>(Wf);
+  cp.bias = bias_or_null; cp.res = res_or_null; cp.y = y; cp.stats = stats_out_or_null;
+  cp.H = (int)H; cp.W = (int)W; cp.nch = (int)(Cin / 16); cp.cpg = stats_out_or_null ? (int)(128 / groups_out) : 4;
+  cp.tiles_x = (int)(W / kC3TW); cp.tiles_y = (int)(H / kC3TH);
+  cp.ntiles = (long)B * cp.tiles_x * cp.tiles_y;
+  cp.tiles_per_xcd = (cp.ntiles + 7) / 8;
+  cp.mscale = mscale;
+  hipLaunchKernelGGL(conv3x3_n128_f16x3_kernel, dim3((unsigned)(8 * cp.tiles_per_xcd)), dim3(256), 0, st, cp);
+  return check_launch();
 }
 
 int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream) {

@@ -129,9 +129,53 @@ def _wino_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
             and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
 
 
+def _direct_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
+    """3x3 stride-1 padding-1 convolutions INTO 128 channels (the 256 x 256 level) run as libgqhip's direct fp16 x 3
+    convolution: at that width every Winograd route is HBM-bound on its transformed tensors (gq_conv3.h)."""
+    return (DIRECT_CONV_N128 and getattr(conv, "_gq_wino", False) and conv.out_channels == 128 and conv.in_channels % 16 == 0
+            and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and not x.is_contiguous())
+
+
+def _direct_weights(conv: nn.Conv2d):
+    """(Wf, u_scale) of conv3x3_direct, cached until the weight changes."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device)
+    if getattr(conv, "_direct_key", None) != key:
+        from .. import _lib
+
+        conv._direct_wf, conv._direct_us = _lib.conv3_weights_f16(w)
+        conv._direct_key = key
+    return conv._direct_wf, conv._direct_us
+
+
+def _gn_tuple(norm: nn.GroupNorm, x: torch.Tensor, pre_bias):
+    """The ``gn`` argument of wino_conv3x3 / conv3x3_direct: statistics left by the producer of x, or computed here."""
+    from .. import _lib
+
+    st = getattr(x, "_gn_stats", None)
+    if st is not None and pre_bias is None and st[1] == norm.num_groups:
+        stats = st[0]
+    else:
+        stats = _lib.gn_stats(x, norm.num_groups, pre_bias)
+    return (norm.weight, norm.bias, norm.num_groups, norm.eps, True, stats, pre_bias)
+
+
 def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None, want_stats: bool = False):
     """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  The GroupNorm(+SiLU) is applied inside the Winograd input
     transform, so the normalised tensor is never written (FUSED_WINO_GN / FUSED_WINO_GN_F4)."""
+    if _defer_ok(x, conv) and _direct_ok(conv, x) and _use_fused(x, norm):
+        from .. import _lib
+
+        if _lib.image_layout(x) == 1:
+            wf, us = _direct_weights(conv)
+            gn = _gn_tuple(norm, x, pre_bias)
+            if want_stats and FUSED_WINO_TAIL and _lib.gn_nhwc_ok(conv.out_channels, GN_GROUPS):
+                y, ostats = _lib.conv3x3_direct(x, wf, us, _gn_act_bound(norm, x), gn=gn, bias=conv.bias,
+                                                stats_groups=GN_GROUPS)
+                y._gn_stats = (ostats, GN_GROUPS)
+                return y, None
+            return _lib.conv3x3_direct(x, wf, us, _gn_act_bound(norm, x), gn=gn), conv.bias
     if _defer_ok(x, conv) and _wino_ok(conv, x) and _use_fused(x, norm):
         from .. import _lib
 
@@ -209,7 +253,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
-        for attr in ("_wino_key", "_wino_f16_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
+        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -260,6 +304,9 @@ WINOGRAD_F16X3 = True
 # 128 -> 128-channel Winograd GEMMs (256 x 256 level: HBM-bound at K = N = 128) through libgqhip's own kernel on the
 # [h | l] operand (4 instead of 6 bytes per element of V): same splits and products as the library route
 WINOGRAD_C128_GEMM = True
+# 3x3 convolutions into 128 channels (256 x 256 level) as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the
+# activation once and writes the result once where Winograd moves 6.4 / 10.7 GB of transformed tensors per convolution
+DIRECT_CONV_N128 = True
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
 # written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
 # since the loads of a tile are issued ahead of the activations (branch-free borders): 53.4 -> 50.8 ms / step.
@@ -322,6 +369,15 @@ class ResnetBlock(nn.Module):
                     and not xs.is_contiguous()):
                 from .. import _lib
 
+                if (_direct_ok(self.conv2, h) and _lib.gn_nhwc_ok(self.out_channels, GN_GROUPS)
+                        and _lib.image_layout(h) == 1):
+                    bias = self.conv2.bias if bs is None else self.conv2.bias + bs
+                    wf, us = _direct_weights(self.conv2)
+                    y, ostats = _lib.conv3x3_direct(h, wf, us, _gn_act_bound(self.norm2, h),
+                                                    gn=_gn_tuple(self.norm2, h, b1), residual=xs, bias=bias,
+                                                    stats_groups=GN_GROUPS)
+                    y._gn_stats = (ostats, GN_GROUPS)
+                    return y
                 if _lib.gn_nhwc_ok(self.out_channels, GN_GROUPS) and _lib.image_layout(h) == 1:
                     # conv2, its bias, the shortcut's constants, the residual add and the next GroupNorm's statistics
                     # in one output-transform pass (and, with F(4x4,3x3), norm2 + swish inside the input transform)
