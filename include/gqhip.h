@@ -226,6 +226,12 @@ int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *
 int conv3x3_n128_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
                        double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t groups_out,
                        float mscale, void *stream);
+/* The two steps above in ONE kernel (no Xs): x [B, H, W, Cin] fp32 is normalised, activated, scaled and split on its way
+ * into LDS.  stats_in [B, groups_in, 2] as gn_stats_f32; Cin % 32 == 0, Cin <= 512. */
+int conv3x3_n128_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                          const double *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
+                          const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B,
+                          int64_t H, int64_t W, int64_t Cin, int64_t groups_out, float mscale, void *stream);
 /* ... with the producer fused in (as wino_in_gn_nhwc_f32 / wino4_in_gn_nhwc_f32): the convolution's input is
  * SiLU(GroupNorm(x + pre_bias)), never written. */
 int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,

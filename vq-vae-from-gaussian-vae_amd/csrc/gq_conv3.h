@@ -33,9 +33,19 @@ namespace gqhip {
 constexpr int kC3TH = 8, kC3TW = 32;                  // output tile of a block
 constexpr int kC3PH = kC3TH + 2, kC3PW = kC3TW + 2;   // staged patch: 10 x 34 pixels
 constexpr int kC3Pix = kC3PH * kC3PW;                 // 340
-constexpr int kC3Plane = kC3Pix * 32;                 // bytes per plane: 16 channels x 2 bytes per pixel
+constexpr int kC3RS = 48;                             // LDS row stride in pixels (a multiple of 16: see conv3_lds_off)
+constexpr int kC3Plane = kC3PH * kC3RS * 32;          // bytes per plane: 16 channels x 2 bytes per pixel, 15 360
+constexpr int kC3Buf = 2 * kC3Plane;                  // h plane + l plane of one chunk
 constexpr int kC3Pieces = kC3Pix * 4;                 // 16-byte pieces per chunk (2 planes x 2 halves per pixel)
 constexpr int kC3Loads = (kC3Pieces + 255) / 256;     // per thread and chunk: 6
+
+// Byte offset of 16-byte half `half` of patch pixel (R, x) inside a plane: 32 bytes per pixel, the two halves swapped on
+// odd groups of 8 pixels of the row -- any 16 consecutive pixels of a row then cover all 64 banks with ds_read_b128.  The
+// row stride of 48 pixels keeps the swap a function of x alone, so a wave's read address for tap (dy, dx) is one of three
+// per-lane registers (dx) plus a compile-time constant (row, plane, buffer).
+__device__ __forceinline__ int conv3_lds_off(int R, int x, int half) {
+  return (R * kC3RS + x) * 32 + 16 * (half ^ ((x >> 3) & 1));
+}
 
 struct Conv3Params {
   const _Float16 *Xs;   // [B][nch][H][W][2][16]
@@ -51,114 +61,51 @@ struct Conv3Params {
   float mscale;
 };
 
-__global__ __launch_bounds__(256, 2) void conv3x3_n128_f16x3_kernel(const Conv3Params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * kC3Plane];
-  __shared__ double red[2 * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+// ---- pieces shared by the two convolution kernels ----
+struct Conv3Tile {
+  long b;
+  int y0, x0;
+};
+__device__ __forceinline__ bool conv3_tile(const Conv3Params &p, Conv3Tile &t) {
   // consecutive tiles (shared halos, same weights) on the same XCD: workgroups go round-robin over the 8 XCDs
   const long tile = (long)(blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
-  if (tile >= p.ntiles) return;
+  if (tile >= p.ntiles) return false;
   const int tx = (int)(tile % p.tiles_x);
   const long t2 = tile / p.tiles_x;
-  const int ty = (int)(t2 % p.tiles_y);
-  const long b = t2 / p.tiles_y;
-  const int y0 = ty * kC3TH, x0 = tx * kC3TW, H = p.H, W = p.W;
-  if (tid < 128) red[tid] = 0.0;
+  t.b = t2 / p.tiles_y;
+  t.y0 = (int)(t2 % p.tiles_y) * kC3TH;
+  t.x0 = tx * kC3TW;
+  return true;
+}
 
-  // ---- loader bookkeeping: piece j = tid + 256 i -> (patch row, pixel, plane, half) ----
-  int goff[kC3Loads], loff[kC3Loads];
-  unsigned inb = 0;
+// One tap (= one MFMA k-step of 16 input channels) of a wave: A operands = the staged patch shifted by (dy, dx).
+// `A` = buffer base + the lane's offset for this dx (conv3_lds_off(4 wm, c + dx, h)).
+__device__ __forceinline__ void conv3_tap(const unsigned char *A, int dy, const f16x8 (&bq)[4], f32x16 (&acc)[4][2]) {
 #pragma unroll
-  for (int i = 0; i < kC3Loads; ++i) {
-    int j = tid + 256 * i;
-    const bool live = j < kC3Pieces;
-    j = live ? j : kC3Pieces - 1;
-    const int R = j / (4 * kC3PW), rem = j % (4 * kC3PW), px = rem >> 2, part = rem & 3;
-    const int gy = y0 - 1 + R, gx = x0 - 1 + px;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-    goff[i] = (cy * W + cx) * 32 + part * 8;                    // halfs, within one (image, chunk) plane pair
-    const int q = R * kC3PW + px;
-    loff[i] = live ? (part >> 1) * kC3Plane + q * 32 + 16 * ((part & 1) ^ ((q >> 3) & 1)) : -1;
-    inb |= (unsigned)(in ? 1 : 0) << i;
-  }
-  const long chunk_stride = (long)H * W * 32;
-  const _Float16 *xb = p.Xs + b * p.nch * chunk_stride;
-  f16x8 st[kC3Loads];
-  auto issue = [&](int chunk) {
-    const _Float16 *src = xb + chunk * chunk_stride;
+  for (int rr = 0; rr < 4; ++rr) {
+    const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + (rr + dy) * kC3RS * 32);
+    const f16x8 al = *reinterpret_cast<const f16x8 *>(A + (rr + dy) * kC3RS * 32 + kC3Plane);
 #pragma unroll
-    for (int i = 0; i < kC3Loads; ++i) st[i] = *reinterpret_cast<const f16x8 *>(src + goff[i]);
-  };
-  auto commit = [&](int buf) {
-    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < kC3Loads; ++i)
-      if (loff[i] >= 0) *reinterpret_cast<f16x8 *>(&sA[buf][loff[i]]) = ((inb >> i) & 1) ? st[i] : zero;
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      acc[rr][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  // weights of k-step ks = chunk * 9 + tap, column tiles 2 wn and 2 wn + 1, planes h / l: 4 operands of 1 KB per wave
-  const f16x8 *wsrc = reinterpret_cast<const f16x8 *>(p.Wf) + (2 * wn) * 128 + lane;
-  f16x8 bq[4], bn[4];   // [2 j + plane]
-  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
-    const f16x8 *s = wsrc + (long)ks * 512;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dst[k] = s[k * 64];
-  };
-  const int nks = p.nch * 9;
-  load_b(0, bq);
-  issue(0);
-  commit(0);
-  __syncthreads();
-
-  for (int chunk = 0; chunk < p.nch; ++chunk) {
-    if (chunk + 1 < p.nch) issue(chunk + 1);
-    const unsigned char *A = sA[chunk & 1];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
-      const int ks = chunk * 9 + tap;
-      load_b(ks + 1 < nks ? ks + 1 : ks, bn);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int q = (4 * wm + rr + dy) * kC3PW + c + dx;
-        const int off = q * 32 + 16 * (h ^ ((q >> 3) & 1));
-        const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + off);
-        const f16x8 al = *reinterpret_cast<const f16x8 *>(A + kC3Plane + off);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
-          acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j + 1], acc[rr][j], 0, 0, 0);
-          acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[2 * j], acc[rr][j], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) bq[k] = bn[k];
-      __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting the LDS reads of later taps (spills otherwise)
+    for (int j = 0; j < 2; ++j) {
+      acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
+      acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j + 1], acc[rr][j], 0, 0, 0);
+      acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[2 * j], acc[rr][j], 0, 0, 0);
     }
-    if (chunk + 1 < p.nch) commit((chunk + 1) & 1);
-    __syncthreads();
   }
+}
 
-  // ---- epilogue: register r of lane (c, h) = pixel x0 + (r & 3) + 8 (r >> 2) + 4 h of row y0 + 4 wm + rr, channel
-  //      (2 wn + j) * 32 + c: a store of one register is two 128-byte runs ----
+// Epilogue: register r of lane (c, h) = pixel x0 + (r & 3) + 8 (r >> 2) + 4 h of row y0 + 4 wm + rr, channel
+// (2 wn + j) * 32 + c: a store of one register is two 128-byte runs.
+__device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3Tile &t, const f32x16 (&acc)[4][2], double *red,
+                                               int tid, int wm, int wn, int c, int h) {
   float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
-  const long pix0 = ((b * H + y0 + 4 * wm) * W + x0 + 4 * h) * 128;
+  const int W = p.W;
+  const long pix0 = ((t.b * p.H + t.y0 + 4 * wm) * W + t.x0 + 4 * h) * 128;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = (2 * wn + j) * 32 + c;
     const float pb = p.bias ? p.bias[n] : 0.f;
-    // the 64 residual values of this column tile in flight at once (the operand registers of the main loop are free
-    // now): two exposed memory latencies per block instead of eight
-    float rv[4][16];
+    float rv[4][16];   // the 64 residual values of this column tile in flight at once
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -183,8 +130,233 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n128_f16x3_kernel(const Conv3P
     }
     __syncthreads();
     const int groups = 128 / p.cpg;
-    if (tid < 2 * groups) atomicAdd(&p.stats[2 * (b * groups) + tid], red[tid]);
+    if (tid < 2 * groups) atomicAdd(&p.stats[2 * (t.b * groups) + tid], red[tid]);
   }
+}
+
+#define GQ_C3_ZERO_ACC(acc)                                                                                         \
+  _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[rr][j] =       \
+      f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
+
+// ---- input = the pre-split tensor Xs (conv3_split_gn_kernel) ----
+__global__ __launch_bounds__(256, 2) void conv3x3_n128_f16x3_kernel(const Conv3Params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2][kC3Buf];
+  __shared__ double red[2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  Conv3Tile t;
+  if (!conv3_tile(p, t)) return;
+  const int H = p.H, W = p.W;
+  if (tid < 128) red[tid] = 0.0;
+
+  // loader bookkeeping: piece j = tid + 256 i -> (patch row, pixel, plane, half)
+  int goff[kC3Loads], loff[kC3Loads];
+  unsigned inb = 0;
+#pragma unroll
+  for (int i = 0; i < kC3Loads; ++i) {
+    int j = tid + 256 * i;
+    const bool live = j < kC3Pieces;
+    j = live ? j : kC3Pieces - 1;
+    const int R = j / (4 * kC3PW), rem = j % (4 * kC3PW), px = rem >> 2, part = rem & 3;
+    const int gy = t.y0 - 1 + R, gx = t.x0 - 1 + px;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    goff[i] = (cy * W + cx) * 32 + part * 8;                    // halfs, within one (image, chunk) plane pair
+    loff[i] = live ? (part >> 1) * kC3Plane + conv3_lds_off(R, px, part & 1) : -1;
+    inb |= (unsigned)(in ? 1 : 0) << i;
+  }
+  int aoff[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) aoff[dx] = conv3_lds_off(4 * wm, c + dx, h);
+  const long chunk_stride = (long)H * W * 32;
+  const _Float16 *xb = p.Xs + t.b * p.nch * chunk_stride;
+  f16x8 st[kC3Loads];
+  auto issue = [&](int chunk) {
+    const _Float16 *src = xb + chunk * chunk_stride;
+#pragma unroll
+    for (int i = 0; i < kC3Loads; ++i) st[i] = *reinterpret_cast<const f16x8 *>(src + goff[i]);
+  };
+  auto commit = [&](int buf) {
+    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < kC3Loads; ++i)
+      if (loff[i] >= 0) *reinterpret_cast<f16x8 *>(&sA[buf][loff[i]]) = ((inb >> i) & 1) ? st[i] : zero;
+  };
+
+  f32x16 acc[4][2];
+  GQ_C3_ZERO_ACC(acc);
+  // weights of k-step ks = chunk * 9 + tap, column tiles 2 wn and 2 wn + 1, planes h / l: 4 operands of 1 KB per wave
+  const f16x8 *wsrc = reinterpret_cast<const f16x8 *>(p.Wf) + (2 * wn) * 128 + lane;
+  f16x8 bq[4], bn[4];   // [2 j + plane]
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+    const f16x8 *s = wsrc + (long)ks * 512;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = s[k * 64];
+  };
+  const int nks = p.nch * 9;
+  load_b(0, bq);
+  issue(0);
+  commit(0);
+  __syncthreads();
+
+  for (int chunk = 0; chunk < p.nch; ++chunk) {
+    if (chunk + 1 < p.nch) issue(chunk + 1);
+    const unsigned char *A = sA[chunk & 1];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ks = chunk * 9 + tap;
+      load_b(ks + 1 < nks ? ks + 1 : ks, bn);
+      conv3_tap(A + aoff[tap % 3], tap / 3, bq, acc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bq[k] = bn[k];
+      __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting the LDS reads of later taps (spills otherwise)
+    }
+    if (chunk + 1 < p.nch) commit((chunk + 1) & 1);
+    __syncthreads();
+  }
+  conv3_epilogue(p, t, acc, red, tid, wm, wn, c, h);
+}
+
+// ---- input = the fp32 tensor itself: SiLU(GroupNorm(x + pre_bias)) * scale and the fp16 split happen on the way into
+//      LDS (no Xs: saves writing and re-reading 4 bytes per element and a launch).  A chunk is 16 channels = 64 bytes of
+//      a pixel's fp32 row; thread -> 4 channels of up to 6 patch pixels (the same channel quad for all of them), the
+//      folded scale / shift of the image's channels sit in LDS.  The conversions of chunk k + 1 are spread over taps 3..8
+//      of chunk k (one piece per tap: in the MFMAs' shadow, and late enough for the loads issued at tap 0 to have landed).
+struct Conv3GnParams {
+  Conv3Params c;
+  const float *x;          // [B][H][W][cin]
+  const float *gamma, *beta, *pre_bias;
+  const double *stats_in;  // [B][groups_in][2]
+  int cin, cpg_in;
+  double eps;
+  float scale;
+};
+
+template <int SILU>
+__global__ __launch_bounds__(256, 2) void conv3x3_n128_gn_f16x3_kernel(const Conv3GnParams pp) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const Conv3Params &p = pp.c;
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kC3Buf];
+  __shared__ double red[2 * 64];
+  __shared__ __attribute__((aligned(16))) float sAff[2][512];   // folded scale, shift per input channel (cin <= 512)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  Conv3Tile t;
+  if (!conv3_tile(p, t)) return;
+  const int H = p.H, W = p.W, cin = pp.cin;
+  if (tid < 128) red[tid] = 0.0;
+  {
+    const int groups = cin / pp.cpg_in;
+    const double n = (double)pp.cpg_in * (double)H * (double)W;
+    for (int ch = tid; ch < cin; ch += 256) {
+      const int g = ch / pp.cpg_in;
+      const double mean = pp.stats_in[2 * (t.b * groups + g)] / n;
+      double var = pp.stats_in[2 * (t.b * groups + g) + 1] / n - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = 1.0 / sqrt(var + pp.eps);
+      const double pbk = pp.pre_bias ? (double)pp.pre_bias[ch] : 0.0;
+      sAff[0][ch] = (float)(rstd * (double)pp.gamma[ch]);
+      sAff[1][ch] = (float)((double)pp.beta[ch] + (pbk - mean) * rstd * (double)pp.gamma[ch]);
+    }
+  }
+  // loader bookkeeping: thread -> channel quad w = tid & 3 of patch pixels q = (tid >> 2) + 64 i (i < 6, q < 340)
+  const int w = tid & 3, qs = tid >> 2;
+  int goff[kC3Loads];
+  unsigned inb = 0;
+#pragma unroll
+  for (int i = 0; i < kC3Loads; ++i) {
+    int q = qs + 64 * i;
+    q = q < kC3Pix ? q : kC3Pix - 1;
+    const int R = q / kC3PW, px = q % kC3PW;
+    const int gy = t.y0 - 1 + R, gx = t.x0 - 1 + px;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    goff[i] = (cy * W + cx) * cin + 4 * w;                      // floats, within the image
+    inb |= (unsigned)(in ? 1 : 0) << i;
+  }
+  const float *xb = pp.x + t.b * (long)H * W * cin;
+  f32x4 st[kC3Loads];
+  auto issue = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < kC3Loads; ++i) st[i] = *reinterpret_cast<const f32x4 *>(xb + goff[i] + chunk * 16);
+  };
+  auto convert = [&](int i, int chunk, int buf) {    // piece i of the chunk in `st` -> activated, scaled, split, into LDS
+    const int q = qs + 64 * i;
+    if (q >= kC3Pix) return;
+    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(&sAff[0][chunk * 16 + 4 * w]);
+    const f32x4 sh4 = *reinterpret_cast<const f32x4 *>(&sAff[1][chunk * 16 + 4 * w]);
+    const f32x4 v = gn_act<SILU>(st[i], a4, sh4) * (((inb >> i) & 1) ? pp.scale : 0.f);
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (_Float16)v[e];
+      lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    }
+    const int off = buf * kC3Buf + conv3_lds_off(q / kC3PW, q % kC3PW, w >> 1) + 8 * (w & 1);
+    *reinterpret_cast<f16x4 *>(&sA[off]) = hi;
+    *reinterpret_cast<f16x4 *>(&sA[off + kC3Plane]) = lo;
+  };
+
+  f32x16 acc[4][2];
+  GQ_C3_ZERO_ACC(acc);
+  int aoff[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) aoff[dx] = conv3_lds_off(4 * wm, c + dx, h);
+  // weights of k-step ks = chunk * 9 + tap, column tiles 2 wn and 2 wn + 1, planes h / l: 4 operands of 1 KB per wave;
+  // uniform base + lane offset, two register sets used alternately (18 taps per loop trip: no copies)
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + (2 * wn) * 128 * 16;
+  const int wl = lane * 16;
+  f16x8 b0[4], b1[4];
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+    const unsigned char *s = wbase + (long)ks * (512 * 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
+  };
+  const int nks = p.nch * 9;
+  load_b(0, b0);
+  issue(0);
+  __syncthreads();          // sAff
+#pragma unroll
+  for (int i = 0; i < kC3Loads; ++i) convert(i, 0, 0);
+  __syncthreads();
+
+  // two chunks per trip (nch is even): chunk cp from buffer 0 while cp + 1 is converted into buffer 1, then cp + 1 from
+  // buffer 1 while cp + 2 goes into buffer 0
+  for (int cp = 0; cp < p.nch; cp += 2) {
+    issue(cp + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ks = cp * 9 + tap;
+      if (tap & 1) {
+        load_b(ks + 1, b0);
+        conv3_tap(sA + aoff[tap % 3], tap / 3, b1, acc);
+      } else {
+        load_b(ks + 1, b1);
+        conv3_tap(sA + aoff[tap % 3], tap / 3, b0, acc);
+      }
+      if (tap >= 9 - kC3Loads) convert(tap - (9 - kC3Loads), cp + 1, 1);
+      __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting the LDS reads of later taps (spills otherwise)
+    }
+    __syncthreads();
+    const bool more = cp + 2 < p.nch;
+    if (more) issue(cp + 2);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ks = cp * 9 + 9 + tap;
+      const int kn = ks + 1 < nks ? ks + 1 : ks;
+      if (tap & 1) {
+        load_b(kn, b1);
+        conv3_tap(sA + kC3Buf + aoff[tap % 3], tap / 3, b0, acc);
+      } else {
+        load_b(kn, b0);
+        conv3_tap(sA + kC3Buf + aoff[tap % 3], tap / 3, b1, acc);
+      }
+      if (tap >= 9 - kC3Loads && more) convert(tap - (9 - kC3Loads), cp + 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  conv3_epilogue(p, t, acc, red, tid, wm, wn, c, h);
 }
 
 // SiLU(GroupNorm(x + pre_bias)) * scale as the chunk-major two-term fp16 split the convolution kernel stages.

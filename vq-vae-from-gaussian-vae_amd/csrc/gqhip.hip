@@ -931,6 +931,36 @@ int conv3x3_n128_f16x3(const void *Xs, const void *Wf, const float *bias_or_null
   return check_launch();
 }
 
+int conv3x3_n128_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                          const double *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
+                          const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B,
+                          int64_t H, int64_t W, int64_t Cin, int64_t groups_out, float mscale, void *stream) {
+  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 32 || Cin % 32 != 0 || Cin > 512 ||
+      H * W > (1 << 22) || groups_in < 1 || Cin % groups_in != 0 || !(scale > 0.f))
+    return GQHIP_ERR_INVALID_ARG;
+  if (stats_out_or_null && (groups_out < 1 || groups_out > 32 || 128 % groups_out != 0)) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !gamma || !beta || !stats_in || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
+    return check_launch();
+  Conv3GnParams gp{};
+  Conv3Params &cp = gp.c;
+  cp.Xs = nullptr; cp.Wf = static_cast<const _Float16 *>(Wf);
+  cp.bias = bias_or_null; cp.res = res_or_null; cp.y = y; cp.stats = stats_out_or_null;
+  cp.H = (int)H; cp.W = (int)W; cp.nch = (int)(Cin / 16); cp.cpg = stats_out_or_null ? (int)(128 / groups_out) : 4;
+  cp.tiles_x = (int)(W / kC3TW); cp.tiles_y = (int)(H / kC3TH);
+  cp.ntiles = (long)B * cp.tiles_x * cp.tiles_y;
+  cp.tiles_per_xcd = (cp.ntiles + 7) / 8;
+  cp.mscale = mscale;
+  gp.x = x; gp.gamma = gamma; gp.beta = beta; gp.pre_bias = pre_bias_or_null; gp.stats_in = stats_in;
+  gp.cin = (int)Cin; gp.cpg_in = (int)(Cin / groups_in); gp.eps = eps; gp.scale = scale;
+  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd));
+  if (apply_silu) hipLaunchKernelGGL(conv3x3_n128_gn_f16x3_kernel<1>, grid, dim3(256), 0, st, gp);
+  else hipLaunchKernelGGL(conv3x3_n128_gn_f16x3_kernel<0>, grid, dim3(256), 0, st, gp);
+  return check_launch();
+}
+
 int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream) {
   if (B < 0 || H < 2 || W < 2 || H % 2 || W % 2 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "conv3_split_gn_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                            ctypes.c_int, ctypes.c_float, _vp]),
     "conv3x3_n128_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
+    "conv3x3_n128_gn_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp,
+                                              _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
@@ -498,6 +500,9 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
     return y
 
 
+DIRECT_CONV_FUSED_SPLIT = True   # conv3x3_direct: GroupNorm + split inside the convolution kernel (A/B switch)
+
+
 def conv3_weights_f16(weight):
     """Operand-order fp16 x 3 weights of a [128, Cin, 3, 3] kernel for conv3x3_direct: (Wf [Cin/16, 9, 4, 2, 64, 8] fp16,
     u_scale) -- see gqhip.h:conv3x3_n128_f16x3."""
@@ -529,6 +534,15 @@ def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None
     v_scale = min(2.0 ** math.floor(math.log2(32768.0 / max(float(x_bound), 1e-30))), 2.0 ** 14)
     L = lib()
     with torch.cuda.device(x.device):
+        if gn is not None and C <= 512 and C % 32 == 0 and DIRECT_CONV_FUSED_SPLIT:
+            gamma, beta, groups, eps, silu, stats, pre_bias = gn
+            y = torch.empty((B, 128, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+            _check(L.conv3x3_n128_gn_f16x3(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(),
+                                           groups, float(eps), 1 if silu else 0, float(v_scale), wf.data_ptr(), _ptr(bias),
+                                           _ptr(residual), y.data_ptr(), _ptr(ostats), B, H, W, C, max(stats_groups, 1),
+                                           1.0 / (v_scale * u_scale), _stream()), "conv3x3_n128_gn_f16x3")
+            return (y, ostats) if stats_groups else y
         xs = torch.empty((B, C // 16, H, W, 2, 16), dtype=torch.float16, device=x.device)
         if gn is not None:
             gamma, beta, groups, eps, silu, stats, pre_bias = gn
