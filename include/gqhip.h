@@ -208,30 +208,32 @@ int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W
 int wino_in_nhwc_f16x2(const float *x, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
                        void *stream);
 int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, int64_t tiles, void *stream);
-/* Direct 3x3 convolution (stride 1, zero padding 1) Cin -> 128 channels, channels_last, as an implicit GEMM on the fp16
- * matrix cores with the fp16 x 3 scheme above (two-term splits of both operands, three products, fp32 accumulation):
- * the 128-channel convolutions of the 256 x 256 level (reference pit/modules/unet.py:142, :149), where every Winograd
- * route is HBM-bound on V and M.  Replaces F.conv2d(swish(norm(x)), w, None, 1, 1) + bias + residual (unet.py:140-153).
- *   conv3_split_gn_f16   Xs [B, Cin/16, H, W, 2, 16] fp16 = (h, l) of SiLU(GroupNorm(x + pre_bias)) * scale (stats as
- *                        gn_stats_f32 / the statistics outputs below; stats NULL: plain split of x * scale); H*W % 16 == 0,
- *                        Cin % 16 == 0; `scale` a power of two with |activation| * scale <= 32768;
- *   conv3x3_n128_f16x3   y [B, H, W, 128] = (Xs (*) Wf) * mscale + bias (+ res); stats_out (optional): GroupNorm
- *                        statistics of y, [B, groups_out, 2] fp64.  H % 8 == 0, W % 32 == 0.
- *                        Wf [Cin/16, 9, 4, 2, 64, 8] fp16: operand-order weights -- chunk, tap ky*3+kx, column tile,
+/* Direct 3x3 convolution (stride 1, zero padding 1) Cin -> Cout (128 or 256) channels, channels_last, as an implicit
+ * GEMM on the fp16 matrix cores with the fp16 x 3 scheme above (two-term splits of both operands, three products, fp32
+ * accumulation): the convolutions of the 256 x 256 level and the encoder's 128 x 128 level (reference pit/modules/unet.py:142,
+ * :149), where the Winograd routes are HBM-bound on V and M.  Replaces F.conv2d(swish(norm(x)), w, None, 1, 1) + bias +
+ * residual (unet.py:140-153).
+ *   conv3x3_gn_f16x3     y [B, H, W, Cout] = (SiLU(GroupNorm(x + pre_bias)) (*) w) + bias (+ res) in ONE kernel: x [B, H, W, Cin]
+ *                        fp32 is normalised, activated, scaled and split on its way into LDS.  stats_in [B, groups_in, 2] as
+ *                        gn_stats_f32 / the statistics outputs of this library; stats_out (optional): GroupNorm statistics of
+ *                        y, [B, groups_out, 2] fp64 (4 | Cout / groups_out | 128).  H % 8 == 0, W % 32 == 0, Cin % 32 == 0,
+ *                        Cin <= 512.  `scale`: a power of two with |activation| * scale <= 32768; mscale = 1 / (scale * u_scale).
+ *                        Wf [Cin/16, 9, Cout/32, 2, 64, 8] fp16: operand-order weights -- chunk, tap ky*3+kx, column tile,
  *                        plane (h, l of w * u_scale), lane (n = 32 tile + lane%32, k-half lane/32), 8 input channels
- *                        16 chunk + 8 (lane/32) + e.  mscale = 1 / (scale * u_scale). */
+ *                        16 chunk + 8 (lane/32) + e.
+ *   conv3_split_gn_f16 + conv3x3_f16x3   the same in two steps, for inputs without a GroupNorm (stats NULL: plain split of
+ *                        x * scale) or Cin % 32 != 0: Xs [B, Cin/16, H, W, 2, 16] fp16 = (h, l) of the activated, scaled
+ *                        tensor; H*W % 16 == 0, Cin % 16 == 0. */
+int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                     const double *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
+                     const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B,
+                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, float mscale, void *stream);
 int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *beta_or_null, const float *pre_bias_or_null,
                        const double *stats_or_null, void *Xs, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                        double eps, int apply_silu, float scale, void *stream);
-int conv3x3_n128_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
-                       double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t groups_out,
-                       float mscale, void *stream);
-/* The two steps above in ONE kernel (no Xs): x [B, H, W, Cin] fp32 is normalised, activated, scaled and split on its way
- * into LDS.  stats_in [B, groups_in, 2] as gn_stats_f32; Cin % 32 == 0, Cin <= 512. */
-int conv3x3_n128_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                          const double *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
-                          const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B,
-                          int64_t H, int64_t W, int64_t Cin, int64_t groups_out, float mscale, void *stream);
+int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
+                  double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
+                  float mscale, void *stream);
 /* ... with the producer fused in (as wino_in_gn_nhwc_f32 / wino4_in_gn_nhwc_f32): the convolution's input is
  * SiLU(GroupNorm(x + pre_bias)), never written. */
 int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,

@@ -507,13 +507,14 @@ def test_direct_conv3x3_matches_fp64_convolution():
     from pit_hip.modules import unet as U
 
     torch.manual_seed(21)
-    for cin, (B, H, W) in ((128, (2, 16, 64)), (256, (1, 8, 32)), (16, (3, 24, 32))):
-        conv = torch.nn.Conv2d(cin, 128, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+    for cin, cout, (B, H, W) in ((128, 128, (2, 16, 64)), (256, 128, (1, 8, 32)), (16, 128, (3, 24, 32)), (128, 256, (2, 16, 32)),
+                                 (256, 256, (1, 8, 64))):
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
         norm = torch.nn.GroupNorm(4 if cin == 16 else 32, cin, eps=1e-6).to(DEV)
         with torch.no_grad():
             norm.weight.normal_(); norm.bias.normal_()
             x = (2 * torch.randn(B, cin, H, W, device=DEV)).contiguous(memory_format=torch.channels_last)
-            res = torch.randn(B, 128, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+            res = torch.randn(B, cout, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
             wf, us = _lib.conv3_weights_f16(conv.weight)
             groups = norm.num_groups
             stats = _lib.gn_stats(x, groups)
@@ -526,7 +527,7 @@ def test_direct_conv3x3_matches_fp64_convolution():
             y, st = _lib.conv3x3_direct(x, wf, us, bound, gn=gn, residual=res, bias=conv.bias, stats_groups=32)
             ref = ref0 + conv.bias.double()[None, :, None, None] + res.double()
             assert float(((y.double() - ref).abs() / sc).max()) <= 6e-7
-            yd = y.double().permute(0, 2, 3, 1).reshape(B, H * W, 32, 4)
+            yd = y.double().permute(0, 2, 3, 1).reshape(B, H * W, 32, cout // 32)
             st_y = torch.stack([yd.sum((1, 3)), (yd ** 2).sum((1, 3))], -1).flatten()
             assert torch.allclose(st, st_y, rtol=2e-6, atol=1e-3), float((st - st_y).abs().max())
             # (b) nothing fused
@@ -555,10 +556,11 @@ def test_direct_conv3x3_rejects_shapes_it_does_not_tile():
     xs = torch.empty(1, 8, 8, 32, 2, 16, dtype=torch.float16, device=DEV)
     y = torch.empty_like(x)
     S = torch.cuda.current_stream().cuda_stream
-    assert L.conv3x3_n128_f16x3(xs.data_ptr(), wf.data_ptr(), None, None, y.data_ptr(), None, 1, 12, 32, 128, 32, 1.0, S) != 0
-    assert L.conv3x3_n128_f16x3(None, wf.data_ptr(), None, None, y.data_ptr(), None, 1, 8, 32, 128, 32, 1.0, S) != 0
+    assert L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), None, None, y.data_ptr(), None, 1, 12, 32, 128, 128, 32, 1.0, S) != 0
+    assert L.conv3x3_f16x3(None, wf.data_ptr(), None, None, y.data_ptr(), None, 1, 8, 32, 128, 128, 32, 1.0, S) != 0
     assert L.conv3_split_gn_f16(x.data_ptr(), None, None, None, None, xs.data_ptr(), 1, 8, 32, 120, 1, 0.0, 0, 1.0, S) != 0
-    assert L.conv3x3_n128_f16x3(xs.data_ptr(), wf.data_ptr(), None, None, y.data_ptr(), None, 0, 8, 32, 128, 32, 1.0, S) == 0
+    assert L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), None, None, y.data_ptr(), None, 0, 8, 32, 128, 128, 32, 1.0, S) == 0
+    assert L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), None, None, y.data_ptr(), None, 1, 8, 32, 128, 192, 32, 1.0, S) != 0
 
 
 def test_resnet_block_direct_and_winograd_routes_agree():
@@ -572,7 +574,7 @@ def test_resnet_block_direct_and_winograd_routes_agree():
     outs = []
     with torch.no_grad():
         for flag in (True, False):
-            U.DIRECT_CONV_N128 = flag
+            U.DIRECT_CONV = flag
             outs.append(blk(x))
-        U.DIRECT_CONV_N128 = True
+        U.DIRECT_CONV = True
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[1].abs().max())

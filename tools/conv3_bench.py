@@ -1,4 +1,4 @@
-"""The direct fp16 x 3 3x3 convolution (libgqhip conv3x3_n128_f16x3) alone: correctness against fp64 and against the
+"""The direct fp16 x 3 3x3 convolution (libgqhip conv3x3_gn_f16x3 / conv3x3_f16x3) alone: correctness against fp64 and against the
 Winograd route, time of the split pass and of the convolution kernel at the 256 x 256 level's shapes."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,12 +43,12 @@ for cin in (128, 256):
         print(f"Cin {cin}: direct max err {err:.2e} of sum|x||w| (Winograd F2 route {errw:.2e}); max abs diff {float((y.double()-ref).abs().max()):.2e}; "
               f"stats rel err {float(((st - st_ref).abs() / st_ref.abs().clamp_min(1)).max()):.1e}", flush=True)
 # ---- timing at the bench shapes ----
-for (cin, H) in ((128, 256), (256, 256), (128, 128)):
-    conv = torch.nn.Conv2d(cin, 128, 3, 1, 1).to(dev).to(memory_format=torch.channels_last)
+for (cin, cout, H) in ((128, 128, 256), (256, 128, 256), (256, 256, 128), (128, 256, 128)):
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(dev).to(memory_format=torch.channels_last)
     norm = torch.nn.GroupNorm(32, cin, eps=1e-6).to(dev)
     with torch.no_grad():
         x = torch.randn(16, cin, H, H, device=dev).contiguous(memory_format=torch.channels_last)
-        res = torch.randn(16, 128, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+        res = torch.randn(16, cout, H, H, device=dev).contiguous(memory_format=torch.channels_last)
         wf, us = _lib.conv3_weights_f16(conv.weight)
         stats = _lib.gn_stats(x, 32)
         gn = (norm.weight, norm.bias, 32, 1e-6, True, stats, None)
@@ -59,12 +59,12 @@ for (cin, H) in ((128, 256), (256, 256), (128, 128)):
         xs = torch.empty((16, cin // 16, H, H, 2, 16), dtype=torch.float16, device=dev)
         t_split = timed(lambda: _lib._check(L.conv3_split_gn_f16(x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), None,
                         stats.data_ptr(), xs.data_ptr(), 16, H, H, cin, 32, 1e-6, 1, 64.0, S), "split"))
-        flops = 2.0 * 16 * H * H * 9 * cin * 128 * 3
+        flops = 2.0 * 16 * H * H * 9 * cin * cout * 3
         y = torch.empty_like(res); ost = torch.empty(2 * 16 * 32, dtype=torch.float64, device=dev)
         def run_conv(r, st_):
-            _lib._check(L.conv3x3_n128_f16x3(xs.data_ptr(), wf.data_ptr(), conv_b, r, y.data_ptr(), st_, 16, H, H, cin, 32,
+            _lib._check(L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), conv_b, r, y.data_ptr(), st_, 16, H, H, cin, cout, 32,
                                              1.0, S), "conv")
-        cb = torch.zeros(128, device=dev); conv_b = cb.data_ptr()
+        cb = torch.zeros(cout, device=dev); conv_b = cb.data_ptr()
         t_full = timed(lambda: run_conv(res.data_ptr(), ost.data_ptr()))
         t_nores = timed(lambda: run_conv(None, ost.data_ptr()))
         t_bare = timed(lambda: run_conv(None, None))
@@ -73,7 +73,7 @@ for (cin, H) in ((128, 256), (256, 256), (128, 128)):
         yf, _ = _lib.conv3x3_direct(x, wf, us, bound, gn=gn, residual=res, bias=conv.bias, stats_groups=32)
         _lib.DIRECT_CONV_FUSED_SPLIT = False
         y2, _ = _lib.conv3x3_direct(x, wf, us, bound, gn=gn, residual=res, bias=conv.bias, stats_groups=32)
-        print(f"Cin {cin} {H}^2: ONE kernel (GroupNorm + split fused) {t_fused:.0f} us = {flops/t_fused/1e6:.0f} TFLOP/s executed; "
+        print(f"{cin}->{cout} {H}^2: ONE kernel (GroupNorm + split fused) {t_fused:.0f} us = {flops/t_fused/1e6:.0f} TFLOP/s executed; "
               f"max diff vs two kernels {float((yf - y2).abs().max()):.1e}")
-        print(f"Cin {cin} {H}^2: split {t_split:.0f} us; conv + residual + stats {t_full:.0f} us = {flops/t_full/1e6:.0f} TFLOP/s executed; "
+        print(f"{cin}->{cout} {H}^2: split {t_split:.0f} us; conv + residual + stats {t_full:.0f} us = {flops/t_full/1e6:.0f} TFLOP/s executed; "
               f"without residual {t_nores:.0f}; without statistics too {t_bare:.0f}; split + conv {t_all:.0f} us", flush=True)

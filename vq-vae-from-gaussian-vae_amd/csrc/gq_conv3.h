@@ -1,5 +1,5 @@
-// gq_conv3.h -- direct 3x3 convolution (stride 1, zero padding 1), Cin -> 128 channels, NHWC, as an implicit GEMM on
-// v_mfma_f32_32x32x16_f16: the 128-channel convolutions of the 256 x 256 level (pit/modules/unet.py:142, :149).
+// gq_conv3.h -- direct 3x3 convolution (stride 1, zero padding 1), Cin -> Cout (a multiple of 128) channels, NHWC, as an
+// implicit GEMM on v_mfma_f32_32x32x16_f16: the convolutions of the two widest levels (pit/modules/unet.py:142, :149).
 //
 // Why not Winograd here: at 128 channels the Winograd route is HBM-bound -- V and M (2.25x / 4x the activation each)
 // cross HBM twice: 6.4 GB per F(4x4,3x3) convolution of a 16 x 256 x 256 x 128 tensor, 10.7 GB with F(2x2,3x3) -- and no
@@ -15,7 +15,7 @@
 //   conv3_split_gn_kernel   x fp32 NHWC -> SiLU(GroupNorm(x + pre_bias)) * scale, split, as
 //                           Xs [B][Cin/16][H][W][2][16] fp16 (chunk-major: a block's 34-pixel patch row of one 16-channel
 //                           chunk is 2176 contiguous bytes);
-//   conv3x3_n128_f16x3_kernel  block = 8 x 32 output pixels x 128 output channels, 4 waves (wave = 4 rows x 64 channels:
+//   conv3x3_f16x3_kernel  block = 8 x 32 output pixels x 128 output channels, 4 waves (wave = 4 rows x 64 channels:
 //                           eight 32 x 32 accumulator tiles).  Per 16-channel chunk the 10 x 34-pixel patch (h and l
 //                           planes, 21.8 KB) is staged in LDS, double buffered, 32 bytes per pixel and plane with the two
 //                           16-byte halves swapped on odd groups of 8 pixels (any 16 consecutive pixels then hit 64
@@ -49,12 +49,13 @@ __device__ __forceinline__ int conv3_lds_off(int R, int x, int half) {
 
 struct Conv3Params {
   const _Float16 *Xs;   // [B][nch][H][W][2][16]
-  const _Float16 *Wf;   // [nch][9][4][2][64][8]
-  const float *bias;    // [128] or null
-  const float *res;     // [B][H][W][128] or null
-  float *y;             // [B][H][W][128]
+  const _Float16 *Wf;   // [nch][9][cout/32][2][64][8]
+  const float *bias;    // [cout] or null
+  const float *res;     // [B][H][W][cout] or null
+  float *y;             // [B][H][W][cout]
   double *stats;        // [B][groups][2] (sum, sum of squares) or null
   int H, W, nch, cpg;   // cpg: channels per GroupNorm group of the output
+  int cout, nnb;        // output channels (a multiple of 128), 128-channel blocks per tile (cout / 128)
   int tiles_x, tiles_y;
   long ntiles;          // B * tiles_y * tiles_x
   long tiles_per_xcd;   // ceil(ntiles / 8)
@@ -64,11 +65,14 @@ struct Conv3Params {
 // ---- pieces shared by the two convolution kernels ----
 struct Conv3Tile {
   long b;
-  int y0, x0;
+  int y0, x0, nb;   // nb: which 128 output channels
 };
 __device__ __forceinline__ bool conv3_tile(const Conv3Params &p, Conv3Tile &t) {
-  // consecutive tiles (shared halos, same weights) on the same XCD: workgroups go round-robin over the 8 XCDs
-  const long tile = (long)(blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+  // workgroups go round-robin over the 8 XCDs: consecutive tiles (shared halos, same weights) and the 128-channel blocks
+  // of one tile (same input patch) land on the same XCD, next to each other in dispatch order
+  const long k = blockIdx.x >> 3;
+  t.nb = (int)(k % p.nnb);
+  const long tile = (long)(blockIdx.x & 7) * p.tiles_per_xcd + k / p.nnb;
   if (tile >= p.ntiles) return false;
   const int tx = (int)(tile % p.tiles_x);
   const long t2 = tile / p.tiles_x;
@@ -96,27 +100,31 @@ __device__ __forceinline__ void conv3_tap(const unsigned char *A, int dy, const 
 
 // Epilogue: register r of lane (c, h) = pixel x0 + (r & 3) + 8 (r >> 2) + 4 h of row y0 + 4 wm + rr, channel
 // (2 wn + j) * 32 + c: a store of one register is two 128-byte runs.
+// COUT is a template parameter: with a run-time channel stride none of the 128 loads / 128 stores of a lane has a constant
+// offset and hipcc materialises their addresses (~300 bytes of scratch per lane).
+template <int COUT>
 __device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3Tile &t, const f32x16 (&acc)[4][2], double *red,
                                                int tid, int wm, int wn, int c, int h) {
   float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
   const int W = p.W;
-  const long pix0 = ((t.b * p.H + t.y0 + 4 * wm) * W + t.x0 + 4 * h) * 128;
+  constexpr int cout = COUT;
+  const long pix0 = ((t.b * p.H + t.y0 + 4 * wm) * W + t.x0 + 4 * h) * cout + t.nb * 128;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = (2 * wn + j) * 32 + c;
-    const float pb = p.bias ? p.bias[n] : 0.f;
+    const float pb = p.bias ? p.bias[t.nb * 128 + n] : 0.f;
     float rv[4][16];   // the 64 residual values of this column tile in flight at once
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        rv[rr][r] = p.res ? p.res[pix0 + ((long)rr * W + (r & 3) + 8 * (r >> 2)) * 128 + n] : 0.f;
+        rv[rr][r] = p.res ? p.res[pix0 + ((long)rr * W + (r & 3) + 8 * (r >> 2)) * cout + n] : 0.f;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[rr][j][r] * p.mscale + pb + rv[rr][r];
-        p.y[pix0 + ((long)rr * W + (r & 3) + 8 * (r >> 2)) * 128 + n] = v;
+        p.y[pix0 + ((long)rr * W + (r & 3) + 8 * (r >> 2)) * cout + n] = v;
         s[j] += v;
         ss[j] += v * v;
       }
@@ -124,13 +132,13 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3
   if (p.stats) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int g = ((2 * wn + j) * 32 + c) / p.cpg;
+      const int g = ((2 * wn + j) * 32 + c) / p.cpg;      // group within this block's 128 channels
       atomicAdd(&red[2 * g], (double)s[j]);
       atomicAdd(&red[2 * g + 1], (double)ss[j]);
     }
     __syncthreads();
-    const int groups = 128 / p.cpg;
-    if (tid < 2 * groups) atomicAdd(&p.stats[2 * (t.b * groups) + tid], red[tid]);
+    const int gpb = 128 / p.cpg, groups = cout / p.cpg;    // groups per block, per image
+    if (tid < 2 * gpb) atomicAdd(&p.stats[2 * (t.b * groups + t.nb * gpb) + tid], red[tid]);
   }
 }
 
@@ -139,7 +147,8 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3
       f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
 
 // ---- input = the pre-split tensor Xs (conv3_split_gn_kernel) ----
-__global__ __launch_bounds__(256, 2) void conv3x3_n128_f16x3_kernel(const Conv3Params p) {
+template <int COUT>
+__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const Conv3Params p) {
   __shared__ __attribute__((aligned(16))) unsigned char sA[2][kC3Buf];
   __shared__ double red[2 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,10 +195,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n128_f16x3_kernel(const Conv3P
   f32x16 acc[4][2];
   GQ_C3_ZERO_ACC(acc);
   // weights of k-step ks = chunk * 9 + tap, column tiles 2 wn and 2 wn + 1, planes h / l: 4 operands of 1 KB per wave
-  const f16x8 *wsrc = reinterpret_cast<const f16x8 *>(p.Wf) + (2 * wn) * 128 + lane;
+  const f16x8 *wsrc = reinterpret_cast<const f16x8 *>(p.Wf) + (4 * t.nb + 2 * wn) * 128 + lane;
   f16x8 bq[4], bn[4];   // [2 j + plane]
   auto load_b = [&](int ks, f16x8 (&dst)[4]) {
-    const f16x8 *s = wsrc + (long)ks * 512;
+    const f16x8 *s = wsrc + (long)ks * (p.nnb * 512);
 #pragma unroll
     for (int k = 0; k < 4; ++k) dst[k] = s[k * 64];
   };
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n128_f16x3_kernel(const Conv3P
     if (chunk + 1 < p.nch) commit((chunk + 1) & 1);
     __syncthreads();
   }
-  conv3_epilogue(p, t, acc, red, tid, wm, wn, c, h);
+  conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
 }
 
 // ---- input = the fp32 tensor itself: SiLU(GroupNorm(x + pre_bias)) * scale and the fp16 split happen on the way into
@@ -232,8 +241,8 @@ struct Conv3GnParams {
   float scale;
 };
 
-template <int SILU>
-__global__ __launch_bounds__(256, 2) void conv3x3_n128_gn_f16x3_kernel(const Conv3GnParams pp) {
+template <int SILU, int COUT>
+__global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnParams pp) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   const Conv3Params &p = pp.c;
   __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kC3Buf];
@@ -304,11 +313,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n128_gn_f16x3_kernel(const Con
   for (int dx = 0; dx < 3; ++dx) aoff[dx] = conv3_lds_off(4 * wm, c + dx, h);
   // weights of k-step ks = chunk * 9 + tap, column tiles 2 wn and 2 wn + 1, planes h / l: 4 operands of 1 KB per wave;
   // uniform base + lane offset, two register sets used alternately (18 taps per loop trip: no copies)
-  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + (2 * wn) * 128 * 16;
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + (4 * t.nb + 2 * wn) * 128 * 16;
   const int wl = lane * 16;
+  const long wstep = (long)p.nnb * (512 * 16);   // bytes per k-step
   f16x8 b0[4], b1[4];
   auto load_b = [&](int ks, f16x8 (&dst)[4]) {
-    const unsigned char *s = wbase + (long)ks * (512 * 16);
+    const unsigned char *s = wbase + ks * wstep;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
   };
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n128_gn_f16x3_kernel(const Con
     }
     __syncthreads();
   }
-  conv3_epilogue(p, t, acc, red, tid, wm, wn, c, h);
+  conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
 }
 
 // SiLU(GroupNorm(x + pre_bias)) * scale as the chunk-major two-term fp16 split the convolution kernel stages.

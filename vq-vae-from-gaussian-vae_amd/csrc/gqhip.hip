@@ -908,37 +908,54 @@ int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *
   return check_launch();
 }
 
-int conv3x3_n128_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
-                       double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t groups_out,
-                       float mscale, void *stream) {
-  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 16 || Cin % 16 != 0 || H * W > (1 << 24))
+// GroupNorm statistics of the output: every group must lie inside one block's 128 channels, 4 | channels per group
+static bool conv3_groups_ok(int64_t Cout, int64_t groups_out) {
+  if (groups_out < 1 || Cout % groups_out != 0) return false;
+  const int64_t cpg = Cout / groups_out;
+  return cpg % 4 == 0 && 128 % cpg == 0;
+}
+
+static void conv3_fill(Conv3Params &cp, const void *Wf, const float *bias, const float *res, float *y, double *stats, int64_t B,
+                       int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, float mscale) {
+  cp.Wf = static_cast<const _Float16 *>(Wf);
+  cp.bias = bias; cp.res = res; cp.y = y; cp.stats = stats;
+  cp.H = (int)H; cp.W = (int)W; cp.nch = (int)(Cin / 16); cp.cpg = stats ? (int)(Cout / groups_out) : 4;
+  cp.cout = (int)Cout; cp.nnb = (int)(Cout / 128);
+  cp.tiles_x = (int)(W / kC3TW); cp.tiles_y = (int)(H / kC3TH);
+  cp.ntiles = (long)B * cp.tiles_x * cp.tiles_y;
+  cp.tiles_per_xcd = (cp.ntiles + 7) / 8;
+  cp.mscale = mscale;
+}
+
+int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
+                  double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
+                  float mscale, void *stream) {
+  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 16 || Cin % 16 != 0 || (Cout != 128 && Cout != 256) ||
+      H * W > (1 << 22))
     return GQHIP_ERR_INVALID_ARG;
-  if (stats_out_or_null && (groups_out < 1 || groups_out > 32 || 128 % groups_out != 0)) return GQHIP_ERR_INVALID_ARG;
+  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!Xs || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
     return check_launch();
   Conv3Params cp{};
-  cp.Xs = static_cast<const _Float16 *>(Xs); cp.Wf = static_cast<const _Float16 *>(Wf);
-  cp.bias = bias_or_null; cp.res = res_or_null; cp.y = y; cp.stats = stats_out_or_null;
-  cp.H = (int)H; cp.W = (int)W; cp.nch = (int)(Cin / 16); cp.cpg = stats_out_or_null ? (int)(128 / groups_out) : 4;
-  cp.tiles_x = (int)(W / kC3TW); cp.tiles_y = (int)(H / kC3TH);
-  cp.ntiles = (long)B * cp.tiles_x * cp.tiles_y;
-  cp.tiles_per_xcd = (cp.ntiles + 7) / 8;
-  cp.mscale = mscale;
-  hipLaunchKernelGGL(conv3x3_n128_f16x3_kernel, dim3((unsigned)(8 * cp.tiles_per_xcd)), dim3(256), 0, st, cp);
+  cp.Xs = static_cast<const _Float16 *>(Xs);
+  conv3_fill(cp, Wf, bias_or_null, res_or_null, y, stats_out_or_null, B, H, W, Cin, Cout, groups_out, mscale);
+  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
+  if (Cout == 128) hipLaunchKernelGGL(conv3x3_f16x3_kernel<128>, grid, dim3(256), 0, st, cp);
+  else hipLaunchKernelGGL(conv3x3_f16x3_kernel<256>, grid, dim3(256), 0, st, cp);
   return check_launch();
 }
 
-int conv3x3_n128_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                          const double *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
-                          const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B,
-                          int64_t H, int64_t W, int64_t Cin, int64_t groups_out, float mscale, void *stream) {
-  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 32 || Cin % 32 != 0 || Cin > 512 ||
+int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                     const double *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
+                     const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B,
+                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, float mscale, void *stream) {
+  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 32 || Cin % 32 != 0 || Cin > 512 || (Cout != 128 && Cout != 256) ||
       H * W > (1 << 22) || groups_in < 1 || Cin % groups_in != 0 || !(scale > 0.f))
     return GQHIP_ERR_INVALID_ARG;
-  if (stats_out_or_null && (groups_out < 1 || groups_out > 32 || 128 % groups_out != 0)) return GQHIP_ERR_INVALID_ARG;
+  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;
   if (!x || !gamma || !beta || !stats_in || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -946,18 +963,18 @@ int conv3x3_n128_gn_f16x3(const float *x, const float *gamma, const float *beta,
     return check_launch();
   Conv3GnParams gp{};
   Conv3Params &cp = gp.c;
-  cp.Xs = nullptr; cp.Wf = static_cast<const _Float16 *>(Wf);
-  cp.bias = bias_or_null; cp.res = res_or_null; cp.y = y; cp.stats = stats_out_or_null;
-  cp.H = (int)H; cp.W = (int)W; cp.nch = (int)(Cin / 16); cp.cpg = stats_out_or_null ? (int)(128 / groups_out) : 4;
-  cp.tiles_x = (int)(W / kC3TW); cp.tiles_y = (int)(H / kC3TH);
-  cp.ntiles = (long)B * cp.tiles_x * cp.tiles_y;
-  cp.tiles_per_xcd = (cp.ntiles + 7) / 8;
-  cp.mscale = mscale;
+  cp.Xs = nullptr;
+  conv3_fill(cp, Wf, bias_or_null, res_or_null, y, stats_out_or_null, B, H, W, Cin, Cout, groups_out, mscale);
   gp.x = x; gp.gamma = gamma; gp.beta = beta; gp.pre_bias = pre_bias_or_null; gp.stats_in = stats_in;
   gp.cin = (int)Cin; gp.cpg_in = (int)(Cin / groups_in); gp.eps = eps; gp.scale = scale;
-  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd));
-  if (apply_silu) hipLaunchKernelGGL(conv3x3_n128_gn_f16x3_kernel<1>, grid, dim3(256), 0, st, gp);
-  else hipLaunchKernelGGL(conv3x3_n128_gn_f16x3_kernel<0>, grid, dim3(256), 0, st, gp);
+  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
+  if (Cout == 128) {
+    if (apply_silu) hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<1, 128>), grid, dim3(256), 0, st, gp);
+    else hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<0, 128>), grid, dim3(256), 0, st, gp);
+  } else {
+    if (apply_silu) hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<1, 256>), grid, dim3(256), 0, st, gp);
+    else hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<0, 256>), grid, dim3(256), 0, st, gp);
+  }
   return check_launch();
 }
 

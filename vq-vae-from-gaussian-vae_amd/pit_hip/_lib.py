@@ -66,9 +66,9 @@ _SIGNATURES = {
                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
     "conv3_split_gn_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                            ctypes.c_int, ctypes.c_float, _vp]),
-    "conv3x3_n128_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
-    "conv3x3_n128_gn_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp,
-                                              _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
+    "conv3x3_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
+    "conv3x3_gn_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp,
+                                         _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
@@ -504,11 +504,11 @@ DIRECT_CONV_FUSED_SPLIT = True   # conv3x3_direct: GroupNorm + split inside the 
 
 
 def conv3_weights_f16(weight):
-    """Operand-order fp16 x 3 weights of a [128, Cin, 3, 3] kernel for conv3x3_direct: (Wf [Cin/16, 9, 4, 2, 64, 8] fp16,
-    u_scale) -- see gqhip.h:conv3x3_n128_f16x3."""
+    """Operand-order fp16 x 3 weights of a [Cout, Cin, 3, 3] kernel for conv3x3_direct: (Wf [Cin/16, 9, Cout/32, 2, 64, 8]
+    fp16, u_scale) -- see gqhip.h:conv3x3_gn_f16x3."""
     cout, cin = weight.shape[0], weight.shape[1]
-    if cout != 128 or cin % 16 or tuple(weight.shape[2:]) != (3, 3):
-        raise GqHipError("conv3_weights_f16 needs a [128, Cin % 16 == 0, 3, 3] kernel")
+    if cout not in (128, 256) or cin % 16 or tuple(weight.shape[2:]) != (3, 3):
+        raise GqHipError("conv3_weights_f16 needs a [128 | 256, Cin % 16 == 0, 3, 3] kernel")
     w = weight.detach().float()
     amax = float(w.abs().max())
     u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0
@@ -517,31 +517,35 @@ def conv3_weights_f16(weight):
     lo = (ws - hi.float()).half()
     planes = torch.stack([hi, lo], 0)                                    # [plane, n, k, ky, kx]
     # n = 32 tile + c, k = 16 chunk + 8 h + e  ->  [chunk, ky, kx, tile, plane, h, c, e]
-    p7 = planes.reshape(2, 4, 32, cin // 16, 2, 8, 3, 3).permute(3, 6, 7, 1, 0, 4, 2, 5)
-    return p7.reshape(cin // 16, 9, 4, 2, 64, 8).contiguous(), u_scale
+    p7 = planes.reshape(2, cout // 32, 32, cin // 16, 2, 8, 3, 3).permute(3, 6, 7, 1, 0, 4, 2, 5)
+    return p7.reshape(cin // 16, 9, cout // 32, 2, 64, 8).contiguous(), u_scale
 
 
 def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None, bias=None, stats_groups: int = 0):
-    """3x3 stride-1 padding-1 convolution Cin -> 128 of a channels_last fp32 HIP tensor as a direct (implicit GEMM) fp16 x 3
-    convolution (gqhip.h:conv3x3_n128_f16x3); ``wf, u_scale`` from conv3_weights_f16, ``x_bound`` >= max|conv input|,
-    ``gn`` as in wino_conv3x3 (then x_bound bounds the activated tensor).  Returns y, or (y, statistics of y) when
-    ``stats_groups`` > 0 (+ bias, + residual in either case)."""
+    """3x3 stride-1 padding-1 convolution Cin -> Cout (128 or 256) of a channels_last fp32 HIP tensor as a direct
+    (implicit GEMM) fp16 x 3 convolution (gqhip.h:conv3x3_gn_f16x3); ``wf, u_scale`` from conv3_weights_f16, ``x_bound`` >=
+    max|conv input|, ``gn`` as in wino_conv3x3 (then x_bound bounds the activated tensor).  Returns y, or (y, statistics of
+    y) when ``stats_groups`` > 0 (+ bias, + residual in either case)."""
     if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 16 or x.shape[2] % 8 or x.shape[3] % 32:
         raise GqHipError("conv3x3_direct needs a dense channels_last fp32 HIP tensor, C % 16 == 0, H % 8 == 0, W % 32 == 0")
     B, C, H, W = x.shape
-    if residual is not None and (image_layout(residual) != 1 or tuple(residual.shape) != (B, 128, H, W)):
-        raise GqHipError("conv3x3_direct: residual must be channels_last [B, 128, H, W]")
+    cout = wf.shape[2] * 32
+    if wf.shape[0] * 16 != C:
+        raise GqHipError("conv3x3_direct: weights are for %d input channels, x has %d" % (wf.shape[0] * 16, C))
+    if residual is not None and (image_layout(residual) != 1 or tuple(residual.shape) != (B, cout, H, W)):
+        raise GqHipError("conv3x3_direct: residual must be channels_last [B, Cout, H, W]")
     v_scale = min(2.0 ** math.floor(math.log2(32768.0 / max(float(x_bound), 1e-30))), 2.0 ** 14)
     L = lib()
     with torch.cuda.device(x.device):
+        y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+        mscale = 1.0 / (v_scale * u_scale)
         if gn is not None and C <= 512 and C % 32 == 0 and DIRECT_CONV_FUSED_SPLIT:
             gamma, beta, groups, eps, silu, stats, pre_bias = gn
-            y = torch.empty((B, 128, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-            ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
-            _check(L.conv3x3_n128_gn_f16x3(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(),
-                                           groups, float(eps), 1 if silu else 0, float(v_scale), wf.data_ptr(), _ptr(bias),
-                                           _ptr(residual), y.data_ptr(), _ptr(ostats), B, H, W, C, max(stats_groups, 1),
-                                           1.0 / (v_scale * u_scale), _stream()), "conv3x3_n128_gn_f16x3")
+            _check(L.conv3x3_gn_f16x3(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(),
+                                      groups, float(eps), 1 if silu else 0, float(v_scale), wf.data_ptr(), _ptr(bias),
+                                      _ptr(residual), y.data_ptr(), _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1),
+                                      mscale, _stream()), "conv3x3_gn_f16x3")
             return (y, ostats) if stats_groups else y
         xs = torch.empty((B, C // 16, H, W, 2, 16), dtype=torch.float16, device=x.device)
         if gn is not None:
@@ -552,10 +556,8 @@ def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None
         else:
             _check(L.conv3_split_gn_f16(x.data_ptr(), None, None, None, None, xs.data_ptr(), B, H, W, C, 1, 0.0, 0,
                                         float(v_scale), _stream()), "conv3_split_gn_f16")
-        y = torch.empty((B, 128, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
-        _check(L.conv3x3_n128_f16x3(xs.data_ptr(), wf.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), _ptr(ostats),
-                                    B, H, W, C, max(stats_groups, 1), 1.0 / (v_scale * u_scale), _stream()), "conv3x3_n128_f16x3")
+        _check(L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), _ptr(ostats),
+                               B, H, W, C, cout, max(stats_groups, 1), mscale, _stream()), "conv3x3_f16x3")
     return (y, ostats) if stats_groups else y
 
 

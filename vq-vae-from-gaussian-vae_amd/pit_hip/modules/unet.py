@@ -130,11 +130,15 @@ def _wino_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
 
 
 def _direct_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
-    """3x3 stride-1 padding-1 convolutions INTO 128 channels (the 256 x 256 level) run as libgqhip's direct fp16 x 3
-    convolution: at that width every Winograd route is HBM-bound on its transformed tensors (gq_conv3.h)."""
-    return (DIRECT_CONV_N128 and getattr(conv, "_gq_wino", False) and conv.out_channels == 128 and conv.in_channels % 16 == 0
-            and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 and x.is_contiguous(memory_format=torch.channels_last)
-            and not x.is_contiguous())
+    """3x3 stride-1 padding-1 convolutions of the widest levels run as libgqhip's direct fp16 x 3 convolution: into 128
+    channels (the 256 x 256 level), where every Winograd route is HBM-bound on its transformed tensors, and -- for modules
+    marked F(2x2,3x3)-only (the encoder) -- into 256 channels too (gq_conv3.h)."""
+    if not (DIRECT_CONV and getattr(conv, "_gq_wino", False) and conv.in_channels % 16 == 0 and x.shape[2] % 8 == 0
+            and x.shape[3] % 32 == 0 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+        return False
+    if conv.out_channels == 128:
+        return True
+    return conv.out_channels == 256 and not (WINOGRAD_F4 and getattr(conv, "_gq_wino4", False))
 
 
 def _direct_weights(conv: nn.Conv2d):
@@ -304,9 +308,10 @@ WINOGRAD_F16X3 = True
 # 128 -> 128-channel Winograd GEMMs (256 x 256 level: HBM-bound at K = N = 128) through libgqhip's own kernel on the
 # [h | l] operand (4 instead of 6 bytes per element of V): same splits and products as the library route
 WINOGRAD_C128_GEMM = True
-# 3x3 convolutions into 128 channels (256 x 256 level) as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the
-# activation once and writes the result once where Winograd moves 6.4 / 10.7 GB of transformed tensors per convolution
-DIRECT_CONV_N128 = True
+# 3x3 convolutions into 128 channels (256 x 256 level) -- and, where the alternative is F(2x2,3x3) (the encoder), into 256
+# channels (128 x 128 level) -- as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the activation once and
+# writes the result once where Winograd moves 6.4 / 10.7 GB of transformed tensors per convolution at 256 x 256
+DIRECT_CONV = True
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
 # written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
 # since the loads of a tile are issued ahead of the activations (branch-free borders): 53.4 -> 50.8 ms / step.
