@@ -2,7 +2,7 @@
 # PMC passes on the direct convolution kernels (tools/conv3_bench.py).  Run on the GPU box.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY" "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_MISC SQ_INSTS_SALU SQ_ACTIVE_INST_SCA"; do
   tag=$(echo "$C" | tr ' ' '_' | cut -c1-30)
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_c3/$tag -- python3 $R/tools/conv3_bench.py > $R/gpurun_out/pmc_c3_stdout.txt 2>&1
 done
@@ -13,7 +13,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(R+"/gpurun_out/pmc_c3/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        if "conv3" in k:
+        if "conv3x3_gn" in k:
             acc[k[:50]+"|grid "+r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in sorted(acc.items()):
     print(k)

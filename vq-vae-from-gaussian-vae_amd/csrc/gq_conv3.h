@@ -67,12 +67,12 @@ struct Conv3Tile {
   long b;
   int y0, x0, nb;   // nb: which 128 output channels
 };
-__device__ __forceinline__ bool conv3_tile(const Conv3Params &p, Conv3Tile &t) {
+__device__ __forceinline__ bool conv3_tile(const Conv3Params &p, Conv3Tile &t, long vb = blockIdx.x) {
   // workgroups go round-robin over the 8 XCDs: consecutive tiles (shared halos, same weights) and the 128-channel blocks
   // of one tile (same input patch) land on the same XCD, next to each other in dispatch order
-  const long k = blockIdx.x >> 3;
+  const long k = vb >> 3;
   t.nb = (int)(k % p.nnb);
-  const long tile = (long)(blockIdx.x & 7) * p.tiles_per_xcd + k / p.nnb;
+  const long tile = (long)(vb & 7) * p.tiles_per_xcd + k / p.nnb;
   if (tile >= p.ntiles) return false;
   const int tx = (int)(tile % p.tiles_x);
   const long t2 = tile / p.tiles_x;
@@ -368,6 +368,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
   }
   conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
 }
+
+// Measured alternative (round 2, removed): a wave-specialised persistent variant -- one block of 8 waves per CU, waves 0-3
+// only multiplying (every operand from LDS, next tap's operands read under the current tap's MFMAs), waves 4-7 only
+// loading (x two chunks ahead, converted into the patch buffer; the weights three steps ahead into an LDS ring), one
+// barrier per three taps.  Bit-identical results; 1003-1056 us against 854-873 us for the kernel above at 16 x 256 x 256 x
+// 128.  Decomposition (loaders or multipliers reduced to their barriers): multipliers alone 808 us, of which 263 us is the
+// epilogue that nothing overlaps in that design (the main loop itself ran at 1.7 PFLOP/s); loaders alone 737 us -- four
+// loader waves per CU are as slow as the multipliers; both together 1032 us.  Two combined-role blocks per CU overlap one
+// block's epilogue with the other's main loop for free, which is worth more here than the cleaner instruction streams.
 
 // SiLU(GroupNorm(x + pre_bias)) * scale as the chunk-major two-term fp16 split the convolution kernel stages.
 // thread -> (pixel, 4 channels): lanes = 4 channel quads of a chunk (fastest) x 16 pixels; a wave writes 2 x 512 bytes

@@ -138,7 +138,7 @@ def _direct_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
         return False
     if conv.out_channels == 128:
         return True
-    return conv.out_channels == 256 and not (WINOGRAD_F4 and getattr(conv, "_gq_wino4", False))
+    return conv.out_channels == 256 and (DIRECT_CONV_OVER_F4 or not (WINOGRAD_F4 and getattr(conv, "_gq_wino4", False)))
 
 
 def _direct_weights(conv: nn.Conv2d):
@@ -312,6 +312,7 @@ WINOGRAD_C128_GEMM = True
 # channels (128 x 128 level) -- as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the activation once and
 # writes the result once where Winograd moves 6.4 / 10.7 GB of transformed tensors per convolution at 256 x 256
 DIRECT_CONV = True
+DIRECT_CONV_OVER_F4 = False   # ... also where the alternative is F(4x4,3x3) (decoder, 256 channels at 128 x 128): A/B switch
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
 # written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
 # since the loads of a tile are issued ahead of the activations (branch-free borders): 53.4 -> 50.8 ms / step.
