@@ -234,6 +234,13 @@ int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *
 int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
                   double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
                   float mscale, void *stream);
+/* 3x3 convolution (stride 1, zero padding 1) into 1..4 channels with GroupNorm (+ SiLU) of the input fused in, fp32 FMAs:
+ * the decoder's conv_out(swish(norm_out(h))) (reference pit/modules/unet.py:585-587).  x [B, H, W, Cin] fp32, w_ohwi
+ * [Cout, 3, 3, Cin] fp32, y [B, H, W, Cout].  H % 16 == 0, W % 16 == 0, Cin % 32 == 0, Cin <= 512. */
+int conv3x3_gn_small_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                         const double *stats_in, int64_t groups_in, double eps, int apply_silu, const float *w_ohwi,
+                         const float *bias_or_null, float *y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                         void *stream);
 /* ... with the producer fused in (as wino_in_gn_nhwc_f32 / wino4_in_gn_nhwc_f32): the convolution's input is
  * SiLU(GroupNorm(x + pre_bias)), never written. */
 int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,

@@ -578,3 +578,50 @@ def test_resnet_block_direct_and_winograd_routes_agree():
             outs.append(blk(x))
         U.DIRECT_CONV = True
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[1].abs().max())
+
+
+def test_conv_out_kernel_matches_fp64_reference():
+    """conv3x3(SiLU(GroupNorm(x))) into 1..4 channels in one kernel (the decoder's conv_out) vs torch fp64."""
+    from pit_hip import _lib
+
+    torch.manual_seed(31)
+    for cin, cout, (B, H, W), silu in ((128, 3, (2, 32, 48), True), (128, 4, (1, 16, 16), False), (256, 1, (1, 16, 32), True)):
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
+        norm = torch.nn.GroupNorm(32, cin, eps=1e-6).to(DEV)
+        with torch.no_grad():
+            norm.weight.normal_(); norm.bias.normal_()
+            x = (2 * torch.randn(B, cin, H, W, device=DEV)).contiguous(memory_format=torch.channels_last)
+            pb = torch.randn(cin, device=DEV)
+            for pre in (None, pb):
+                stats = _lib.gn_stats(x, 32, pre)
+                y = _lib.conv3x3_gn_small(x, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias,
+                                          (norm.weight, norm.bias, 32, 1e-6, silu, stats, pre))
+                xin = x.double() if pre is None else x.double() + pre.double()[None, :, None, None]
+                xn = torch.nn.functional.group_norm(xin, 32, norm.weight.double(), norm.bias.double(), 1e-6)
+                if silu:
+                    xn = xn * torch.sigmoid(xn)
+                ref = torch.nn.functional.conv2d(xn, conv.weight.double(), conv.bias.double(), 1, 1)
+                sc = torch.nn.functional.conv2d(xn.abs(), conv.weight.double().abs(), None, 1, 1) + 1.0
+                assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+                assert float(((y.double() - ref).abs() / sc).max()) <= 2e-6, (cin, cout, pre is not None)
+    with pytest.raises(_lib.GqHipError):
+        _lib.conv3x3_gn_small(torch.randn(1, 128, 8, 16, device=DEV).contiguous(memory_format=torch.channels_last),
+                              torch.randn(3, 3, 3, 128, device=DEV), None, (norm.weight, norm.bias, 32, 1e-6, True, stats, None))
+
+
+def test_decoder_with_and_without_fused_conv_out_agree():
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(2)
+    cfg = dict(ch=128, out_ch=3, in_channels=3, resolution=64, z_channels=16, double_z=True, ch_mult=[1, 2, 4, 4],
+               num_res_blocks=2, attn_resolutions=[8], dropout=0.0)
+    dec = U.Decoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
+    U.mark_winograd(dec, f4=True)
+    z = torch.randn(2, 16, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last)
+    outs = []
+    with torch.no_grad():
+        for flag in (True, False):
+            U.FUSED_CONV_OUT = flag
+            outs.append(dec(z))
+    U.FUSED_CONV_OUT = True
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * max(1.0, float(outs[1].abs().max()))

@@ -426,4 +426,82 @@ __global__ __launch_bounds__(256) void conv3_split_gn_kernel(const float *__rest
   }
 }
 
+// ---- 3x3 convolution (stride 1, zero padding 1) into a handful of channels (conv_out: 128 -> 3, unet.py:585-587) with the
+// GroupNorm + SiLU of its input fused in: fp32 FMAs on the vector ALU.  With 3 output channels there is no GEMM to speak of
+// (3456 FMAs per pixel, 7 GFLOP per 16 x 256 x 256 batch) and the job is to read the activation once: MIOpen's implicit GEMM
+// takes 0.96 ms for it, after a 0.2 ms normalisation pass; this kernel is bound by its LDS reads near 0.25 ms.
+// Block = 16 x 16 output pixels, thread = pixel.  Per 32-channel chunk the 18 x 18 patch is normalised, activated and staged
+// in LDS (pixel stride 36 floats: 16 lanes reading 16 bytes each at that stride cover all 64 banks); the weights are uniform
+// per instruction and come through scalar loads.  w: [COUT][3][3][Cin] (output channel, tap, input channel).
+template <int SILU, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_gn_small_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta,
+                                                               const float *__restrict__ pre_bias,
+                                                               const double *__restrict__ stats, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, float *__restrict__ y, int H,
+                                                               int W, int C, int cpg, double eps) {
+  constexpr int PW = 18, PS = 36;                       // patch width, floats per staged pixel
+  __shared__ __attribute__((aligned(16))) float sX[PW * PW * PS];
+  __shared__ __attribute__((aligned(16))) float sAff[2][512];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int tiles_x = W / 16, tiles_y = H / 16;
+  const int txb = blockIdx.x % tiles_x, tyb = (blockIdx.x / tiles_x) % tiles_y;
+  const long b = blockIdx.x / (tiles_x * tiles_y);
+  const int y0 = tyb * 16, x0 = txb * 16;
+  {
+    const int groups = C / cpg;
+    const double n = (double)cpg * (double)H * (double)W;
+    for (int ch = tid; ch < C; ch += 256) {
+      const int g = ch / cpg;
+      const double mean = stats[2 * (b * groups + g)] / n;
+      double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = 1.0 / sqrt(var + eps);
+      const double pbk = pre_bias ? (double)pre_bias[ch] : 0.0;
+      sAff[0][ch] = (float)(rstd * (double)gamma[ch]);
+      sAff[1][ch] = (float)((double)beta[ch] + (pbk - mean) * rstd * (double)gamma[ch]);
+    }
+  }
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+  const float *xb = x + b * (long)H * W * C;
+  __syncthreads();
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    // stage: 324 pixels x 8 channel quads; borders read a clamped address and are zeroed (no branch around the load)
+    for (int i = tid; i < PW * PW * 8; i += 256) {
+      const int px = i >> 3, q = i & 7;
+      const int R = px / PW, X = px % PW;
+      const int gy = y0 - 1 + R, gx = x0 - 1 + X;
+      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + ((long)cy * W + cx) * C + c0 + 4 * q);
+      const f32x4 a4 = *reinterpret_cast<const f32x4 *>(&sAff[0][c0 + 4 * q]);
+      const f32x4 sh4 = *reinterpret_cast<const f32x4 *>(&sAff[1][c0 + 4 * q]);
+      *reinterpret_cast<f32x4 *>(&sX[px * PS + 4 * q]) = gn_act<SILU>(v, a4, sh4) * (in ? 1.f : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float *s = &sX[((ty + tap / 3) * PW + tx + tap % 3) * PS];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(s + 4 * q);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          const float *wp = w + ((long)(co * 9 + tap) * C + c0 + 4 * q);    // uniform: scalar loads
+          acc[co] = __builtin_fmaf(v.x, wp[0], acc[co]);
+          acc[co] = __builtin_fmaf(v.y, wp[1], acc[co]);
+          acc[co] = __builtin_fmaf(v.z, wp[2], acc[co]);
+          acc[co] = __builtin_fmaf(v.w, wp[3], acc[co]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float *yo = y + ((b * H + y0 + ty) * W + x0 + tx) * COUT;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) yo[co] = acc[co];
+}
+
 }  // namespace gqhip

@@ -978,6 +978,33 @@ int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, cons
   return check_launch();
 }
 
+int conv3x3_gn_small_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
+                         const double *stats_in, int64_t groups_in, double eps, int apply_silu, const float *w_ohwi,
+                         const float *bias_or_null, float *y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                         void *stream) {
+  if (B < 0 || H < 16 || W < 16 || H % 16 || W % 16 || Cin < 32 || Cin % 32 != 0 || Cin > 512 || Cout < 1 || Cout > 4 ||
+      groups_in < 1 || Cin % groups_in != 0 || B * (H / 16) * (W / 16) > 0x7fffffffL)
+    return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !gamma || !beta || !stats_in || !w_ohwi || !y) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(B * (H / 16) * (W / 16)));
+  const int cpg = (int)(Cin / groups_in);
+#define GQ_CS(S, CO)                                                                                                      \
+  hipLaunchKernelGGL((conv3x3_gn_small_kernel<S, CO>), grid, dim3(256), 0, st, x, gamma, beta, pre_bias_or_null, stats_in, \
+                     w_ohwi, bias_or_null, y, (int)H, (int)W, (int)Cin, cpg, eps)
+#define GQ_CS2(CO) do { if (apply_silu) GQ_CS(1, CO); else GQ_CS(0, CO); } while (0)
+  switch (Cout) {
+    case 1: GQ_CS2(1); break;
+    case 2: GQ_CS2(2); break;
+    case 3: GQ_CS2(3); break;
+    default: GQ_CS2(4); break;
+  }
+#undef GQ_CS2
+#undef GQ_CS
+  return check_launch();
+}
+
 int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream) {
   if (B < 0 || H < 2 || W < 2 || H % 2 || W % 2 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
   if (B == 0) return GQHIP_OK;

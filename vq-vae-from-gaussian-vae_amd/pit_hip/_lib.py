@@ -69,6 +69,8 @@ _SIGNATURES = {
     "conv3x3_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "conv3x3_gn_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp,
                                          _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
+    "conv3x3_gn_small_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _i64, _i64,
+                                             _i64, _i64, _i64, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
@@ -559,6 +561,24 @@ def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None
         _check(L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), _ptr(ostats),
                                B, H, W, C, cout, max(stats_groups, 1), mscale, _stream()), "conv3x3_f16x3")
     return (y, ostats) if stats_groups else y
+
+
+def conv3x3_gn_small(x, w_ohwi, bias, gn):
+    """conv3x3(SiLU(GroupNorm(x))) into 1..4 channels (gqhip.h:conv3x3_gn_small_f32): x channels_last fp32 [B, Cin, H, W],
+    w_ohwi [Cout, 3, 3, Cin] fp32 contiguous, ``gn`` = (gamma, beta, groups, eps, silu, stats, pre_bias)."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 32 or x.shape[2] % 16 or x.shape[3] % 16:
+        raise GqHipError("conv3x3_gn_small needs a dense channels_last fp32 HIP tensor, C % 32 == 0, H % 16 == 0, W % 16 == 0")
+    B, C, H, W = x.shape
+    cout = w_ohwi.shape[0]
+    if tuple(w_ohwi.shape) != (cout, 3, 3, C) or not w_ohwi.is_contiguous() or w_ohwi.dtype != torch.float32:
+        raise GqHipError("conv3x3_gn_small: weights must be fp32 [Cout, 3, 3, Cin] contiguous")
+    gamma, beta, groups, eps, silu, stats, pre_bias = gn
+    y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        _check(lib().conv3x3_gn_small_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(),
+                                          groups, float(eps), 1 if silu else 0, w_ohwi.data_ptr(), _ptr(bias), y.data_ptr(),
+                                          B, H, W, C, cout, _stream()), "conv3x3_gn_small_f32")
+    return y
 
 
 def upconv_im2col(x, scales=None):

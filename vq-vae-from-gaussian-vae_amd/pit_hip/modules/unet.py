@@ -165,6 +165,25 @@ def _gn_tuple(norm: nn.GroupNorm, x: torch.Tensor, pre_bias):
     return (norm.weight, norm.bias, norm.num_groups, norm.eps, True, stats, pre_bias)
 
 
+def _norm_act_conv_small(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
+    """conv(swish(norm(x + pre_bias))) for a 3x3 convolution into <= 4 channels (the decoder's conv_out, unet.py:585-587):
+    one libgqhip kernel -- GroupNorm + swish applied while staging, fp32 FMAs -- instead of a normalisation pass and
+    MIOpen's implicit GEMM (0.2 + 0.96 ms at 16 x 256 x 256 x 128)."""
+    if (FUSED_CONV_OUT and _use_fused(x, norm) and conv.out_channels <= 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and x.shape[1] % 32 == 0 and x.shape[1] <= 512 and x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0):
+        from .. import _lib
+
+        if _lib.image_layout(x) == 1:
+            w = conv.weight
+            key = (w.data_ptr(), w._version, w.device)
+            if getattr(conv, "_ohwi_key", None) != key:
+                conv._ohwi = w.detach().permute(0, 2, 3, 1).contiguous()
+                conv._ohwi_key = key
+            return _lib.conv3x3_gn_small(x, conv._ohwi, conv.bias, _gn_tuple(norm, x, pre_bias))
+    return conv(_norm_act(norm, x, pre_bias=pre_bias))
+
+
 def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None, want_stats: bool = False):
     """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  The GroupNorm(+SiLU) is applied inside the Winograd input
     transform, so the normalised tensor is never written (FUSED_WINO_GN / FUSED_WINO_GN_F4)."""
@@ -257,7 +276,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
-        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
+        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -312,6 +331,7 @@ WINOGRAD_C128_GEMM = True
 # channels (128 x 128 level) -- as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the activation once and
 # writes the result once where Winograd moves 6.4 / 10.7 GB of transformed tensors per convolution at 256 x 256
 DIRECT_CONV = True
+FUSED_CONV_OUT = True      # decoder conv_out (128 -> 3) with norm_out + swish fused in: one VALU kernel
 DIRECT_CONV_OVER_F4 = False   # ... also where the alternative is F(4x4,3x3) (decoder, 256 channels at 128 x 128): A/B switch
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
 # written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
@@ -696,5 +716,5 @@ class Decoder(nn.Module):
                 h, pb = self.up[lvl].upsample(h)
         if self.give_pre_end:
             return h
-        h = self.conv_out(_norm_act(self.norm_out, h))
+        h = _norm_act_conv_small(self.norm_out, self.conv_out, h, pb)
         return torch.tanh(h) if self.tanh_out else h
