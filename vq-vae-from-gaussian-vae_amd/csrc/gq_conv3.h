@@ -22,7 +22,7 @@
 //                           different banks with ds_read_b128); each of the 9 taps is one MFMA k-step whose A operand is
 //                           the patch shifted by (dy, dx) -- 8 LDS reads for 24 MFMAs per wave.  The weights, laid out in
 //                           operand order ([chunk][tap][column tile][plane][lane][8]), come straight from L2 into
-//                           registers, one k-step ahead: a wave's load is 1 KB contiguous.
+//                           registers, two k-steps ahead (three register sets): a wave's load is 1 KB contiguous.
 //                           Epilogue: * mscale + bias (+ residual), store, GroupNorm statistics of the result.
 #pragma once
 #include "gq_common.h"
@@ -284,17 +284,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
     inb |= (unsigned)(in ? 1 : 0) << i;
   }
   const float *xb = pp.x + t.b * (long)H * W * cin;
-  f32x4 st[kC3Loads];
-  auto issue = [&](int chunk) {
-#pragma unroll
-    for (int i = 0; i < kC3Loads; ++i) st[i] = *reinterpret_cast<const f32x4 *>(xb + goff[i] + chunk * 16);
-  };
-  auto convert = [&](int i, int chunk, int buf) {    // piece i of the chunk in `st` -> activated, scaled, split, into LDS
+  // three staging registers: piece i of the next chunk is loaded at tap i (i < 3) or tap i (3 <= i < 6, into the register
+  // piece i - 3 just left) and converted three taps later
+  f32x4 st[3];
+  auto issue = [&](int i, int chunk) { st[i % 3] = *reinterpret_cast<const f32x4 *>(xb + goff[i] + chunk * 16); };
+  auto convert = [&](int i, int chunk, int buf) {    // piece i of the chunk (in st[i % 3]) -> activated, scaled, split, into LDS
     const int q = qs + 64 * i;
     if (q >= kC3Pix) return;
     const f32x4 a4 = *reinterpret_cast<const f32x4 *>(&sAff[0][chunk * 16 + 4 * w]);
     const f32x4 sh4 = *reinterpret_cast<const f32x4 *>(&sAff[1][chunk * 16 + 4 * w]);
-    const f32x4 v = gn_act<SILU>(st[i], a4, sh4) * (((inb >> i) & 1) ? pp.scale : 0.f);
+    const f32x4 v = gn_act<SILU>(st[i % 3], a4, sh4) * (((inb >> i) & 1) ? pp.scale : 0.f);
     f16x4 hi, lo;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -312,57 +311,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) aoff[dx] = conv3_lds_off(4 * wm, c + dx, h);
   // weights of k-step ks = chunk * 9 + tap, column tiles 2 wn and 2 wn + 1, planes h / l: 4 operands of 1 KB per wave;
-  // uniform base + lane offset, two register sets used alternately (18 taps per loop trip: no copies)
+  // uniform base + lane offset.  THREE register sets, loads two taps ahead: vmcnt retires in order, so with one tap of
+  // lead every wait for a weight operand (L2) also waited for the x loads issued just before it (HBM).  Now the wait at
+  // tap T is for loads issued at tap T - 2, the x piece issued at the end of tap T - 3 is first covered by the wait at
+  // tap T -- the tap that converts it.
   const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + (4 * t.nb + 2 * wn) * 128 * 16;
   const int wl = lane * 16;
   const long wstep = (long)p.nnb * (512 * 16);   // bytes per k-step
-  f16x8 b0[4], b1[4];
+  f16x8 bs[3][4];
   auto load_b = [&](int ks, f16x8 (&dst)[4]) {
     const unsigned char *s = wbase + ks * wstep;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
   };
   const int nks = p.nch * 9;
-  load_b(0, b0);
-  issue(0);
+  load_b(0, bs[0]);
+  load_b(1, bs[1]);
   __syncthreads();          // sAff
+  for (int i0 = 0; i0 < kC3Loads; i0 += 3) {   // chunk 0, three pieces at a time
 #pragma unroll
-  for (int i = 0; i < kC3Loads; ++i) convert(i, 0, 0);
+    for (int i = 0; i < 3; ++i) issue(i0 + i, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) convert(i0 + i, 0, 0);
+  }
   __syncthreads();
 
-  // two chunks per trip (nch is even): chunk cp from buffer 0 while cp + 1 is converted into buffer 1, then cp + 1 from
-  // buffer 1 while cp + 2 goes into buffer 0
-  for (int cp = 0; cp < p.nch; cp += 2) {
-    issue(cp + 1);
+  for (int chunk = 0; chunk < p.nch; ++chunk) {
+    const bool more = chunk + 1 < p.nch;
+    const unsigned char *A = sA + (chunk & 1) * kC3Buf;
+    const int nbuf = (chunk + 1) & 1;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int ks = cp * 9 + tap;
-      if (tap & 1) {
-        load_b(ks + 1, b0);
-        conv3_tap(sA + aoff[tap % 3], tap / 3, b1, acc);
-      } else {
-        load_b(ks + 1, b1);
-        conv3_tap(sA + aoff[tap % 3], tap / 3, b0, acc);
+      const int ks = chunk * 9 + tap;
+      load_b(ks + 2 < nks ? ks + 2 : nks - 1, bs[(tap + 2) % 3]);
+      conv3_tap(A + aoff[tap % 3], tap / 3, bs[tap % 3], acc);
+      if (more) {
+        if (tap >= 3) convert(tap - 3, chunk + 1, nbuf);
+        if (tap < kC3Loads) issue(tap, chunk + 1);
       }
-      if (tap >= 9 - kC3Loads) convert(tap - (9 - kC3Loads), cp + 1, 1);
       __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting the LDS reads of later taps (spills otherwise)
-    }
-    __syncthreads();
-    const bool more = cp + 2 < p.nch;
-    if (more) issue(cp + 2);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ks = cp * 9 + 9 + tap;
-      const int kn = ks + 1 < nks ? ks + 1 : ks;
-      if (tap & 1) {
-        load_b(kn, b1);
-        conv3_tap(sA + kC3Buf + aoff[tap % 3], tap / 3, b0, acc);
-      } else {
-        load_b(kn, b0);
-        conv3_tap(sA + kC3Buf + aoff[tap % 3], tap / 3, b1, acc);
-      }
-      if (tap >= 9 - kC3Loads && more) convert(tap - (9 - kC3Loads), cp + 2, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
