@@ -234,6 +234,16 @@ int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *
 int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
                   double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
                   float mscale, void *stream);
+/* 1x1 convolution Cin -> Cout (128, 256 or 512) of a channels_last tensor = a GEMM over its B * HW pixels, fp16 x 3 as above
+ * with the split of x done inside the kernel: the ResnetBlocks' nin_shortcut (reference pit/modules/unet.py:151-152) and the
+ * attention block's proj_out (:203).  x [B * HW, Cin] fp32 (NOT normalised; + pre_bias[c], a bias still pending on it); the
+ * power-of-two scale of x + pre_bias comes from
+ * scales_dev = {scale, 1 / (scale * u_scale)} in device memory (f16_scales_from_gn_stats) or, when that is NULL, from the
+ * `scale` / `mscale` arguments.  Wf [Cin/16, 1, Cout/32, 2, 64, 8] as for conv3x3_f16x3; y = x W * mscale + bias (+ res);
+ * stats_out optional.  HW % 256 == 0, Cin % 32 == 0. */
+int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf, const float *scales_dev_or_null, float scale,
+                  float mscale, const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t HW,
+                  int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
 /* 3x3 convolution (stride 1, zero padding 1) into 1..4 channels with GroupNorm (+ SiLU) of the input fused in, fp32 FMAs:
  * the decoder's conv_out(swish(norm_out(h))) (reference pit/modules/unet.py:585-587).  x [B, H, W, Cin] fp32, w_ohwi
  * [Cout, 3, 3, Cin] fp32, y [B, H, W, Cout].  H % 16 == 0, W % 16 == 0, Cin % 32 == 0, Cin <= 512. */

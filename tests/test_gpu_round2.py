@@ -625,3 +625,69 @@ def test_decoder_with_and_without_fused_conv_out_agree():
             outs.append(dec(z))
     U.FUSED_CONV_OUT = True
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * max(1.0, float(outs[1].abs().max()))
+
+
+def test_conv1x1_f16x3_matches_fp64():
+    """conv1x1_direct (fp16 x 3 GEMM over the pixels, x + pending bias split inside the kernel; device-side or host scale;
+    bias / residual / statistics epilogue) vs fp64: error <= 1.2e-6 of sum |x||w| (worst case 3 x 2^-22 = 7.2e-7 + fp32 accumulation over K <= 512; a 4e3 outlier in x
+    forces a scale at which the low parts of ordinary elements sit near fp16's subnormals)."""
+    from pit_hip import _lib
+
+    torch.manual_seed(41)
+    for cin, cout, (B, H, W) in ((256, 128, (2, 16, 32)), (128, 256, (1, 16, 16)), (512, 512, (2, 32, 32)), (384, 512, (1, 8, 32))):
+        conv = torch.nn.Conv2d(cin, cout, 1).to(DEV).to(memory_format=torch.channels_last)
+        with torch.no_grad():
+            x = (3 * torch.randn(B, cin, H, W, device=DEV)).contiguous(memory_format=torch.channels_last)
+            x[0, 5, 3, 7] = 4e3                                       # an outlier the scale has to cover
+            res = torch.randn(B, cout, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+            pb = torch.randn(cin, device=DEV)
+            wf, us = _lib.conv3_weights_f16(conv.weight)
+            w64 = conv.weight.double()
+            for pre in (None, pb):
+                xin = x.double() if pre is None else x.double() + pre.double()[None, :, None, None]
+                ref0 = torch.nn.functional.conv2d(xin, w64)
+                sc = torch.nn.functional.conv2d(xin.abs(), w64.abs())
+                if _lib.gn_nhwc_ok(cin, 32):                          # device-side scale from GroupNorm statistics
+                    scales = _lib.f16_scales(_lib.gn_stats(x, 32, pre), 1.0, us)
+                    y, st = _lib.conv1x1_direct(x, wf, us, scales, residual=res, bias=conv.bias, stats_groups=32, pre_bias=pre)
+                    ref = ref0 + conv.bias.double()[None, :, None, None] + res.double()
+                    assert float(((y.double() - ref).abs() / sc).max()) <= 1.2e-6, (cin, cout)
+                    yd = y.double().permute(0, 2, 3, 1).reshape(B, H * W, 32, cout // 32)
+                    st_y = torch.stack([yd.sum((1, 3)), (yd ** 2).sum((1, 3))], -1).flatten()
+                    assert torch.allclose(st, st_y, rtol=2e-6, atol=1e-2), float((st - st_y).abs().max())
+                y2 = _lib.conv1x1_direct(x, wf, us, float(xin.abs().max()), pre_bias=pre)      # host bound
+                assert float(((y2.double() - ref0).abs() / sc).max()) <= 1.2e-6, (cin, cout)
+    L = _lib.lib()
+    S = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(1, 128, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
+    y = torch.empty(1, 128, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
+    wf, us = _lib.conv3_weights_f16(torch.randn(128, 128, 1, 1, device=DEV))
+    assert L.conv1x1_f16x3(x.data_ptr(), None, wf.data_ptr(), None, 1.0, 1.0, None, None, y.data_ptr(), None, 1, 200, 128, 128, 32, S) != 0
+    assert L.conv1x1_f16x3(x.data_ptr(), None, wf.data_ptr(), None, 0.0, 1.0, None, None, y.data_ptr(), None, 1, 256, 128, 128, 32, S) != 0
+    assert L.conv1x1_f16x3(x.data_ptr(), None, wf.data_ptr(), None, 1.0, 1.0, None, None, y.data_ptr(), None, 1, 256, 128, 192, 32, S) != 0
+    with pytest.raises(_lib.GqHipError):
+        _lib.conv1x1_direct(torch.randn(1, 128, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last), wf, us, 10.0)
+
+
+def test_shortcut_and_attention_pointwise_routes_agree_with_miopen():
+    """ResnetBlock with a channel change (nin_shortcut) and AttnBlock (proj_out + residual add) with the 1x1 convolutions as
+    libgqhip GEMMs vs MIOpen's fp32 convolutions: same function, same statistics left for the next GroupNorm."""
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(7)
+    blk = U.ResnetBlock(256, 128, 0.0).eval().to(DEV).to(memory_format=torch.channels_last)
+    att = U.AttnBlock(512).eval().to(DEV).to(memory_format=torch.channels_last)
+    U.mark_winograd(blk)
+    x = torch.randn(2, 256, 16, 32, device=DEV).contiguous(memory_format=torch.channels_last)
+    pb = torch.randn(256, device=DEV)
+    xa = torch.randn(2, 512, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    with torch.no_grad():
+        for flag in (True, False):
+            U.DIRECT_CONV_1X1 = flag
+            outs[flag] = (blk(x), blk(x, pb), att(xa))
+        U.DIRECT_CONV_1X1 = True
+    for a, b in zip(outs[True], outs[False]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+        sa, sb = getattr(a, "_gn_stats", None), getattr(b, "_gn_stats", None)
+        assert sa is not None and sb is not None and torch.allclose(sa[0], sb[0], rtol=1e-5, atol=1e-2)

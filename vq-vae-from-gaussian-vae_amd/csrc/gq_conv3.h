@@ -413,6 +413,113 @@ __global__ __launch_bounds__(256) void conv3_split_gn_kernel(const float *__rest
   }
 }
 
+// ---- 1x1 convolution Cin -> 128 / 256 channels (the ResnetBlocks' nin_shortcut, unet.py:151-152; the attention block's
+// proj_out, unet.py:203) = a GEMM over the pixels, same fp16 x 3 scheme, the split of x done on the way into LDS.  MIOpen
+// runs these on the fp32 matrix cores at ~100 TFLOP/s (725 us for 256 -> 128 at 16 x 256 x 256, HBM floor 320 us).
+// The pixel rows are treated as an image of width 32 (tile = 256 consecutive pixels of ONE image: HW % 256 == 0), so tile
+// decoding and the epilogue are those of the 3x3 kernel.  A stage = 32 channels (two MFMA k-steps; a pixel's 128 bytes =
+// one line), double buffered: 2 x 32 KB.  x is NOT normalised here (the shortcut takes the raw residual stream): its
+// scale comes from the host (a bound the caller knows) or from device memory (f16_scales_from_gn_stats: no sync).
+struct Conv1Params {
+  Conv3Params c;           // H = HW / 32, W = 32, tiles_x = 1, tiles_y = HW / 256
+  const float *x;          // [B * HW][cin]
+  const float *pre_bias;   // [cin] or null: added to x before the split (a bias still pending on x)
+  const float *scales_dev; // {scale, 1 / (scale * u_scale)} or null (then c.mscale and `scale` below)
+  float scale;
+  int cin;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const Conv1Params pp) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  Conv3Params p = pp.c;
+  constexpr int kPlane = 256 * 32, kChunk = 2 * kPlane, kStage = 2 * kChunk;   // bytes
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kStage];
+  __shared__ double red[2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  Conv3Tile t;
+  if (!conv3_tile(p, t)) return;
+  if (tid < 128) red[tid] = 0.0;
+  const float scale = pp.scales_dev ? pp.scales_dev[0] : pp.scale;
+  if (pp.scales_dev) p.mscale = pp.scales_dev[1];
+  const int cin = pp.cin, nst = cin / 32;
+  // loader: thread -> channel quad w8 = tid & 7 of the stage's 32 channels, rows (tid >> 3) + 32 i
+  const int w8 = tid & 7, r0 = tid >> 3;
+  const float *xb = pp.x + ((t.b * p.H + t.y0) * 32L + r0) * cin + 4 * w8;
+  const float *pbp = pp.pre_bias ? pp.pre_bias + 4 * w8 : nullptr;
+  f32x4 pb4 = {0.f, 0.f, 0.f, 0.f};
+  const int loff = (w8 >> 2) * kChunk + r0 * 32 + 16 * (((w8 >> 1) & 1) ^ ((r0 >> 3) & 1)) + 8 * (w8 & 1);
+  f32x4 st[8];
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = *reinterpret_cast<const f32x4 *>(xb + (long)(32 * i) * cin + stage * 32);
+  };
+  auto convert = [&](int i, int buf) {     // rows r0 + 32 i: (r >> 3) & 1 = (r0 >> 3) & 1
+    const f32x4 v = (st[i] + pb4) * scale;
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (_Float16)v[e];
+      lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    }
+    unsigned char *d = sA + buf * kStage + loff + i * (32 * 32);
+    *reinterpret_cast<f16x4 *>(d) = hi;
+    *reinterpret_cast<f16x4 *>(d + kPlane) = lo;
+  };
+  f32x16 acc[4][2];
+  GQ_C3_ZERO_ACC(acc);
+  const int aoff = (4 * wm) * 1024 + c * 32 + 16 * (h ^ ((c >> 3) & 1));
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + (4 * t.nb + 2 * wn) * 128 * 16;
+  const int wl = lane * 16;
+  const long wstep = (long)p.nnb * (512 * 16);
+  f16x8 b0[4], b1[4];
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+    const unsigned char *s = wbase + ks * wstep;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
+  };
+  auto kstep = [&](const unsigned char *A, const f16x8 (&bq)[4]) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + aoff + rr * 1024);
+      const f16x8 al = *reinterpret_cast<const f16x8 *>(A + aoff + rr * 1024 + kPlane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j + 1], acc[rr][j], 0, 0, 0);
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[2 * j], acc[rr][j], 0, 0, 0);
+      }
+    }
+  };
+  const int nks = 2 * nst;
+  load_b(0, b0);
+  issue(0);
+  if (pbp) pb4 = *reinterpret_cast<const f32x4 *>(pbp);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) convert(i, 0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const bool more = s + 1 < nst;
+    const unsigned char *A = sA + (s & 1) * kStage;
+    const int nbuf = (s + 1) & 1;
+    load_b(2 * s + 1, b1);
+    if (more) issue(s + 1);
+    kstep(A, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(2 * s + 2 < nks ? 2 * s + 2 : nks - 1, b0);
+    kstep(A + kChunk, b1);
+    if (more) {
+      if (pbp) pb4 = *reinterpret_cast<const f32x4 *>(pbp + (s + 1) * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) convert(i, nbuf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
+}
+
 // ---- 3x3 convolution (stride 1, zero padding 1) into a handful of channels (conv_out: 128 -> 3, unet.py:585-587) with the
 // GroupNorm + SiLU of its input fused in: fp32 FMAs on the vector ALU.  With 3 output channels there is no GEMM to speak of
 // (3456 FMAs per pixel, 7 GFLOP per 16 x 256 x 256 batch) and the job is to read the activation once: MIOpen's implicit GEMM

@@ -978,6 +978,30 @@ int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, cons
   return check_launch();
 }
 
+int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf, const float *scales_dev_or_null, float scale,
+                  float mscale, const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t HW,
+                  int64_t Cin, int64_t Cout, int64_t groups_out, void *stream) {
+  if (B < 0 || HW < 256 || HW % 256 != 0 || Cin < 32 || Cin % 32 != 0 || (Cout != 128 && Cout != 256 && Cout != 512) ||
+      HW > (1 << 24) || (!scales_dev_or_null && !(scale > 0.f)))
+    return GQHIP_ERR_INVALID_ARG;
+  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
+    return check_launch();
+  Conv1Params gp{};
+  Conv3Params &cp = gp.c;
+  conv3_fill(cp, Wf, bias_or_null, res_or_null, y, stats_out_or_null, B, HW / 32, 32, Cin, Cout, groups_out, mscale);
+  cp.nch = (int)(Cin / 16);
+  gp.x = x; gp.pre_bias = pre_bias_or_null; gp.scales_dev = scales_dev_or_null; gp.scale = scale; gp.cin = (int)Cin;
+  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
+  if (Cout == 128) hipLaunchKernelGGL(conv1x1_f16x3_kernel<128>, grid, dim3(256), 0, st, gp);
+  else if (Cout == 256) hipLaunchKernelGGL(conv1x1_f16x3_kernel<256>, grid, dim3(256), 0, st, gp);
+  else hipLaunchKernelGGL(conv1x1_f16x3_kernel<512>, grid, dim3(256), 0, st, gp);
+  return check_launch();
+}
+
 int conv3x3_gn_small_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                          const double *stats_in, int64_t groups_in, double eps, int apply_silu, const float *w_ohwi,
                          const float *bias_or_null, float *y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,

@@ -69,6 +69,8 @@ _SIGNATURES = {
     "conv3x3_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "conv3x3_gn_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp,
                                          _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
+    "conv1x1_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                      _vp]),
     "conv3x3_gn_small_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _i64, _i64,
                                              _i64, _i64, _i64, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -508,9 +510,9 @@ DIRECT_CONV_FUSED_SPLIT = True   # conv3x3_direct: GroupNorm + split inside the 
 def conv3_weights_f16(weight):
     """Operand-order fp16 x 3 weights of a [Cout, Cin, 3, 3] kernel for conv3x3_direct: (Wf [Cin/16, 9, Cout/32, 2, 64, 8]
     fp16, u_scale) -- see gqhip.h:conv3x3_gn_f16x3."""
-    cout, cin = weight.shape[0], weight.shape[1]
-    if cout not in (128, 256) or cin % 16 or tuple(weight.shape[2:]) != (3, 3):
-        raise GqHipError("conv3_weights_f16 needs a [128 | 256, Cin % 16 == 0, 3, 3] kernel")
+    cout, cin, kk = weight.shape[0], weight.shape[1], weight.shape[2]
+    if cout not in ((128, 256, 512) if kk == 1 else (128, 256)) or cin % 16 or tuple(weight.shape[2:]) not in ((3, 3), (1, 1)):
+        raise GqHipError("conv3_weights_f16 needs a [128 | 256, Cin % 16 == 0, 3, 3] or [128 | 256 | 512, Cin % 16 == 0, 1, 1] kernel")
     w = weight.detach().float()
     amax = float(w.abs().max())
     u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0
@@ -519,8 +521,8 @@ def conv3_weights_f16(weight):
     lo = (ws - hi.float()).half()
     planes = torch.stack([hi, lo], 0)                                    # [plane, n, k, ky, kx]
     # n = 32 tile + c, k = 16 chunk + 8 h + e  ->  [chunk, ky, kx, tile, plane, h, c, e]
-    p7 = planes.reshape(2, cout // 32, 32, cin // 16, 2, 8, 3, 3).permute(3, 6, 7, 1, 0, 4, 2, 5)
-    return p7.reshape(cin // 16, 9, cout // 32, 2, 64, 8).contiguous(), u_scale
+    p7 = planes.reshape(2, cout // 32, 32, cin // 16, 2, 8, kk, kk).permute(3, 6, 7, 1, 0, 4, 2, 5)
+    return p7.reshape(cin // 16, kk * kk, cout // 32, 2, 64, 8).contiguous(), u_scale
 
 
 def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None, bias=None, stats_groups: int = 0):
@@ -560,6 +562,33 @@ def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None
                                         float(v_scale), _stream()), "conv3_split_gn_f16")
         _check(L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), _ptr(ostats),
                                B, H, W, C, cout, max(stats_groups, 1), mscale, _stream()), "conv3x3_f16x3")
+    return (y, ostats) if stats_groups else y
+
+
+def conv1x1_direct(x, wf, u_scale: float, scale, residual=None, bias=None, stats_groups: int = 0, pre_bias=None):
+    """1x1 convolution Cin -> Cout (128 | 256) of a channels_last fp32 HIP tensor as an fp16 x 3 GEMM over its pixels with the
+    split of x inside the kernel (gqhip.h:conv1x1_f16x3).  ``wf, u_scale`` from conv3_weights_f16 of the [Cout, Cin, 1, 1]
+    kernel; ``pre_bias``: per-channel bias still pending on x (added before the split); ``scale``: a float bound >=
+    max|x + pre_bias|, or the device float[2] of f16_scales(statistics of x + pre_bias, 1.0, u_scale)."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 32 or (x.shape[2] * x.shape[3]) % 256:
+        raise GqHipError("conv1x1_direct needs a dense channels_last fp32 HIP tensor, C % 32 == 0, H * W % 256 == 0")
+    B, C, H, W = x.shape
+    cout = wf.shape[2] * 32
+    if wf.shape[0] * 16 != C or wf.shape[1] != 1:
+        raise GqHipError("conv1x1_direct: weights do not match (need conv3_weights_f16 of a [Cout, %d, 1, 1] kernel)" % C)
+    if residual is not None and (image_layout(residual) != 1 or tuple(residual.shape) != (B, cout, H, W)):
+        raise GqHipError("conv1x1_direct: residual must be channels_last [B, Cout, H, W]")
+    if torch.is_tensor(scale):
+        sdev, v_scale, mscale = scale.data_ptr(), 0.0, 0.0
+    else:
+        v_scale = min(2.0 ** math.floor(math.log2(32768.0 / max(float(scale), 1e-30))), 2.0 ** 14)
+        sdev, mscale = None, 1.0 / (v_scale * u_scale)
+    with torch.cuda.device(x.device):
+        y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+        _check(lib().conv1x1_f16x3(x.data_ptr(), _ptr(pre_bias), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), _ptr(residual),
+                                   y.data_ptr(), _ptr(ostats), B, H * W, C, cout, max(stats_groups, 1), _stream()),
+               "conv1x1_f16x3")
     return (y, ostats) if stats_groups else y
 
 

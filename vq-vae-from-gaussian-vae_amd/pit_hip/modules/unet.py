@@ -153,16 +153,35 @@ def _direct_weights(conv: nn.Conv2d):
     return conv._direct_wf, conv._direct_us
 
 
-def _gn_tuple(norm: nn.GroupNorm, x: torch.Tensor, pre_bias):
-    """The ``gn`` argument of wino_conv3x3 / conv3x3_direct: statistics left by the producer of x, or computed here."""
+def _stats_of(x: torch.Tensor, pre_bias, groups: int):
+    """GroupNorm statistics of x + pre_bias: left by the producer of x, computed earlier for the same pending bias, or
+    computed (and remembered on x) here."""
     from .. import _lib
 
     st = getattr(x, "_gn_stats", None)
-    if st is not None and pre_bias is None and st[1] == norm.num_groups:
-        stats = st[0]
-    else:
-        stats = _lib.gn_stats(x, norm.num_groups, pre_bias)
-    return (norm.weight, norm.bias, norm.num_groups, norm.eps, True, stats, pre_bias)
+    if st is not None and pre_bias is None and st[1] == groups:
+        return st[0]
+    sp = getattr(x, "_gn_stats_pb", None)
+    if sp is not None and sp[1] == groups and sp[2] is pre_bias:
+        return sp[0]
+    stats = _lib.gn_stats(x, groups, pre_bias)
+    x._gn_stats_pb = (stats, groups, pre_bias)
+    return stats
+
+
+def _gn_tuple(norm: nn.GroupNorm, x: torch.Tensor, pre_bias):
+    """The ``gn`` argument of wino_conv3x3 / conv3x3_direct: statistics left by the producer of x, or computed here."""
+    return (norm.weight, norm.bias, norm.num_groups, norm.eps, True, _stats_of(x, pre_bias, norm.num_groups), pre_bias)
+
+
+def _pointwise_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
+    """1x1 convolutions into 128 / 256 / 512 channels (ResnetBlock shortcuts, attention proj_out) as libgqhip's fp16 x 3
+    GEMM over the pixels (gq_conv3.h: conv1x1_f16x3) instead of MIOpen's fp32 implicit GEMM (~100 TFLOP/s)."""
+    return (DIRECT_CONV_1X1 and FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.out_channels in (128, 256, 512) and conv.in_channels % 128 == 0 and x.dim() == 4
+            and (x.shape[2] * x.shape[3]) % 256 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and not x.is_contiguous())
 
 
 def _norm_act_conv_small(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
@@ -276,7 +295,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
-        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
+        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -331,6 +350,7 @@ WINOGRAD_C128_GEMM = True
 # channels (128 x 128 level) -- as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the activation once and
 # writes the result once where Winograd moves 6.4 / 10.7 GB of transformed tensors per convolution at 256 x 256
 DIRECT_CONV = True
+DIRECT_CONV_1X1 = True     # 1x1 shortcut / proj_out convolutions as an fp16 x 3 GEMM with the split of x inside the kernel
 FUSED_CONV_OUT = True      # decoder conv_out (128 -> 3) with norm_out + swish fused in: one VALU kernel
 DIRECT_CONV_OVER_F4 = False   # ... also where the alternative is F(4x4,3x3) (decoder, 256 channels at 128 x 128): A/B switch
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
@@ -379,7 +399,15 @@ class ResnetBlock(nn.Module):
     def forward(self, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
         """``pre_bias``: bias of the conv that produced ``x``, not yet added (deferred path)."""
         h, b1 = _norm_act_conv(self.norm1, self.conv1, x, pre_bias, want_stats=True)   # norm2 follows
-        if self.in_channels != self.out_channels:
+        if self.in_channels != self.out_channels and _pointwise_ok(self.nin_shortcut, x) and _use_fused(x, self.norm1):
+            # nin(x + pb) as one fp16 x 3 GEMM over the pixels; x + pb is split inside the kernel, its power-of-two scale
+            # comes (on the device) from the statistics norm1 needed anyway: |x + pb| <= sqrt(group sum of squares)
+            from .. import _lib
+
+            wf, us = _direct_weights(self.nin_shortcut)
+            scales = _lib.f16_scales(_stats_of(x, pre_bias, GN_GROUPS), 1.0, us)
+            xs, bs = _lib.conv1x1_direct(x, wf, us, scales, pre_bias=pre_bias), self.nin_shortcut.bias
+        elif self.in_channels != self.out_channels:
             # nin(x + pb) = nin_nobias(x) + W.pb + nin.bias : every constant goes into the fused add
             xs, bs = _conv(self.nin_shortcut, x)
             if pre_bias is not None:
@@ -474,8 +502,30 @@ class AttnBlock(nn.Module):
             q, k, v = (f(y).reshape(b, 1, c, h * w).transpose(2, 3).contiguous() for f in (self.q, self.k, self.v))
             a = _sdpa(q, k, v)
             a = a.transpose(2, 3).reshape(b, c, h, w)
+        if (_pointwise_ok(self.proj_out, a) and FUSED_ADD_STATS and x.is_contiguous(memory_format=torch.channels_last)
+                and not x.is_contiguous() and self.proj_out.bias is not None):
+            # proj_out + bias + residual add + the next GroupNorm's statistics in one fp16 x 3 GEMM over the pixels.  Scale:
+            # the attention output is a convex combination of the rows of v, so |a| <= max|v| <= max|y| max_j ||W_v[j]||_1 +
+            # max|b_v|, with |y| bounded by the GroupNorm bound
+            from .. import _lib
+
+            if _lib.image_layout(a) == 1 and _lib.gn_nhwc_ok(c, GN_GROUPS):
+                wf, us = _direct_weights(self.proj_out)
+                out, st = _lib.conv1x1_direct(a, wf, us, self._v_bound(_gn_act_bound(self.norm, x)), residual=x,
+                                              bias=self.proj_out.bias, stats_groups=GN_GROUPS)
+                out._gn_stats = (st, GN_GROUPS)
+                return out
         p, pb = _conv(self.proj_out, a)
         return _add(x, p, pb)
+
+    def _v_bound(self, y_bound: float) -> float:
+        """max|v| for |y| <= y_bound: v = W_v y + b_v."""
+        key = (self.v.weight.data_ptr(), self.v.weight._version, self.v.bias.data_ptr(), self.v.bias._version)
+        if getattr(self, "_vb_key", None) != key:
+            wv = self.v.weight.detach().reshape(self.v.weight.shape[0], -1)
+            self._vb = (float(wv.abs().sum(1).max()), float(self.v.bias.detach().abs().max()))
+            self._vb_key = key
+        return y_bound * self._vb[0] + self._vb[1]
 
 
 class Downsample(nn.Module):
