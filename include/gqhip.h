@@ -234,7 +234,7 @@ int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *
 int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
                   double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
                   float mscale, void *stream);
-/* 1x1 convolution Cin -> Cout (128, 256 or 512) of a channels_last tensor = a GEMM over its B * HW pixels, fp16 x 3 as above
+/* 1x1 convolution Cin -> Cout (128, 256, 512 or 1536 = the attention block's q | k | v) of a channels_last tensor = a GEMM over its B * HW pixels, fp16 x 3 as above
  * with the split of x done inside the kernel: the ResnetBlocks' nin_shortcut (reference pit/modules/unet.py:151-152) and the
  * attention block's proj_out (:203).  x [B * HW, Cin] fp32 (NOT normalised; + pre_bias[c], a bias still pending on it); the
  * power-of-two scale of x + pre_bias comes from

@@ -9,7 +9,7 @@ import bench
 from pit_hip.modules import unet
 
 dev = torch.device("cuda:0")
-vae = bench.build_model(dev).to(memory_format=torch.channels_last)
+vae = bench.build_model(dev, bench.CONFIGS["gq_0.25"]).to(memory_format=torch.channels_last)
 d = np.load(os.path.join(ROOT, "tests", "golden", "g7_full_e2e.npz"))
 gx = torch.Generator().manual_seed(1000)
 x1 = (torch.rand(1, 3, 256, 256, generator=gx) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)

@@ -7,7 +7,7 @@ import bench
 from pit_hip.graphed import GraphedAutoencoder
 
 dev = torch.device("cuda:0")
-vae = bench.build_model(dev).to(memory_format=torch.channels_last)
+vae = bench.build_model(dev, bench.CONFIGS["gq_0.25"]).to(memory_format=torch.channels_last)
 for B in (1, 4, 16):
     x = (torch.rand(B, 3, 256, 256) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():

@@ -10,7 +10,7 @@ gx = torch.Generator().manual_seed(1000)
 x = (torch.rand(1, 3, 256, 256, generator=gx) * 2 - 1).to(dev)
 ref = torch.from_numpy(d["x_rec"].astype(np.float32))
 for cl in (0, 1):
-    vae = bench.build_model(dev)
+    vae = bench.build_model(dev, bench.CONFIGS["gq_0.25"])
     xx = x
     if cl:
         vae = vae.to(memory_format=torch.channels_last); xx = x.contiguous(memory_format=torch.channels_last)

@@ -3,7 +3,7 @@ import sys, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/vq-vae-from-gaussian-vae_amd")
 import bench
 dev = torch.device("cuda:0")
-vae = bench.build_model(dev)
+vae = bench.build_model(dev, bench.CONFIGS["gq_0.25"])
 x = (torch.rand(2, 3, 512, 512) * 2 - 1).to(dev)
 with torch.no_grad():
     z0 = vae.encoder(x); zh0, i0 = vae.regularization(z0); r0 = vae.decode(zh0)

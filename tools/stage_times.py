@@ -44,7 +44,7 @@ def main():
     unet.SUBPIXEL_UPCONV = bool(a.subpixel)
     unet.WINOGRAD = bool(a.winograd)
     torch.backends.cudnn.benchmark = False
-    vae = bench.build_model(dev)
+    vae = bench.build_model(dev, bench.CONFIGS["gq_0.25"])
     x = (torch.rand(a.batch, 3, 256, 256) * 2 - 1).to(dev)
     if a.channels_last:
         vae = vae.to(memory_format=torch.channels_last)

@@ -981,7 +981,7 @@ int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, cons
 int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf, const float *scales_dev_or_null, float scale,
                   float mscale, const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t HW,
                   int64_t Cin, int64_t Cout, int64_t groups_out, void *stream) {
-  if (B < 0 || HW < 256 || HW % 256 != 0 || Cin < 32 || Cin % 32 != 0 || (Cout != 128 && Cout != 256 && Cout != 512) ||
+  if (B < 0 || HW < 256 || HW % 256 != 0 || Cin < 32 || Cin % 32 != 0 || (Cout != 128 && Cout != 256 && Cout != 512 && Cout != 1536) ||
       HW > (1 << 24) || (!scales_dev_or_null && !(scale > 0.f)))
     return GQHIP_ERR_INVALID_ARG;
   if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
@@ -998,7 +998,8 @@ int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf,
   const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
   if (Cout == 128) hipLaunchKernelGGL(conv1x1_f16x3_kernel<128>, grid, dim3(256), 0, st, gp);
   else if (Cout == 256) hipLaunchKernelGGL(conv1x1_f16x3_kernel<256>, grid, dim3(256), 0, st, gp);
-  else hipLaunchKernelGGL(conv1x1_f16x3_kernel<512>, grid, dim3(256), 0, st, gp);
+  else if (Cout == 512) hipLaunchKernelGGL(conv1x1_f16x3_kernel<512>, grid, dim3(256), 0, st, gp);
+  else hipLaunchKernelGGL(conv1x1_f16x3_kernel<1536>, grid, dim3(256), 0, st, gp);
   return check_launch();
 }
 

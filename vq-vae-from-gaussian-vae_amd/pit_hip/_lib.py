@@ -511,8 +511,8 @@ def conv3_weights_f16(weight):
     """Operand-order fp16 x 3 weights of a [Cout, Cin, 3, 3] kernel for conv3x3_direct: (Wf [Cin/16, 9, Cout/32, 2, 64, 8]
     fp16, u_scale) -- see gqhip.h:conv3x3_gn_f16x3."""
     cout, cin, kk = weight.shape[0], weight.shape[1], weight.shape[2]
-    if cout not in ((128, 256, 512) if kk == 1 else (128, 256)) or cin % 16 or tuple(weight.shape[2:]) not in ((3, 3), (1, 1)):
-        raise GqHipError("conv3_weights_f16 needs a [128 | 256, Cin % 16 == 0, 3, 3] or [128 | 256 | 512, Cin % 16 == 0, 1, 1] kernel")
+    if cout not in ((128, 256, 512, 1536) if kk == 1 else (128, 256)) or cin % 16 or tuple(weight.shape[2:]) not in ((3, 3), (1, 1)):
+        raise GqHipError("conv3_weights_f16 needs a [128 | 256, Cin % 16 == 0, 3, 3] or [128 | 256 | 512 | 1536, Cin % 16 == 0, 1, 1] kernel")
     w = weight.detach().float()
     amax = float(w.abs().max())
     u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0

@@ -295,7 +295,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
-        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
+        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkv_wf_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -492,7 +492,17 @@ class AttnBlock(nn.Module):
                 # q, k, v = three 1x1 convolutions of the same tensor = ONE GEMM [b*hw, c] x [c, 3c] with the biases in
                 # its epilogue (instead of 3 MIOpen launches + 3 bias-add passes); the thirds are strided views
                 wqkv, bqkv = self._qkv_weights()
-                qkv = torch.addmm(bqkv, y.permute(0, 2, 3, 1).reshape(b * h * w, c), wqkv).view(b, 1, h * w, 3 * c)
+                if DIRECT_CONV_1X1 and c == 512 and (h * w) % 256 == 0:
+                    # ... as libgqhip's fp16 x 3 GEMM over the pixels (the fp32 library GEMM runs at ~130 TFLOP/s)
+                    from .. import _lib
+
+                    if getattr(self, "_qkv_wf_key", None) != self._qkv_key:
+                        self._qkv_wf, self._qkv_us = _lib.conv3_weights_f16(wqkv.t().reshape(3 * c, c, 1, 1))
+                        self._qkv_wf_key = self._qkv_key
+                    qkv = _lib.conv1x1_direct(y, self._qkv_wf, self._qkv_us, _gn_act_bound(self.norm, x), bias=bqkv)
+                    qkv = qkv.permute(0, 2, 3, 1).reshape(b, 1, h * w, 3 * c)
+                else:
+                    qkv = torch.addmm(bqkv, y.permute(0, 2, 3, 1).reshape(b * h * w, c), wqkv).view(b, 1, h * w, 3 * c)
                 q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
             else:
                 q, k, v = (f(y).permute(0, 2, 3, 1).reshape(b, 1, h * w, c) for f in (self.q, self.k, self.v))
