@@ -244,6 +244,15 @@ int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, con
 int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf, const float *scales_dev_or_null, float scale,
                   float mscale, const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t HW,
                   int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
+/* 3x3 convolution with stride 2 over x padded by one zero row / column at the bottom / right -- the reference's Downsample
+ * (pit/modules/unet.py:76-97: F.pad(x, (0,1,0,1)) + conv stride 2) -- Cin -> Cout (128, 256 or 512), fp16 x 3 on the four
+ * phase images of x (nine k-steps per 16 input channels).  x [B, Hin, Win, Cin] fp32 (not normalised; scale as for
+ * conv1x1_f16x3), y [B, Hin/2, Win/2, Cout] = conv * mscale + bias; stats_out optional.  Hin % 16 == 0, Win % 64 == 0,
+ * Cin % 16 == 0.  Wf [9 Cin/16, Cout/32, 2, 64, 8]: operand-order weights, k-steps in the order (phase (a, b) = (0,0), (0,1),
+ * (1,0), (1,1); chunk; tap (dy, dx) of the phase, ky = 2 dy + a, kx = 2 dx + b). */
+int conv3x3s2_f16x3(const float *x, const void *Wf, const float *scales_dev_or_null, float scale, float mscale,
+                    const float *bias_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t Hin, int64_t Win,
+                    int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
 /* 3x3 convolution (stride 1, zero padding 1) into 1..4 channels with GroupNorm (+ SiLU) of the input fused in, fp32 FMAs:
  * the decoder's conv_out(swish(norm_out(h))) (reference pit/modules/unet.py:585-587).  x [B, H, W, Cin] fp32, w_ohwi
  * [Cout, 3, 3, Cin] fp32, y [B, H, W, Cout].  H % 16 == 0, W % 16 == 0, Cin % 32 == 0, Cin <= 512. */

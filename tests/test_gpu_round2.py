@@ -691,3 +691,50 @@ def test_shortcut_and_attention_pointwise_routes_agree_with_miopen():
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
         sa, sb = getattr(a, "_gn_stats", None), getattr(b, "_gn_stats", None)
         assert sa is not None and sb is not None and torch.allclose(sa[0], sb[0], rtol=1e-5, atol=1e-2)
+
+
+def test_stride2_conv_f16x3_matches_fp64():
+    """conv3x3s2_direct (the reference's Downsample: zero row / column at the bottom / right, then 3x3 stride 2) on the four
+    phase images, fp16 x 3: error <= 8e-7 of sum |x||w| vs fp64; bias, statistics, device-side and host scale, several tiles."""
+    from pit_hip import _lib
+
+    torch.manual_seed(51)
+    for cin, cout, (B, H, W) in ((128, 128, (2, 32, 128)), (64, 256, (1, 16, 64)), (256, 512, (1, 16, 64)), (16, 128, (3, 48, 64))):
+        conv = torch.nn.Conv2d(cin, cout, 3, 2, 0).to(DEV).to(memory_format=torch.channels_last)
+        with torch.no_grad():
+            x = (3 * torch.randn(B, cin, H, W, device=DEV)).contiguous(memory_format=torch.channels_last)
+            wf, us = _lib.conv3s2_weights_f16(conv.weight)
+            xp = torch.nn.functional.pad(x.double(), (0, 1, 0, 1))
+            ref = torch.nn.functional.conv2d(xp, conv.weight.double(), conv.bias.double(), 2, 0)
+            sc = torch.nn.functional.conv2d(xp.abs(), conv.weight.double().abs(), None, 2, 0)
+            y, st = _lib.conv3x3s2_direct(x, wf, us, float(x.abs().max()), bias=conv.bias, stats_groups=32)
+            assert tuple(y.shape) == (B, cout, H // 2, W // 2) and y.is_contiguous(memory_format=torch.channels_last)
+            assert float(((y.double() - ref).abs() / sc).max()) <= 8e-7, (cin, cout)
+            yd = y.double().permute(0, 2, 3, 1).reshape(B, (H // 2) * (W // 2), 32, cout // 32)
+            st_y = torch.stack([yd.sum((1, 3)), (yd ** 2).sum((1, 3))], -1).flatten()
+            assert torch.allclose(st, st_y, rtol=2e-6, atol=1e-2), float((st - st_y).abs().max())
+            if _lib.gn_nhwc_ok(cin, 32):
+                y2 = _lib.conv3x3s2_direct(x, wf, us, _lib.f16_scales(_lib.gn_stats(x, 32), 1.0, us))
+                ref2 = ref - conv.bias.double()[None, :, None, None]
+                assert float(((y2.double() - ref2).abs() / sc).max()) <= 8e-7, (cin, cout)
+    with pytest.raises(_lib.GqHipError):
+        _lib.conv3x3s2_direct(torch.randn(1, 128, 16, 32, device=DEV).contiguous(memory_format=torch.channels_last), wf, us, 1.0)
+    with pytest.raises(_lib.GqHipError):
+        _lib.conv3s2_weights_f16(torch.randn(96, 128, 3, 3, device=DEV))
+
+
+def test_downsample_direct_and_miopen_routes_agree():
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(9)
+    ds = U.Downsample(128).eval().to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 128, 32, 64, device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        U.DIRECT_CONV_S2 = True
+        y, pb = ds(x)
+        U.DIRECT_CONV_S2 = False
+        y0, pb0 = ds(x)
+        U.DIRECT_CONV_S2 = True
+    assert pb is None and getattr(y, "_gn_stats", None) is not None
+    y0 = y0 if pb0 is None else y0 + pb0[None, :, None, None]
+    assert float((y - y0).abs().max()) <= 2e-5 * float(y0.abs().max())

@@ -1,5 +1,7 @@
-"""What Winograd in the ENCODER does to the indices (it is on by default, unet.WINOGRAD_ENCODER): perturbation of z against the
-direct-conv encoder and against the CPU golden, and the number of index flips on a bs-16 random batch."""
+"""What the encoder's convolution routes do to the indices: perturbation of z against the CPU golden and against the
+all-MIOpen (fp32 implicit GEMM) encoder, and the number of index flips on bs-16 random batches.  Variants: MIOpen only; the
+default (direct fp16 x 3 convolution at the two widest levels, Winograd F(2x2,3x3) below, 1x1 as fp16 x 3 GEMMs); the same with
+F(4x4,3x3) at the 512-channel levels and the middle block."""
 import os, sys
 import numpy as np
 import torch
@@ -18,14 +20,13 @@ NB = int(os.environ.get("GQ_CHECK_BATCHES", "8"))   # bs-16 batches for the flip
 xs = [(torch.rand(16, 3, 256, 256, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last) for _ in range(NB)]
 res = {}
 with torch.no_grad():
-    for name in ("direct", "winograd", "F(4,3) level 0 only", "winograd F(4,3)"):
-        unet.WINOGRAD = name != "direct"
-        if name == "F(4,3) level 0 only":     # the 128-channel convolutions at full resolution (memory-bound with F(2,3))
-            for m in vae.encoder.down[0].modules():
-                if getattr(m, "_gq_wino", False):
-                    m._gq_wino4 = True
-        if name == "winograd F(4,3)":
-            unet.mark_winograd(vae.encoder, f4=True)
+    for name in ("direct", "default", "F(4,3) deep levels"):
+        unet.WINOGRAD = unet.DIRECT_CONV = unet.DIRECT_CONV_1X1 = name != "direct"
+        if name == "F(4,3) deep levels":
+            for part in (vae.encoder.down[2], vae.encoder.down[3], vae.encoder.mid):
+                for m in part.modules():
+                    if getattr(m, "_gq_wino", False):
+                        m._gq_wino4 = True
         z1 = vae.encoder(x1)
         _, i1 = vae.quant(x1)
         z16 = torch.cat([vae.encoder(xb).cpu() for xb in xs])
@@ -34,14 +35,14 @@ with torch.no_grad():
         for _ in range(5): vae.encoder(xs[0])
         torch.cuda.synchronize(); t_enc = (time.perf_counter() - t0) / 5 * 1e3
         res[name] = (z1.cpu(), i1.cpu(), z16, i16, t_enc)
-unet.WINOGRAD = True
+unet.WINOGRAD = unet.DIRECT_CONV = unet.DIRECT_CONV_1X1 = True
 zc = torch.from_numpy(d["z_enc"])
 for name in res:
     z1, i1 = res[name][0], res[name][1]
     print(f"{name:20s} (encoder {res[name][4]:.1f} ms): max|z - z_cpu| = {float((z1 - zc).abs().max()):.3e}; index mismatches vs CPU golden: "
           f"{int((i1.numpy() != d['indices']).sum())} / {i1.numel()}")
 zd = res["direct"][2]
-for name in ("winograd", "F(4,3) level 0 only", "winograd F(4,3)"):
+for name in ("default", "F(4,3) deep levels"):
     zw = res[name][2]
     flips = (res["direct"][3] != res[name][3])
     print(f"{NB} x bs16 {name}: max|z - z_direct| = {float((zw - zd).abs().max()):.3e} (mean |z| {float(zd.abs().mean()):.3f}); "

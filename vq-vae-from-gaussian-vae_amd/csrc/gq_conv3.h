@@ -25,6 +25,8 @@
 //                           registers, two k-steps ahead (three register sets): a wave's load is 1 KB contiguous.
 //                           Epilogue: * mscale + bias (+ residual), store, GroupNorm statistics of the result.
 #pragma once
+#include <type_traits>
+
 #include "gq_common.h"
 #include "gq_wino_gemm.h"
 
@@ -517,6 +519,134 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const Conv1Params
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
+  conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
+}
+
+// ---- 3x3 convolution with stride 2 on an input padded by one zero row / column at the bottom / right (Downsample,
+// unet.py:76-97): out(y, x) = sum_k w[ky][kx] in(2y + ky, 2x + kx).  MIOpen: fp32 implicit GEMM at ~115 TFLOP/s (0.64-0.70 ms
+// per convolution of the encoder).  Here: the same fp16 x 3 machinery on the four PHASE images P_ab(y, x) = in(2y + a, 2x + b):
+// the convolution is the sum of four stride-1 convolutions with 2x2, 2x1, 1x2 and 1x1 kernels (taps (dy, dx) with
+// ky = 2 dy + a, kx = 2 dx + b <= 2) -- nine k-steps per 16 input channels, none wasted.  A staging unit = 16 channels of
+// one phase over the tile's 9 x 33 patch (it fits the stride-1 kernel's LDS buffer and uses its operand addressing);
+// phases are the OUTER loop so that the two 64-byte halves of an input line are fetched by consecutive units.
+// x is not normalised here (Downsample takes the residual stream): scale from the host or from device memory.
+// Wf: k-steps in the order (phase, chunk, tap of the phase) -- _lib.conv3s2_weights_f16.
+struct Conv3S2Params {
+  Conv3Params c;            // H, W: OUTPUT size; tiles over the output
+  const float *x;           // [B][Hin][Win][cin]
+  const float *scales_dev;  // {scale, 1 / (scale * u_scale)} or null
+  float scale;
+  int cin, Hin, Win;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(const Conv3S2Params pp) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  Conv3Params p = pp.c;
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kC3Buf];
+  __shared__ double red[2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  Conv3Tile t;
+  if (!conv3_tile(p, t)) return;
+  if (tid < 128) red[tid] = 0.0;
+  const float scale = pp.scales_dev ? pp.scales_dev[0] : pp.scale;
+  if (pp.scales_dev) p.mscale = pp.scales_dev[1];
+  const int cin = pp.cin, nch = p.nch, Hin = pp.Hin, Win = pp.Win;
+  constexpr int PR = kC3TH + 1, PC = kC3TW + 1, NP = 5;      // patch 9 x 33 pixels; pieces per thread (297 x 4 / 256)
+  const int w = tid & 3, qs = tid >> 2;
+  const float *xb = pp.x + t.b * (long)Hin * Win * cin + 4 * w;
+  int goff[NP], loff[NP];
+  unsigned inb = 0;
+  auto setup_phase = [&](int a, int b) {
+    inb = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = qs + 64 * i;
+      const int qq = q < PR * PC ? q : PR * PC - 1;
+      const int R = qq / PC, X = qq % PC;
+      const int gy = 2 * (t.y0 + R) + a, gx = 2 * (t.x0 + X) + b;
+      const bool in = gy < Hin && gx < Win;
+      const int cy = gy < Hin ? gy : Hin - 1, cx = gx < Win ? gx : Win - 1;
+      goff[i] = (cy * Win + cx) * cin;
+      loff[i] = q < PR * PC ? conv3_lds_off(R, X, w >> 1) + 8 * (w & 1) : -1;
+      inb |= (unsigned)(in ? 1 : 0) << i;
+    }
+  };
+  f32x4 st[NP];
+  auto issue = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) st[i] = *reinterpret_cast<const f32x4 *>(xb + goff[i] + chunk * 16);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (loff[i] < 0) continue;
+      const f32x4 v = st[i] * (((inb >> i) & 1) ? scale : 0.f);
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)v[e];
+        lo[e] = (_Float16)(v[e] - (float)hi[e]);
+      }
+      unsigned char *d = sA + buf * kC3Buf + loff[i];
+      *reinterpret_cast<f16x4 *>(d) = hi;
+      *reinterpret_cast<f16x4 *>(d + kC3Plane) = lo;
+    }
+  };
+  f32x16 acc[4][2];
+  GQ_C3_ZERO_ACC(acc);
+  int aoff[2];
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx) aoff[dx] = conv3_lds_off(4 * wm, c + dx, h);
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + (4 * t.nb + 2 * wn) * 128 * 16;
+  const int wl = lane * 16;
+  const long wstep = (long)p.nnb * (512 * 16);
+  f16x8 bq[4], bn[4];
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+    const unsigned char *s = wbase + ks * wstep;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
+  };
+  const int nks = 9 * nch;
+  int ks = 0, unit = 0;
+  load_b(0, bq);
+  setup_phase(0, 0);
+  issue(0);
+  commit(0);
+  __syncthreads();
+  // one unit: NT taps of phase (a, b) on the staged patch, while the next unit (next chunk, or chunk 0 of the next phase) loads
+  auto run_unit = [&](auto nt_tag, auto a_tag, auto b_tag, int chunk) {
+    constexpr int NT = decltype(nt_tag)::value, PA = decltype(a_tag)::value, PB = decltype(b_tag)::value;
+    const bool last_chunk = chunk + 1 >= nch;
+    const bool more = !(last_chunk && PA == 1 && PB == 1);
+    if (more) {
+      if (last_chunk) setup_phase(PB == 1 ? 1 : PA, PB == 1 ? 0 : 1);      // (0,0) -> (0,1) -> (1,0) -> (1,1)
+      issue(last_chunk ? 0 : chunk + 1);
+    }
+    const unsigned char *A = sA + (unit & 1) * kC3Buf;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      // phase (0,0): (dy, dx) = (ti / 2, ti % 2); (0,1): (ti, 0); (1,0): (0, ti); (1,1): (0, 0)
+      const int ddy = (PA == 0 && PB == 0) ? ti / 2 : (PA == 0 && PB == 1) ? ti : 0;
+      const int ddx = (PA == 0 && PB == 0) ? ti % 2 : (PA == 1 && PB == 0) ? ti : 0;
+      load_b(ks + 1 < nks ? ks + 1 : ks, bn);
+      conv3_tap(A + aoff[ddx], ddy, bq, acc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bq[k] = bn[k];
+      ++ks;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) commit((unit + 1) & 1);
+    ++unit;
+    __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+  for (int chunk = 0; chunk < nch; ++chunk) run_unit(I4{}, I0{}, I0{}, chunk);
+  for (int chunk = 0; chunk < nch; ++chunk) run_unit(I2{}, I0{}, I1{}, chunk);
+  for (int chunk = 0; chunk < nch; ++chunk) run_unit(I2{}, I1{}, I0{}, chunk);
+  for (int chunk = 0; chunk < nch; ++chunk) run_unit(I1{}, I1{}, I1{}, chunk);
   conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
 }
 

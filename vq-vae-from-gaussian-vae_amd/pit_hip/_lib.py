@@ -71,6 +71,8 @@ _SIGNATURES = {
                                          _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "conv1x1_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                       _vp]),
+    "conv3x3s2_f16x3": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                        _i64, _vp]),
     "conv3x3_gn_small_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _i64, _i64,
                                              _i64, _i64, _i64, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -589,6 +591,53 @@ def conv1x1_direct(x, wf, u_scale: float, scale, residual=None, bias=None, stats
         _check(lib().conv1x1_f16x3(x.data_ptr(), _ptr(pre_bias), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), _ptr(residual),
                                    y.data_ptr(), _ptr(ostats), B, H * W, C, cout, max(stats_groups, 1), _stream()),
                "conv1x1_f16x3")
+    return (y, ostats) if stats_groups else y
+
+
+def conv3s2_weights_f16(weight):
+    """Operand-order fp16 x 3 weights of a [Cout, Cin, 3, 3] kernel for conv3x3s2_direct (stride 2): k-steps in the order
+    (phase, chunk, tap of the phase) -- gqhip.h:conv3x3s2_f16x3.  Returns (Wf [9 Cin/16, Cout/32, 2, 64, 8], u_scale)."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cout not in (128, 256, 512) or cin % 16 or tuple(weight.shape[2:]) != (3, 3):
+        raise GqHipError("conv3s2_weights_f16 needs a [128 | 256 | 512, Cin % 16 == 0, 3, 3] kernel")
+    w = weight.detach().float()
+    amax = float(w.abs().max())
+    u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0
+    ws = w * u_scale
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    planes = torch.stack([hi, lo], 0)                                    # [plane, n, k, ky, kx]
+    std = planes.reshape(2, cout // 32, 32, cin // 16, 2, 8, 3, 3).permute(3, 6, 7, 1, 0, 4, 2, 5)   # [chunk, ky, kx, tile, plane, h, c, e]
+    steps = []
+    for a, b in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        taps = [(dy, dx) for dy in range(2 if a == 0 else 1) for dx in range(2 if b == 0 else 1)]
+        for chunk in range(cin // 16):
+            for dy, dx in taps:
+                steps.append(std[chunk, 2 * dy + a, 2 * dx + b])
+    return torch.stack(steps, 0).reshape(9 * (cin // 16), cout // 32, 2, 64, 8).contiguous(), u_scale
+
+
+def conv3x3s2_direct(x, wf, u_scale: float, scale, bias=None, stats_groups: int = 0):
+    """The reference's Downsample convolution -- F.pad(x, (0, 1, 0, 1)) then 3x3 stride 2 -- of a channels_last fp32 HIP tensor
+    as an fp16 x 3 convolution on the four phase images (gqhip.h:conv3x3s2_f16x3).  ``wf, u_scale`` from conv3s2_weights_f16;
+    ``scale``: a float bound >= max|x| or the device float[2] of f16_scales.  Returns y [B, Cout, H/2, W/2] (+ bias), or
+    (y, statistics of y)."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 16 or x.shape[2] % 16 or x.shape[3] % 64:
+        raise GqHipError("conv3x3s2_direct needs a dense channels_last fp32 HIP tensor, C % 16 == 0, H % 16 == 0, W % 64 == 0")
+    B, C, H, W = x.shape
+    cout = wf.shape[1] * 32
+    if wf.shape[0] != 9 * (C // 16):
+        raise GqHipError("conv3x3s2_direct: weights do not match the input channels")
+    if torch.is_tensor(scale):
+        sdev, v_scale, mscale = scale.data_ptr(), 0.0, 0.0
+    else:
+        v_scale = min(2.0 ** math.floor(math.log2(32768.0 / max(float(scale), 1e-30))), 2.0 ** 14)
+        sdev, mscale = None, 1.0 / (v_scale * u_scale)
+    with torch.cuda.device(x.device):
+        y = torch.empty((B, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+        _check(lib().conv3x3s2_f16x3(x.data_ptr(), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), y.data_ptr(),
+                                     _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1), _stream()), "conv3x3s2_f16x3")
     return (y, ostats) if stats_groups else y
 
 

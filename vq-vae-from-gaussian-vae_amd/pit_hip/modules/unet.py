@@ -295,7 +295,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
-        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkv_wf_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
+        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkv_wf_key", "_s2_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -350,6 +350,7 @@ WINOGRAD_C128_GEMM = True
 # channels (128 x 128 level) -- as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the activation once and
 # writes the result once where Winograd moves 6.4 / 10.7 GB of transformed tensors per convolution at 256 x 256
 DIRECT_CONV = True
+DIRECT_CONV_S2 = True      # Downsample (pad + 3x3 stride 2) as an fp16 x 3 convolution on the four phase images of x
 DIRECT_CONV_1X1 = True     # 1x1 shortcut / proj_out convolutions as an fp16 x 3 GEMM with the split of x inside the kernel
 FUSED_CONV_OUT = True      # decoder conv_out (128 -> 3) with norm_out + swish fused in: one VALU kernel
 DIRECT_CONV_OVER_F4 = False   # ... also where the alternative is F(4x4,3x3) (decoder, 256 channels at 128 x 128): A/B switch
@@ -552,6 +553,26 @@ class Downsample(nn.Module):
         """Returns (y, pending_bias) -- see ``_conv``."""
         if not self.with_conv:
             return F.avg_pool2d(x, 2, 2), None
+        conv = self.conv
+        if (DIRECT_CONV_S2 and self.mode == "constant" and FUSED_GN and x.is_cuda and x.dtype == torch.float32
+                and not torch.is_grad_enabled() and conv.out_channels in (128, 256, 512) and conv.in_channels % 16 == 0
+                and conv.bias is not None and x.dim() == 4 and x.shape[2] % 16 == 0 and x.shape[3] % 64 == 0
+                and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+            # pad + stride-2 convolution + bias + the next GroupNorm's statistics as ONE fp16 x 3 kernel on the four phase
+            # images of x (MIOpen: a padding pass + an fp32 implicit GEMM, 0.7-1.0 ms); the scale of x comes, on the device,
+            # from the statistics its producer left behind: |x| <= sqrt(group sum of squares)
+            from .. import _lib
+
+            if _lib.gn_nhwc_ok(x.shape[1], GN_GROUPS) and _lib.gn_nhwc_ok(conv.out_channels, GN_GROUPS):
+                w = conv.weight
+                key = (w.data_ptr(), w._version, w.device)
+                if getattr(conv, "_s2_key", None) != key:
+                    conv._s2_wf, conv._s2_us = _lib.conv3s2_weights_f16(w)
+                    conv._s2_key = key
+                scales = _lib.f16_scales(_stats_of(x, None, GN_GROUPS), 1.0, conv._s2_us)
+                y, st = _lib.conv3x3s2_direct(x, conv._s2_wf, conv._s2_us, scales, bias=conv.bias, stats_groups=GN_GROUPS)
+                y._gn_stats = (st, GN_GROUPS)
+                return y, None
         if self.mode == "constant":
             x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
         else:
