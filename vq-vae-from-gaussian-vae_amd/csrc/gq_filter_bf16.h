@@ -194,6 +194,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   constexpr int S0 = NM >= 6 ? 2 : 1;   // MFMA steps issued before the previous tile's epilogue
+  // Staging schedule of a full chunk (round 2, after the ablation in tools/abl_filter.sh: with the copy of the next chunk
+  // at the chunk's end -- 8 ds_write_b128 per thread, barrier, first operand reads -- the matrix pipes drained at every
+  // chunk boundary: 137 us without the staging, 143 without the barriers, 155-164 with both):
+  //   * the R4 register -> LDS writes of the NEXT chunk are spread over steps W0 .. CT-2 (its buffer is free for the whole
+  //     chunk: the previous barrier came after every read of it; the loads were issued at the chunk's first step);
+  //   * ONE barrier at the end of step CT-2: every wave's writes are visible, and every wave has finished READING the
+  //     current buffer (the operands of tile CT-1 were read at the start of step CT-2);
+  //   * step CT-1 then prefetches tile 0 of the next chunk under its own MFMAs, so no step ever starts with an LDS read.
+  constexpr int W0 = CT / 2 - 1, WSTEPS = CT - 1 - W0;
+  static_assert(CT >= 4 && WSTEPS >= 1, "chunk too short for the staggered staging");
   f32x16 dprev[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -201,69 +211,81 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     for (int r = 0; r < 16; ++r) dprev[rt][r] = NEG_INF;
   int tprev = t_begin - 1;
   bool have_prev = false;
+  u32x4 cv[NCV];
+  if (nchunks > 0) read_ops(lds[0] + h * 32 + c, cv);
 
   for (int ch = 0; ch < nchunks; ++ch) {
     const int tile0 = t_begin + ch * CT;
     if (ch + 1 < nchunks) load_chunk(tile0 + CT);
     const int nt = min(CT, t_full_end - tile0);
-    const u32x4 *base = lds[ch & 1] + h * 32 + c;   // this lane's slot within a vector
+    const u32x4 *base = lds[ch & 1] + h * 32 + c;          // this lane's slot within a vector
+    const u32x4 *nbase = lds[(ch + 1) & 1] + h * 32 + c;
+    u32x4 *wdst = &lds[(ch + 1) & 1][tid];
     if (nt == CT) {
-      u32x4 cv[NCV];
-      read_ops(base, cv);
-      auto step = [&](int tt, auto prev_closes, auto last) {
-        constexpr bool PREV_CLOSES = decltype(prev_closes)::value, LAST = decltype(last)::value;
+      auto step = [&](auto tt_tag) {
+        constexpr int TT = decltype(tt_tag)::value;
+        constexpr bool PREV_CLOSES = (TT % GT) == 0;
         u32x4 cvn[NCV];
-        if constexpr (!LAST) read_ops(base + (tt + 1) * TILE_Q, cvn);
+        if constexpr (TT < CT - 1) read_ops(base + (TT + 1) * TILE_Q, cvn);
+        else read_ops(nbase, cvn);                         // after the barrier of step CT-2: tile 0 of the next chunk
+        // this step's share of the next chunk's copy (stale registers after the last chunk: written, never read)
+#pragma unroll
+        for (int r = 0; r < R4; ++r)
+          if constexpr (TT < CT - 1)
+            if (W0 + (r * WSTEPS) / R4 == TT) wdst[NT * r] = stage[r];
+        // hard fence: hipcc otherwise sinks these reads below the MFMAs of this step (seen in the ISA of the round-1 kernel:
+        // every tile began with its own operand reads and lgkmcnt waits, the prefetch existed only in the source)
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 d[RT];
         tile_mfma_bf16<NV, RT, 0, S0>(cv, rv, d);
         fold(dprev, tprev, PREV_CLOSES);
         tile_mfma_bf16<NV, RT, S0, NM>(cv, rv, d);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) dprev[rt] = d[rt];
-        tprev = tile0 + tt;
-        if constexpr (!LAST) {
+        tprev = tile0 + TT;
 #pragma unroll
-          for (int v = 0; v < NCV; ++v) cv[v] = cvn[v];
-          __builtin_amdgcn_sched_group_barrier(0x100, NCV, 0);
-        }
-        // pin the order: next tile's LDS reads | then every MFMA of this tile followed by a slice of the
-        // PREVIOUS tile's epilogue (its accumulators are long complete; bf16 MFMAs and VALU overlap)
+        for (int v = 0; v < NCV; ++v) cv[v] = cvn[v];
+        // pin the order: every MFMA of this tile followed by a slice of the PREVIOUS tile's epilogue (its accumulators
+        // are long complete; bf16 MFMAs and VALU overlap)
         // (VALU budget slightly under the real count, none after the last MFMA: a slot left over would pull the
         // NEXT step's epilogue -- the accumulators just written -- forward and stall on the MFMA latency)
         constexpr int BUDGET = (PREV_CLOSES ? (TOP4 ? 20 : 16) : 8) * RT, K = NM * RT - 1;
-        constexpr int PER = BUDGET / K, EXTRA = BUDGET % K;   // the first EXTRA MFMAs carry PER+1 VALU slots
+        // the first SKIP MFMAs carry no VALU (the previous tile's last accumulators are not readable yet: hipcc pads with
+        // s_nop otherwise), the next EXTRA carry PER+1 slots, the rest PER
+        constexpr int SKIP = K > 4 ? 2 : 0, SLOTS = K - SKIP;
+        constexpr int PER = BUDGET / SLOTS, EXTRA = BUDGET % SLOTS;
+#pragma unroll
+        for (int k = 0; k < SKIP; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
         for (int k = 0; k < EXTRA; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, PER + 1, 0);
         }
 #pragma unroll
-        for (int k = EXTRA; k < K; ++k) {
+        for (int k = EXTRA; k < SLOTS; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           if constexpr (PER > 0) __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TT == CT - 2) __syncthreads();
       };
       // one step per tile of the chunk, fully unrolled (the tags are compile-time constants)
-      auto run_all = [&](auto... is) {
-        (step(decltype(is)::value, std::bool_constant<(decltype(is)::value % GT) == 0>{},
-              std::bool_constant<decltype(is)::value == CT - 1>{}), ...);
-      };
+      auto run_all = [&](auto... is) { (step(is), ...); };
       call_with_indices(run_all, std::make_integer_sequence<int, CT>{});
       have_prev = true;
     } else {
+      // the one partial chunk (always the last): staged by the previous chunk (or the prologue), plain loop
       if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);
       have_prev = false;
       for (int tt = 0; tt < nt; ++tt) {
-        u32x4 cv[NCV];
-        read_ops(base + tt * TILE_Q, cv);
+        u32x4 cw[NCV];
+        read_ops(base + tt * TILE_Q, cw);
         f32x16 d[RT];
-        tile_mfma_bf16<NV, RT, 0, NM>(cv, rv, d);
+        tile_mfma_bf16<NV, RT, 0, NM>(cw, rv, d);
         fold(d, tile0 + tt, ((tile0 + tt) % GT) == GT - 1);
       }
     }
-    if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
-    __syncthreads();
   }
   if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);
 #ifdef GQHIP_CLOCK_STAMPS
