@@ -208,6 +208,13 @@ int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W
 int wino_in_nhwc_f16x2(const float *x, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
                        void *stream);
 int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, int64_t tiles, void *stream);
+/* The wider levels (Cin % 32 == 0, Cout % 128 == 0, tiles % 256 == 0; the SD3-UNet's 256- and 512-channel convolutions,
+ * reference pit/modules/unet.py:142, :149): M [P, tiles, Cout] fp32 = V2 (x) U with Wf [P, Cin/16, Cout/32, 2, 64, 8] fp16 =
+ * (U_h, U_l) of U * u_scale in MFMA operand order (lane (c, h) of column tile nt holds k = 16 chunk + 8 h .. + 7 of column
+ * 32 nt + c).  Replaces the hipBLASLt GEMM over K' = 3 Cin of V3 = [h | h | l]: same splits, same three products, fp32
+ * accumulation; a third less traffic on V. */
+int wino_gemm_f16x2(const void *V2, const void *Wf, float *M, int64_t P, int64_t tiles, int64_t Cin, int64_t Cout,
+                    void *stream);
 /* Direct 3x3 convolution (stride 1, zero padding 1) Cin -> Cout (128 or 256) channels, channels_last, as an implicit
  * GEMM on the fp16 matrix cores with the fp16 x 3 scheme above (two-term splits of both operands, three products, fp32
  * accumulation): the convolutions of the 256 x 256 level and the encoder's 128 x 128 level (reference pit/modules/unet.py:142,

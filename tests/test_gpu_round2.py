@@ -372,6 +372,73 @@ def test_winograd_f16x3_gemm_is_as_accurate_as_the_fp32_gemm():
                 assert torch.allclose(st_a, st_b, rtol=1e-4, atol=1e-2)
 
 
+def test_wino_gemm_f16x2_wider_levels_match_fp64_and_the_library_route():
+    """libgqhip's own Winograd GEMM for the 256- / 512-channel levels ([h | l] operand, weights in MFMA operand order, three
+    products in the kernel): (1) the GEMM alone against fp64 of the same split operands and against the library's
+    K-concatenated fp16 GEMM, incl. Cin != Cout; (2) through wino_conv3x3 (both tile sizes, fused GroupNorm) against an
+    fp64 convolution: no worse than the library route."""
+    import torch.nn.functional as F
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(11)
+    L = _lib.lib()
+    for P, tiles, cin, cout in ((3, 512, 256, 256), (2, 256, 512, 512), (2, 768, 512, 256), (2, 256, 256, 512), (1, 256, 32, 128)):
+        V = torch.randn(P, tiles, cin, device=DEV) * 40.0
+        Uw = torch.randn(P, cin, cout, device=DEV) * 3.0
+        vh = V.half(); vl = (V - vh.float()).half()
+        uh = Uw.half(); ul = (Uw - uh.float()).half()
+        V2 = torch.cat([vh, vl], 2).contiguous()
+        Wf = _lib.wino_weights_operand_order(uh, ul)
+        M = torch.full((P, tiles, cout), float("nan"), device=DEV)
+        _lib._check(L.wino_gemm_f16x2(V2.data_ptr(), Wf.data_ptr(), M.data_ptr(), P, tiles, cin, cout,
+                                      torch.cuda.current_stream().cuda_stream), "wino_gemm_f16x2")
+        r64 = (torch.bmm(vh.double(), uh.double()) + torch.bmm(vh.double(), ul.double()) + torch.bmm(vl.double(), uh.double()))
+        sc = torch.bmm(V.abs().double(), Uw.abs().double())
+        e = float(((M.double() - r64).abs() / sc).max())
+        lib3 = torch.bmm(torch.cat([vh, vh, vl], 2), torch.cat([uh, ul, uh], 1), out_dtype=torch.float32)
+        e_lib = float(((lib3.double() - r64).abs() / sc).max())
+        print(f"wino_gemm_f16x2 {P} x {tiles} x {cin} -> {cout}: err {e:.2e} of sum|a||b| (library K-concatenated GEMM {e_lib:.2e})")
+        assert torch.isfinite(M).all() and e <= 3e-7, e
+    # invalid shapes are refused, not mis-tiled
+    assert L.wino_gemm_f16x2(V2.data_ptr(), Wf.data_ptr(), M.data_ptr(), 1, 255, 32, 128, None) != 0
+    assert L.wino_gemm_f16x2(V2.data_ptr(), Wf.data_ptr(), M.data_ptr(), 1, 256, 48, 128, None) != 0
+    assert L.wino_gemm_f16x2(V2.data_ptr(), Wf.data_ptr(), M.data_ptr(), 1, 256, 32, 64, None) != 0
+
+    # through the convolution: sizes for which own_gemm_fits() holds (>= one full round of 512 blocks)
+    for cin, cout, B, H, W in ((256, 256, 8, 64, 64), (512, 512, 4, 64, 64)):
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+        norm = torch.nn.GroupNorm(32, cin, eps=1e-6).to(DEV)
+        with torch.no_grad():
+            norm.weight.uniform_(0.5, 1.5); norm.bias.uniform_(-0.3, 0.3)
+        x = torch.randn(B, cin, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            a = F.silu(norm(x))
+            ref = F.conv2d(a.double(), conv.weight.double(), None, 1, 1)
+            scale = float(ref.abs().mean())
+            stats = _lib.gn_stats(x, 32)
+            gn = (norm.weight, norm.bias, 32, 1e-6, True, stats, None)
+            for f4 in (False, True):
+                Uw = U._wino_weights(conv, f4)
+                u3, us = U._wino_weights_f16(conv, f4)
+                wf2 = conv._wino_wf2
+                tiles = B * (H // (4 if f4 else 2)) * (W // (4 if f4 else 2))
+                assert wf2 is not None and (_lib.own_gemm_fits(Uw.shape[0], tiles, cout, cin) or cin > 256 or f4)
+                bound = U._gn_act_bound(norm, x)
+                y_lib = _lib.wino_conv3x3(x, Uw, gn=gn, f16=(u3, us, bound, None, None))
+                y_own = _lib.wino_conv3x3(x, Uw, gn=gn, f16=(u3, us, bound, None, wf2))
+                e_lib = float((y_lib.double() - ref).abs().max()) / scale
+                e_own = float((y_own.double() - ref).abs().max()) / scale
+                print(f"F({4 if f4 else 2},3) {cin}->{cout}: library f16x3 {e_lib:.2e}, own GEMM {e_own:.2e}, "
+                      f"max diff {float((y_own - y_lib).abs().max()) / scale:.2e}")
+                assert e_own <= 1.5 * e_lib + 1e-7, (e_own, e_lib)
+                res = torch.randn_like(y_own)
+                ya, sa = _lib.wino_conv3x3(x, Uw, gn=gn, residual=res, bias=conv.bias, stats_groups=32, f16=(u3, us, bound, None, None))
+                yb, sb = _lib.wino_conv3x3(x, Uw, gn=gn, residual=res, bias=conv.bias, stats_groups=32, f16=(u3, us, bound, None, wf2))
+                assert float((ya - yb).abs().max()) <= 2e-5 * max(scale, 1.0) * (10 if f4 else 1)
+                assert torch.allclose(sa, sb, rtol=1e-5, atol=1e-2)
+
+
 def test_gn_act_bound_is_a_bound_and_unet_agrees_with_fp32_gemms():
     from pit_hip.modules import unet as U
 

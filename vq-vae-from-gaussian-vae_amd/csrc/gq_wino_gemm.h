@@ -123,4 +123,115 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_c128_f16x2_kernel(const Wino
   }
 }
 
+// ---- the Winograd batched GEMM of the wider levels (Cin, Cout in {256, 512}): M[p] = V[p] x U[p], [tiles, Cin] x [Cin, Cout].
+// The library route (ONE hipBLASLt fp16 GEMM over K' = 3 Cin of V3 = [h | h | l]) runs these at 0.6-0.95 PFLOP/s executed
+// and 3-4.4 TB/s: the 256-channel level is HBM-bound on V3 + M, the 512-channel ones sit between both limits
+// (tools/gemm_shapes_step.py).  This kernel reads V2 = [h | l] (4 instead of 6 bytes per element, 9 instead of 13.5 out of
+// the input transform) and forms the three products itself -- the machinery of conv1x1_f16x3_kernel (gq_conv3.h) without its
+// conversions: block = 256 rows x 128 output columns, 4 waves (wave = 128 rows x 64 columns = eight 32 x 32 accumulators),
+// two blocks per CU; a stage = 32 k of both planes (32 KiB: [k16 chunk][plane][row] x 32 bytes, the two 16-byte halves of a
+// row swapped on odd groups of 8 rows: conflict-free ds_read_b128), double buffered; the weights come straight from L2 in
+// MFMA operand order Wf [P][Cin/16][Cout/32][plane][lane][8] (a wave's load is 1 KiB contiguous), one k-step ahead.
+// Workgroups go round-robin over the XCDs; the Cout/128 blocks that share a row tile sit next to each other on one XCD.
+struct WinoGemm2Params {
+  const _Float16 *V2;   // [P][tiles][2 cin]  (h[0..cin) | l[0..cin)) of V * v_scale
+  const _Float16 *Wf;   // [P][cin/16][cout/32][2][64][8]  operand-order (U_h, U_l) of U * u_scale
+  float *M;             // [P][tiles][cout]
+  long tiles;           // a multiple of 256
+  int cin, cout, nnb;   // nnb = cout / 128
+  long mtiles;          // tiles / 256
+  long ntile_total;     // P * mtiles
+  long tiles_per_xcd;   // ceil(ntile_total / 8)
+};
+
+__global__ __launch_bounds__(256, 2) void wino_gemm_f16x2_kernel(const WinoGemm2Params p) {
+  // the four (k16 chunk, plane) regions of a stage are 64 bytes apart modulo 256: the loader's ds_write_b128 of a wave (8 rows x
+  // 8 pieces: 2 rows x 32 bytes in each of the four regions per 16 lanes) then covers all 64 banks instead of hitting 16 banks
+  // four times (at an 8 KiB region stride the kernel was bound by exactly these writes: 0.66 PFLOP/s)
+  constexpr int kPlane = 256 * 32 + 64, kChunk = 2 * kPlane, kStage = 2 * kChunk;   // bytes
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kStage];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const long vb = blockIdx.x, kq = vb >> 3;
+  const int nb = (int)(kq % p.nnb);
+  const long tile = (vb & 7) * p.tiles_per_xcd + kq / p.nnb;
+  if (tile >= p.ntile_total) return;
+  const long pos = tile / p.mtiles, m0 = (tile % p.mtiles) * 256;
+  const int cin = p.cin, nst = cin / 32;
+  // loader: thread -> 16-byte piece w8 = tid & 7 of a row's stage (plane w8 >> 2, k16 chunk (w8 >> 1) & 1, half w8 & 1),
+  // rows (tid >> 3) + 32 i
+  const int w8 = tid & 7, r0 = tid >> 3, pl = w8 >> 2, jc = (w8 >> 1) & 1, jh = w8 & 1;
+  const _Float16 *src = p.V2 + ((pos * p.tiles + m0 + r0) * 2L * cin) + pl * cin + 16 * jc + 8 * jh;
+  const int loff = jc * kChunk + pl * kPlane + r0 * 32 + 16 * (jh ^ ((r0 >> 3) & 1));
+  const long rstride = 64L * cin;   // 32 rows, halfs
+  f16x8 st[8];
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = *reinterpret_cast<const f16x8 *>(src + i * rstride + stage * 32);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f16x8 *>(sA + buf * kStage + loff + i * 1024) = st[i];
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      acc[rr][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int aoff = (4 * wm) * 1024 + c * 32 + 16 * (h ^ ((c >> 3) & 1));
+  const long wstep = (long)p.nnb * (512 * 16);   // bytes per k-step
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + pos * (cin / 16) * wstep +
+                               (4 * nb + 2 * wn) * 128 * 16;
+  const int wl = lane * 16;
+  f16x8 b0[4], b1[4];
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+    const unsigned char *s = wbase + ks * wstep;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
+  };
+  auto kstep = [&](const unsigned char *A, const f16x8 (&bq)[4]) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + aoff + rr * 1024);
+      const f16x8 al = *reinterpret_cast<const f16x8 *>(A + aoff + rr * 1024 + kPlane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j + 1], acc[rr][j], 0, 0, 0);
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[2 * j], acc[rr][j], 0, 0, 0);
+      }
+    }
+  };
+  const int nks = 2 * nst;
+  load_b(0, b0);
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const bool more = s + 1 < nst;
+    const unsigned char *A = sA + (s & 1) * kStage;
+    load_b(2 * s + 1, b1);
+    if (more) issue(s + 1);
+    kstep(A, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(2 * s + 2 < nks ? 2 * s + 2 : nks - 1, b0);
+    kstep(A + kChunk, b1);
+    if (more) commit((s + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  // ---- store: register r of lane (c, h) = row (4 wm + rr) * 32 + (r & 3) + 8 (r >> 2) + 4 h, column (2 wn + j) * 32 + c ----
+  float *Mp = p.M + ((pos * p.tiles + m0 + 4 * wm * 32 + 4 * h) * (long)p.cout) + nb * 128 + c;
+  const long cs = p.cout;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float *base = Mp + (rr * 32L) * cs + (2 * wn + j) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) base[(long)((r & 3) + 8 * (r >> 2)) * cs] = acc[rr][j][r];
+    }
+}
+
 }  // namespace gqhip

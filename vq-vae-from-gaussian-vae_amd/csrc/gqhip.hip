@@ -805,6 +805,23 @@ int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, i
   return check_launch();
 }
 
+int wino_gemm_f16x2(const void *V2, const void *Wf, float *M, int64_t P, int64_t tiles, int64_t Cin, int64_t Cout,
+                    void *stream) {
+  if (P < 1 || tiles < 0 || tiles > 0x3fffffff || tiles % 256 != 0 || Cin < 32 || Cin % 32 != 0 || Cin > 4096 || Cout < 128 ||
+      Cout % 128 != 0 || Cout > 4096)
+    return GQHIP_ERR_INVALID_ARG;
+  if (tiles == 0) return GQHIP_OK;
+  if (!V2 || !Wf || !M) return GQHIP_ERR_INVALID_ARG;
+  WinoGemm2Params wp{};
+  wp.V2 = static_cast<const _Float16 *>(V2); wp.Wf = static_cast<const _Float16 *>(Wf); wp.M = M; wp.tiles = tiles;
+  wp.cin = (int)Cin; wp.cout = (int)Cout; wp.nnb = (int)(Cout / 128);
+  wp.mtiles = tiles / 256; wp.ntile_total = P * wp.mtiles; wp.tiles_per_xcd = (wp.ntile_total + 7) / 8;
+  const long blocks = 8 * wp.tiles_per_xcd * wp.nnb;
+  if (blocks > 0x7fffffffL) return GQHIP_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(wino_gemm_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), wp);
+  return check_launch();
+}
+
 int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64_t C, int64_t HW, int64_t groups,
                  double *stats_out, void *stream) {
   if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "wino_in_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
     "wino_in_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
     "wino_gemm_c128_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "wino_gemm_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "wino_in_gn_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
     "wino_in_gn_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
@@ -451,8 +452,12 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
             amp = 100.0 if f4 else 4.0
             v_scale = 2.0 ** math.floor(math.log2(32768.0 / (amp * max(float(x_bound), 1e-30))))
             v_scale = min(v_scale, 2.0 ** 14)
-            if C == 128 and cout == 128 and len(f16) > 3 and f16[3] is not None:
-                # HBM-bound case: [h | l] operand (4 bytes per element) + our own GEMM kernel forming the three products
+            use_c128 = C == 128 and cout == 128 and len(f16) > 3 and f16[3] is not None
+            use_own = (not use_c128 and len(f16) > 4 and f16[4] is not None and tiles % 256 == 0
+                       and own_gemm_fits(U.shape[0], tiles, cout, C))
+            if use_c128 or use_own:
+                # [h | l] operand (4 bytes per element) + our own GEMM kernel forming the three products: the HBM-bound
+                # 128-channel case (wino_gemm_c128_f16x2) and the wider levels (wino_gemm_f16x2: weights in operand order)
                 V = torch.empty((U.shape[0], tiles, 2 * C), dtype=torch.float16, device=x.device)
                 if gn is not None:
                     gamma, beta, groups, eps, silu, stats, pre_bias = gn
@@ -463,8 +468,12 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
                     _check(L.wino_in_nhwc_f16x2(x.data_ptr(), V.data_ptr(), B, H, W, C, t, float(v_scale), _stream()),
                            "wino_in_nhwc_f16x2")
                 M = torch.empty((U.shape[0], tiles, cout), dtype=torch.float32, device=x.device)
-                _check(L.wino_gemm_c128_f16x2(V.data_ptr(), f16[3].data_ptr(), M.data_ptr(), U.shape[0], tiles, _stream()),
-                       "wino_gemm_c128_f16x2")
+                if use_c128:
+                    _check(L.wino_gemm_c128_f16x2(V.data_ptr(), f16[3].data_ptr(), M.data_ptr(), U.shape[0], tiles, _stream()),
+                           "wino_gemm_c128_f16x2")
+                else:
+                    _check(L.wino_gemm_f16x2(V.data_ptr(), f16[4].data_ptr(), M.data_ptr(), U.shape[0], tiles, C, cout,
+                                             _stream()), "wino_gemm_f16x2")
                 V = None
             else:
                 V = torch.empty((U.shape[0], tiles, 3 * C), dtype=torch.float16, device=x.device)
@@ -504,6 +513,29 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
         _check((L.wino4_out_nhwc_f32 if f4 else L.wino_out_nhwc_f32)(M.data_ptr(), y.data_ptr(), B, H, W, cout,
                                                                      float(mscale), _stream()), "wino_out_nhwc_f32")
     return y
+
+
+def own_gemm_fits(positions: int, tiles: int, cout: int, cin: int = 256) -> bool:
+    """Where wino_gemm_f16x2 (256 x 128 blocks, two per CU) beats the library's K-concatenated GEMM: the 256-channel level,
+    whose GEMM is HBM-bound on V + M (1.05-1.10x alone, and the input transform writes 9 instead of 13.5 bytes per
+    element); at 512 channels the library's 256 x 256 tiles win (0.83-1.02x, tools/wino_gemm2_bench.py).  The grid must fill
+    whole rounds of the chip reasonably (36 x 1024 tiles x 512 channels = 576 blocks = 1.125 rounds would not)."""
+    if OWN_GEMM_MAX_CH and (cin > OWN_GEMM_MAX_CH or cout > OWN_GEMM_MAX_CH):
+        return False
+    blocks = positions * (tiles // 256) * (cout // 128)
+    rounds = blocks / 512.0
+    return rounds >= 1.0 and rounds / math.ceil(rounds) >= 0.85
+
+
+OWN_GEMM_MAX_CH = 256   # 0: no channel limit (A/B switch)
+
+
+def wino_weights_operand_order(h, l):
+    """(U_h, U_l) [T, Cin, Cout] fp16 -> Wf [T, Cin/16, Cout/32, 2, 64, 8]: the B operands of v_mfma_f32_32x32x16_f16 as
+    wino_gemm_f16x2 loads them (lane (c, hh) of column tile nt: k = 16 chunk + 8 hh .. + 7 of column 32 nt + c)."""
+    T, cin, cout = h.shape
+    planes = torch.stack([h, l], 0).reshape(2, T, cin // 16, 2, 8, cout // 32, 32)   # [pl, t, kc, hh, e, nt, c]
+    return planes.permute(1, 2, 5, 0, 3, 6, 4).reshape(T, cin // 16, cout // 32, 2, 64, 8).contiguous()
 
 
 DIRECT_CONV_FUSED_SPLIT = True   # conv3x3_direct: GroupNorm + split inside the convolution kernel (A/B switch)

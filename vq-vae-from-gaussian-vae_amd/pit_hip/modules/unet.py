@@ -81,7 +81,7 @@ def _f16_args(conv: nn.Conv2d, x: torch.Tensor, f4: bool):
     if not WINOGRAD_F16X3 or bound is None:
         return None
     u3, u_scale = _wino_weights_f16(conv, f4)
-    return u3, u_scale, bound, (conv._wino_u2t if WINOGRAD_C128_GEMM else None)
+    return u3, u_scale, bound, (conv._wino_u2t if WINOGRAD_C128_GEMM else None), (conv._wino_wf2 if WINOGRAD_OWN_GEMM else None)
 
 
 def _f16_args_gn(conv: nn.Conv2d, norm: nn.GroupNorm, x: torch.Tensor, f4: bool):
@@ -90,7 +90,8 @@ def _f16_args_gn(conv: nn.Conv2d, norm: nn.GroupNorm, x: torch.Tensor, f4: bool)
     if not WINOGRAD_F16X3:
         return None
     u3, u_scale = _wino_weights_f16(conv, f4)
-    return u3, u_scale, _gn_act_bound(norm, x), (conv._wino_u2t if WINOGRAD_C128_GEMM else None)
+    return (u3, u_scale, _gn_act_bound(norm, x), (conv._wino_u2t if WINOGRAD_C128_GEMM else None),
+            (conv._wino_wf2 if WINOGRAD_OWN_GEMM else None))
 
 
 def _conv(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
@@ -272,6 +273,13 @@ def _wino_weights_f16(conv: nn.Conv2d, f4: bool = False):
         # 128 -> 128 channels: (U_h^T, U_l^T) [T, 2, Cout, Cin] for wino_gemm_c128_f16x2 (k contiguous per output column)
         conv._wino_u2t = (torch.stack([h, l], 1).transpose(2, 3).contiguous()
                           if WINOGRAD_C128_GEMM and tuple(U.shape[1:]) == (128, 128) else None)
+        # wider levels: (U_h, U_l) in MFMA operand order for wino_gemm_f16x2 (the [h | l] route beyond 128 channels)
+        if WINOGRAD_OWN_GEMM and conv._wino_u2t is None and U.shape[1] % 32 == 0 and U.shape[2] % 128 == 0:
+            from .. import _lib
+
+            conv._wino_wf2 = _lib.wino_weights_operand_order(h, l)
+        else:
+            conv._wino_wf2 = None
         conv._wino_u_scale = u_scale
         conv._wino_f16_key = conv._wino_key
     return conv._wino_u3, conv._wino_u_scale
@@ -346,6 +354,9 @@ WINOGRAD_F16X3 = True
 # 128 -> 128-channel Winograd GEMMs (256 x 256 level: HBM-bound at K = N = 128) through libgqhip's own kernel on the
 # [h | l] operand (4 instead of 6 bytes per element of V): same splits and products as the library route
 WINOGRAD_C128_GEMM = True
+# ... and the 256- / 512-channel Winograd GEMMs through libgqhip's wino_gemm_f16x2 on the same [h | l] operand (weights in MFMA
+# operand order, three products in the kernel) where its grid fills the chip (_lib.own_gemm_fits); else the library GEMM
+WINOGRAD_OWN_GEMM = True
 # 3x3 convolutions into 128 channels (256 x 256 level) -- and, where the alternative is F(2x2,3x3) (the encoder), into 256
 # channels (128 x 128 level) -- as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the activation once and
 # writes the result once where Winograd moves 6.4 / 10.7 GB of transformed tensors per convolution at 256 x 256
