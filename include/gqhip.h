@@ -325,6 +325,17 @@ int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64
  * (image, group)) that the producer of x left behind: bound = sqrt(max sum of squares) >= max|x| rigorously, no host sync. */
 int upconv_im2col_nhwc_f16x3(const float *x, void *A3, int64_t B, int64_t H, int64_t W, int64_t C,
                              const float *scales_dev, void *stream);
+/* Single-head attention softmax(q k^T C^-1/2) v (reference pit/modules/unet.py:185-206: F.scaled_dot_product_attention on
+ * [B, 1, L, C]) as two fp16 GEMMs with fp32 accumulation over K axes of two-term fp16 splits, fp32 results:
+ *   attn_split_qkv_f16x3   qkv [B, L, 3C] fp32 (q | k | v per token) -> Q3 [B, L, 3C] = [q_h | q_h | q_l] of q * sq,
+ *                          K3 [B, L, 3C] = [k_h | k_l | k_h] of k * sq, V3 [B, 3L, C] = [v_h ; v_l ; v_h] of v * sv
+ *                          (sq, sv: powers of two keeping the operands inside fp16's range; C % 4 == 0);
+ *   attn_softmax_split_f16x3  S' [rows, L] fp32 (= Q3 K3^T = sq^2 q k^T) -> P3 [rows, 3L] = [p_h | p_h | p_l] of
+ *                          softmax(S' * factor) * 2^14, factor = C^-1/2 / sq^2; L % 64 == 0, L <= 4096.
+ * The caller multiplies Q3 K3^T and P3 V3 (library fp16 GEMMs, fp32 out) and scales the result by 1 / (2^14 sv). */
+int attn_split_qkv_f16x3(const float *qkv, void *Q3, void *K3, void *V3, int64_t B, int64_t L, int64_t C, float sq, float sv,
+                         void *stream);
+int attn_softmax_split_f16x3(const float *S, void *P3, int64_t rows, int64_t L, float factor, void *stream);
 int f16_scales_from_gn_stats(const double *stats, int64_t n_bg, double amp, double u_scale, float *scales_out,
                              void *stream);
 

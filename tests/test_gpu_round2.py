@@ -805,3 +805,56 @@ def test_downsample_direct_and_miopen_routes_agree():
     assert pb is None and getattr(y, "_gn_stats", None) is not None
     y0 = y0 if pb0 is None else y0 + pb0[None, :, None, None]
     assert float((y - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+
+
+def test_attention_f16x3_matches_fp64_attention():
+    """softmax(q k^T C^-1/2) v as two fp16 GEMMs over K axes of two-term fp16 splits (attn_split_qkv_f16x3 + library GEMM +
+    attn_softmax_split_f16x3 + library GEMM): against fp64 attention the error must be at the level of the fp32 matmul /
+    softmax / matmul route, with tight and with very loose operand bounds (the power-of-two scales are exact), at both token
+    counts of the bench configurations (1024; 4096 at 512 x 512)."""
+    from pit_hip import _lib
+
+    torch.manual_seed(21)
+    for B, L, C, amp in ((2, 1024, 512, 1.0), (1, 4096, 512, 3.0), (3, 256, 64, 0.2), (2, 64, 32, 1.0)):
+        qkv = (amp * torch.randn(B, L, 3 * C, device=DEV)).contiguous()
+        q, k, v = qkv[..., :C].double(), qkv[..., C:2 * C].double(), qkv[..., 2 * C:].double()
+        ref = torch.softmax(q @ k.transpose(1, 2) * C ** -0.5, -1) @ v
+        q32, k32, v32 = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        y32 = torch.matmul(torch.softmax(torch.matmul(q32, k32.transpose(1, 2)) * C ** -0.5, -1), v32)
+        scale = float(ref.abs().max())
+        e32 = float((y32.double() - ref).abs().max()) / scale
+        qb, vb = float(qkv[..., :2 * C].abs().max()), float(qkv[..., 2 * C:].abs().max())
+        for loose in (1.0, 300.0):
+            O, ps = _lib.attention_f16x3(qkv, qb * loose, vb * loose)
+            assert O.dtype == torch.float32 and tuple(O.shape) == (B, L, C) and torch.isfinite(O).all()
+            e16 = float((O.double() * ps - ref).abs().max()) / scale
+            print(f"attention B{B} L{L} C{C} amp {amp:g} bounds x{loose:g}: fp32 route {e32:.2e}, f16x3 {e16:.2e}")
+            assert e16 <= 2.0 * e32 + 2e-6, (e16, e32)
+    with pytest.raises(_lib.GqHipError):
+        _lib.attention_f16x3(torch.randn(1, 100, 96, device=DEV), 1.0, 1.0)     # token count without an instantiation
+
+
+def test_attn_block_f16x3_and_fp32_routes_agree():
+    """AttnBlock with the attention GEMMs on the fp16 x 3 route vs the fp32 matmul route (same projections, same proj_out
+    kernel): the block outputs and the GroupNorm statistics they leave behind agree to fp32 rounding level."""
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(22)
+    blk = U.AttnBlock(512).to(DEV).eval().to(memory_format=torch.channels_last)
+    x = torch.randn(4, 512, 32, 32, device=DEV).contiguous(memory_format=torch.channels_last)
+    old = U.ATTN_F16X3
+    try:
+        with torch.no_grad():
+            U.ATTN_F16X3 = False
+            y0 = blk(x)
+            U.ATTN_F16X3 = True
+            y1 = blk(x)
+    finally:
+        U.ATTN_F16X3 = old
+    d = float((y1 - y0).abs().max())
+    print(f"AttnBlock f16x3 vs fp32 attention GEMMs: max abs diff {d:.2e} (|y| max {float(y0.abs().max()):.2f})")
+    assert d <= 2e-5 * max(float(y0.abs().max()), 1.0)
+    s0, s1 = getattr(y0, "_gn_stats", None), getattr(y1, "_gn_stats", None)
+    assert (s0 is None) == (s1 is None)
+    if s0 is not None:
+        assert torch.allclose(s0[0], s1[0], rtol=1e-5, atol=1e-2)

@@ -1006,4 +1006,99 @@ __global__ __launch_bounds__(256) void from_u16_kernel(const uint16_t *__restric
   if (i < count) idx[i] = (int64_t)in[i];
 }
 
+// ---- single-head attention of the deepest level (pit/modules/unet.py:185-206) on the fp16 matrix cores, fp32 results:
+// softmax(q k^T c^-1/2) v as TWO library fp16 GEMMs with fp32 accumulation whose K axes carry the three products of
+// two-term fp16 splits (the scheme of the Winograd GEMMs) instead of two fp32 GEMMs (a split-bf16 emulation on gfx950 at
+// ~120 TFLOP/s).  attn_split_qkv_kernel prepares the operands of both GEMMs from the fused q|k|v projection; the softmax
+// between them writes its result directly as the split operand of the second GEMM.
+//   qkv [B][L][3C] fp32 (q | k | v per token)  ->  Q3 [B][L][3C] = [q_h | q_h | q_l] of q * sq
+//                                                   K3 [B][L][3C] = [k_h | k_l | k_h] of k * sq     (S' = Q3 K3^T = sq^2 q k^T)
+//                                                   V3 [B][3L][C] = [v_h ; v_l ; v_h] of v * sv     (rows stacked along K)
+// thread = 4 channels of one token.
+__global__ __launch_bounds__(256) void attn_split_qkv_kernel(const float *__restrict__ qkv, _Float16 *__restrict__ Q3,
+                                                             _Float16 *__restrict__ K3, _Float16 *__restrict__ V3, long L,
+                                                             int C4, float sq, float sv, long total) {
+  const int C = 4 * C4;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int q4 = (int)(t % C4);
+    const long tok = t / C4;            // b * L + l
+    const long b = tok / L, l = tok % L;
+    const float *src = qkv + tok * 3 * C + 4 * q4;
+    f32x4 q = *reinterpret_cast<const f32x4 *>(src) * sq;
+    f32x4 k = *reinterpret_cast<const f32x4 *>(src + C) * sq;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(src + 2 * C) * sv;
+    f16x4 qh, ql, kh, kl, vh, vl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qh[e] = (_Float16)q[e]; ql[e] = (_Float16)(q[e] - (float)qh[e]);
+      kh[e] = (_Float16)k[e]; kl[e] = (_Float16)(k[e] - (float)kh[e]);
+      vh[e] = (_Float16)v[e]; vl[e] = (_Float16)(v[e] - (float)vh[e]);
+    }
+    f16x4 *qo = reinterpret_cast<f16x4 *>(Q3 + tok * 3 * C) + q4;
+    qo[0] = qh; qo[C4] = qh; qo[2 * C4] = ql;
+    f16x4 *ko = reinterpret_cast<f16x4 *>(K3 + tok * 3 * C) + q4;
+    ko[0] = kh; ko[C4] = kl; ko[2 * C4] = kh;
+    f16x4 *vo = reinterpret_cast<f16x4 *>(V3 + (b * 3 * L + l) * C) + q4;
+    vo[0] = vh; vo[L * C4] = vl; vo[2 * L * C4] = vh;
+  }
+}
+
+// Row softmax of S' * factor (factor = c^-1/2 / sq^2) written as the split operand of the second GEMM:
+// P3 [rows][3L] = [p_h | p_h | p_l] of p * 2^14 (p <= 1).  One wave per row, the row in registers (L = 64 * NPL <= 4096).
+template <int NPL>
+__global__ __launch_bounds__(256) void attn_softmax_split_kernel(const float *__restrict__ S, _Float16 *__restrict__ P3,
+                                                                 long rows, float factor) {
+  constexpr int L = 64 * NPL;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *s = S + row * L;
+  float v[NPL];
+  float m = -__builtin_inff();
+  if constexpr (NPL % 4 == 0) {      // lane owns runs of 4 consecutive elements: 16-byte loads, 8-byte stores
+#pragma unroll
+    for (int i = 0; i < NPL / 4; ++i) {
+      const f32x4 x = *reinterpret_cast<const f32x4 *>(s + (i * 64 + lane) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[4 * i + e] = x[e] * factor; m = fmaxf(m, v[4 * i + e]); }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { v[i] = s[i * 64 + lane] * factor; m = fmaxf(m, v[i]); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { v[i] = expf(v[i] - m); sum += v[i]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 16384.0f / sum;
+  _Float16 *p = P3 + row * 3 * L;
+  if constexpr (NPL % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < NPL / 4; ++i) {
+      f16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[4 * i + e] * inv;
+        // opaque: hipcc otherwise forms h as v_fma_mixlo_f16(v, inv) -- ONE rounding of the exact product -- for the residual
+        // while the stored h is the conversion of the fp32 product: at double-rounding ties h + l was one fp16 ulp off
+        asm volatile("" : "+v"(x));
+        h[e] = (_Float16)x; l[e] = (_Float16)(x - (float)h[e]);
+      }
+      f16x4 *o = reinterpret_cast<f16x4 *>(p) + i * 64 + lane;
+      o[0] = h; o[L / 4] = h; o[2 * (L / 4)] = l;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      float x = v[i] * inv;
+      asm volatile("" : "+v"(x));
+      const _Float16 h = (_Float16)x;
+      p[i * 64 + lane] = h; p[L + i * 64 + lane] = h; p[2 * L + i * 64 + lane] = (_Float16)(x - (float)h);
+    }
+  }
+}
+
 }  // namespace gqhip

@@ -1164,6 +1164,40 @@ int upconv_im2col_nhwc_f16x3(const float *x, void *A3, int64_t B, int64_t H, int
   return check_launch();
 }
 
+int attn_split_qkv_f16x3(const float *qkv, void *Q3, void *K3, void *V3, int64_t B, int64_t L, int64_t C, float sq, float sv,
+                         void *stream) {
+  if (B < 0 || L < 1 || C < 4 || C % 4 != 0 || !(sq > 0.f) || !(sv > 0.f)) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!qkv || !Q3 || !K3 || !V3) return GQHIP_ERR_INVALID_ARG;
+  const long total = (long)(B * L * (C / 4));
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(attn_split_qkv_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), qkv,
+                     static_cast<_Float16 *>(Q3), static_cast<_Float16 *>(K3), static_cast<_Float16 *>(V3), (long)L,
+                     (int)(C / 4), sq, sv, total);
+  return check_launch();
+}
+
+int attn_softmax_split_f16x3(const float *S, void *P3, int64_t rows, int64_t L, float factor, void *stream) {
+  if (rows < 0 || L < 64 || L % 64 != 0 || L > 4096 || !(factor > 0.f)) return GQHIP_ERR_INVALID_ARG;
+  if (rows == 0) return GQHIP_OK;
+  if (!S || !P3) return GQHIP_ERR_INVALID_ARG;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  _Float16 *p = static_cast<_Float16 *>(P3);
+#define GQ_SM(N) hipLaunchKernelGGL(attn_softmax_split_kernel<N>, grid, dim3(256), 0, st, S, p, (long)rows, factor)
+  switch (L / 64) {
+    case 1: GQ_SM(1); break;
+    case 4: GQ_SM(4); break;
+    case 16: GQ_SM(16); break;
+    case 36: GQ_SM(36); break;
+    case 64: GQ_SM(64); break;
+    default: return GQHIP_ERR_INVALID_ARG;
+  }
+#undef GQ_SM
+  return check_launch();
+}
+
 int f16_scales_from_gn_stats(const double *stats, int64_t n_bg, double amp, double u_scale, float *scales_out,
                              void *stream) {
   if (!stats || !scales_out || n_bg < 1 || n_bg > 0x7fffffff || !(amp > 0.0) || !(u_scale > 0.0)) return GQHIP_ERR_INVALID_ARG;

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "wino_in_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
     "wino_gemm_c128_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "wino_gemm_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "attn_split_qkv_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float, _vp]),
+    "attn_softmax_split_f16x3": (ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_float, _vp]),
     "wino_in_gn_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
     "wino_in_gn_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
@@ -515,6 +517,39 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
     return y
 
 
+ATTN_L_OK = (64, 256, 1024, 2304, 4096)   # token counts attn_softmax_split_f16x3 is instantiated for
+
+
+def attention_f16x3(qkv, q_bound: float, v_bound: float):
+    """softmax(q k^T C^-1/2) v for the fused projection qkv [B, L, 3C] fp32 (dense), single head: two library fp16 GEMMs with
+    fp32 accumulation over K axes of two-term fp16 splits (gqhip.h:attn_split_qkv_f16x3) -- fp32-grade results at several
+    times the rate of the fp32 GEMMs (a split-bf16 emulation on gfx950).  ``q_bound`` >= max(|q|, |k|), ``v_bound`` >= max|v|
+    (rigorous bounds from the caller: GroupNorm bound x weight row sums).  Returns (O_raw [B, L, C] fp32, post_scale) with
+    attention output = O_raw * post_scale (a power of two the consumer folds into its own scale)."""
+    if not (qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 3 and qkv.is_contiguous() and qkv.shape[2] % 12 == 0):
+        raise GqHipError("attention_f16x3 needs a dense fp32 HIP tensor [B, L, 3C], C % 4 == 0")
+    B, Ltok, C3 = qkv.shape
+    C = C3 // 3
+    if Ltok not in ATTN_L_OK:
+        raise GqHipError("attention_f16x3: token count %d not in %s" % (Ltok, ATTN_L_OK))
+    pow2 = lambda bound: min(2.0 ** math.floor(math.log2(32768.0 / max(float(bound), 1e-30))), 2.0 ** 14)
+    # q k^T sums C products of scaled operands in fp32: keep sq^2 C q_bound^2 well inside fp32 (it always is: <= 2^30 C)
+    sq, sv = pow2(q_bound), pow2(v_bound)
+    L_ = lib()
+    with torch.cuda.device(qkv.device):
+        Q3 = torch.empty((B, Ltok, C3), dtype=torch.float16, device=qkv.device)
+        K3 = torch.empty((B, Ltok, C3), dtype=torch.float16, device=qkv.device)
+        V3 = torch.empty((B, 3 * Ltok, C), dtype=torch.float16, device=qkv.device)
+        _check(L_.attn_split_qkv_f16x3(qkv.data_ptr(), Q3.data_ptr(), K3.data_ptr(), V3.data_ptr(), B, Ltok, C, sq, sv,
+                                       _stream()), "attn_split_qkv_f16x3")
+        S = torch.bmm(Q3, K3.transpose(1, 2), out_dtype=torch.float32)
+        P3 = torch.empty((B, Ltok, 3 * Ltok), dtype=torch.float16, device=qkv.device)
+        _check(L_.attn_softmax_split_f16x3(S.data_ptr(), P3.data_ptr(), B * Ltok, Ltok, float(C) ** -0.5 / (sq * sq), _stream()),
+               "attn_softmax_split_f16x3")
+        O = torch.bmm(P3, V3, out_dtype=torch.float32)
+    return O, 1.0 / (16384.0 * sv)
+
+
 def own_gemm_fits(positions: int, tiles: int, cout: int, cin: int = 256) -> bool:
     """Where wino_gemm_f16x2 (256 x 128 blocks, two per CU) beats the library's K-concatenated GEMM: the 256-channel level,
     whose GEMM is HBM-bound on V + M (1.05-1.10x alone, and the input transform writes 9 instead of 13.5 bytes per
@@ -599,7 +634,8 @@ def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None
     return (y, ostats) if stats_groups else y
 
 
-def conv1x1_direct(x, wf, u_scale: float, scale, residual=None, bias=None, stats_groups: int = 0, pre_bias=None):
+def conv1x1_direct(x, wf, u_scale: float, scale, residual=None, bias=None, stats_groups: int = 0, pre_bias=None,
+                   post_scale: float = 1.0):
     """1x1 convolution Cin -> Cout (128 | 256) of a channels_last fp32 HIP tensor as an fp16 x 3 GEMM over its pixels with the
     split of x inside the kernel (gqhip.h:conv1x1_f16x3).  ``wf, u_scale`` from conv3_weights_f16 of the [Cout, Cin, 1, 1]
     kernel; ``pre_bias``: per-channel bias still pending on x (added before the split); ``scale``: a float bound >=
@@ -613,10 +649,13 @@ def conv1x1_direct(x, wf, u_scale: float, scale, residual=None, bias=None, stats
     if residual is not None and (image_layout(residual) != 1 or tuple(residual.shape) != (B, cout, H, W)):
         raise GqHipError("conv1x1_direct: residual must be channels_last [B, Cout, H, W]")
     if torch.is_tensor(scale):
+        if post_scale != 1.0:
+            raise GqHipError("conv1x1_direct: post_scale needs a host-side scale bound")
         sdev, v_scale, mscale = scale.data_ptr(), 0.0, 0.0
     else:
         v_scale = min(2.0 ** math.floor(math.log2(32768.0 / max(float(scale), 1e-30))), 2.0 ** 14)
-        sdev, mscale = None, 1.0 / (v_scale * u_scale)
+        # post_scale: x is post_scale^-1 times the tensor meant (a power of two its producer left pending)
+        sdev, mscale = None, float(post_scale) / (v_scale * u_scale)
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None

@@ -303,7 +303,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
-        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkv_wf_key", "_s2_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
+        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkb_key", "_qkv_wf_key", "_s2_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -378,6 +378,7 @@ FUSED_QKV = True         # attention: q, k, v as one GEMM with fused biases (cha
 FUSED_ADD_STATS = True   # residual add also produces the next GroupNorm's statistics (channels_last only)
 GN_GROUPS = 32     # unet.py:54-57: every Normalize is GroupNorm(32, C, eps=1e-6)
 DEFER_BIAS = True
+ATTN_F16X3 = True   # both attention GEMMs as fp16 x 3 library GEMMs (split of q, k, v and softmax + split in libgqhip kernels)
 ATTN_MATH = "auto"  # explicit matmul/softmax/matmul instead of the fused SDPA kernel: "auto" = on HIP devices
 
 
@@ -517,9 +518,21 @@ class AttnBlock(nn.Module):
                     qkv = torch.addmm(bqkv, y.permute(0, 2, 3, 1).reshape(b * h * w, c), wqkv).view(b, 1, h * w, 3 * c)
                 q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
             else:
+                qkv = None
                 q, k, v = (f(y).permute(0, 2, 3, 1).reshape(b, 1, h * w, c) for f in (self.q, self.k, self.v))
-            a = _sdpa(q, k, v)
-            a = a.reshape(b, h, w, c).permute(0, 3, 1, 2)
+            a_scale = 1.0
+            if ATTN_F16X3 and qkv is not None and qkv.is_contiguous() and c % 4 == 0:
+                from .. import _lib
+
+                if (h * w) in _lib.ATTN_L_OK:
+                    # both attention GEMMs as fp16 GEMMs over K axes of two-term fp16 splits (fp32 accumulation): the fp32
+                    # GEMMs are a split-bf16 emulation at ~120 TFLOP/s; operand scales from rigorous bounds (GroupNorm bound x
+                    # weight row sums), the softmax writes the split operand of the second GEMM directly
+                    yb = _gn_act_bound(self.norm, x)
+                    a, a_scale = _lib.attention_f16x3(qkv.view(b, h * w, 3 * c), self._qk_bound(yb), self._v_bound(yb))
+            if a_scale == 1.0:
+                a = _sdpa(q, k, v)
+            a = a.reshape(b, h, w, c).permute(0, 3, 1, 2)   # (times a_scale: folded into proj_out's scale below)
         else:
             q, k, v = (f(y).reshape(b, 1, c, h * w).transpose(2, 3).contiguous() for f in (self.q, self.k, self.v))
             a = _sdpa(q, k, v)
@@ -533,12 +546,26 @@ class AttnBlock(nn.Module):
 
             if _lib.image_layout(a) == 1 and _lib.gn_nhwc_ok(c, GN_GROUPS):
                 wf, us = _direct_weights(self.proj_out)
-                out, st = _lib.conv1x1_direct(a, wf, us, self._v_bound(_gn_act_bound(self.norm, x)), residual=x,
-                                              bias=self.proj_out.bias, stats_groups=GN_GROUPS)
+                out, st = _lib.conv1x1_direct(a, wf, us, self._v_bound(_gn_act_bound(self.norm, x)) / a_scale, residual=x,
+                                              bias=self.proj_out.bias, stats_groups=GN_GROUPS, post_scale=a_scale)
                 out._gn_stats = (st, GN_GROUPS)
                 return out
+        if a_scale != 1.0:
+            a = a * a_scale
         p, pb = _conv(self.proj_out, a)
         return _add(x, p, pb)
+
+    def _qk_bound(self, y_bound: float) -> float:
+        """max(|q|, |k|) for |y| <= y_bound: q = W_q y + b_q, k = W_k y + b_k."""
+        ps = (self.q.weight, self.k.weight, self.q.bias, self.k.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_qkb_key", None) != key:
+            c = self.q.weight.shape[0]
+            rs = max(float(self.q.weight.detach().reshape(c, -1).abs().sum(1).max()),
+                     float(self.k.weight.detach().reshape(c, -1).abs().sum(1).max()))
+            self._qkb = (rs, max(float(self.q.bias.detach().abs().max()), float(self.k.bias.detach().abs().max())))
+            self._qkb_key = key
+        return y_bound * self._qkb[0] + self._qkb[1]
 
     def _v_bound(self, y_bound: float) -> float:
         """max|v| for |y| <= y_bound: v = W_v y + b_v."""
