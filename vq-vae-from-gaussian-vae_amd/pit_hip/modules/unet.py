@@ -497,6 +497,7 @@ class AttnBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b, c, h, w = x.shape
+        a_scale = 1.0      # power of two still pending on the attention output (fp16 x 3 route)
         y = _norm_act(self.norm, x, act=False)
         # [b, c, h, w] -> [b, 1, hw, c]
         if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
@@ -520,7 +521,6 @@ class AttnBlock(nn.Module):
             else:
                 qkv = None
                 q, k, v = (f(y).permute(0, 2, 3, 1).reshape(b, 1, h * w, c) for f in (self.q, self.k, self.v))
-            a_scale = 1.0
             if ATTN_F16X3 and qkv is not None and qkv.is_contiguous() and c % 4 == 0:
                 from .. import _lib
 
