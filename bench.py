@@ -487,22 +487,30 @@ def main():
             avg_ms = kernel_ms / max(launches, 1)
             achieved = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
             plan = _lib.debug_plan(rows, N_CODES, dim)
-            bf16 = plan["bf16"] == 1
+            kind = plan["bf16"]          # 0 fp32 MFMA filter, 1 split-bf16, 2 fp16 + fp8 (dim 16, Gaussian score)
+            if kind == 2 and cfg["family"] == "vq":
+                kind = 1                 # the VQ distance keeps the split-bf16 filter (arbitrary embedding magnitudes)
+            bf16 = kind >= 1
             whole = flops / (stages["quantiser"] * 1e-3) / 1e12
             whole_b2b = flops / (call_us * 1e-6) / 1e12
             if bf16:
                 kname = "gq_filter_bf16_kernel"
                 traffic, prov = pmc_traffic(kname)
-                # split-bf16 filter: every algorithmic fp32 MAC is executed as 3 bf16 MACs (A_h s_h + A_h s_l + A_l s_h)
-                roofline = {"kernel": f"{kname} (split-bf16 MFMA filter of the fused quantiser; plan {plan})",
+                # executed work per algorithmic fp32 MAC, in bf16-rate MACs: split-bf16 = 3 bf16 MACs (A_h s_h + A_h s_l +
+                # A_l s_h); fp16 + fp8 = 1 fp16 MAC + 2 fp8 MACs on the block-scaled instruction (twice the bf16 rate) = 2
+                ex = 3 if kind == 1 else 2
+                what = ("split-bf16 MFMA filter" if kind == 1 else
+                        "fp16 + fp8 MFMA filter: v_mfma_f32_32x32x16_f16 main product + v_mfma_scale_f32_32x32x64_f8f6f4 corrections")
+                roofline = {"kernel": f"{kname} ({what} of the fused quantiser; plan {plan})",
                             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                            "executed": round(3 * achieved, 2), "executed_frac": round(3 * achieved / PEAK_BF16_TFLOPS, 4),
+                            "executed": round(ex * achieved, 2), "executed_frac": round(ex * achieved / PEAK_BF16_TFLOPS, 4),
                             "vs_fp32_mfma_peak": round(achieved / PEAK_F32_TFLOPS, 3),
                             "note": "achieved = algorithmic fp32-equivalent flops (SURVEY 8d: 4*dim*N per row; VQ 2*dim*N) / "
-                                    "launch time; the kernel executes 3 bf16 MACs per algorithmic MAC (two-term bf16 splits, "
-                                    "exact re-rank keeps the indices bit-identical), so executed = 3 x achieved is what the "
-                                    "dense bf16 MFMA peak bounds",
+                                    "launch time against the dense bf16/fp16 MFMA peak; executed = the MFMA work the kernel issues per "
+                                    "algorithmic MAC in bf16-rate MACs (split-bf16: three bf16 products of two-term splits; fp16 + fp8: "
+                                    "one fp16 product + two fp8 correction products at twice the rate = 2) -- the exact re-rank keeps "
+                                    "the indices bit-identical either way",
                             "traffic": traffic, "traffic_source": prov,
                             "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate rocprofv3 --pmc passes of "
                                             "tools/kbench.py at this shape (not re-measured in this run: PMC needs the profiler)"}

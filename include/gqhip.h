@@ -54,18 +54,21 @@ const char *gqhip_status_string(int status);
 /* last hipError_t observed by a failing call on this thread (0 if none). */
 int gqhip_last_hip_error(void);
 
-/* Filter kernel of the fused arg-max (gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32).  AUTO: the
- * split-bf16 MFMA filter for dims 4/8/16/32 (three bf16 products per fp32 product, ~3x faster; rows it cannot decide
- * cascade through the fp32 MFMA filter, then an fp64 stage); FP32: always the fp32 MFMA filter.  Both feed the same exact re-rank: the indices are identical.
+/* Filter kernel of the fused arg-max (gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32).  AUTO: at dim 16 with the
+ * Gaussian score the fp16 + fp8 MFMA filter (one fp16 product + block-scaled fp8 corrections per fp32 product), at the other
+ * MFMA dims (4/8/32) and for VQ the split-bf16 filter (three bf16 products per fp32 product); rows a filter cannot decide
+ * cascade through the fp32 MFMA filter, then an fp64 stage.  FP32: always the fp32 MFMA filter.  BF16: the split-bf16
+ * filter wherever it applies (no fp16 + fp8).  All feed the same exact re-rank: the indices are identical.
  * Process-wide; initial value from the environment (GQHIP_FILTER=fp32|bf16).  The workspace size depends on it:
  * query gqhip_workspace_bytes after changing it.  (No reference counterpart.) */
 #define GQHIP_FILTER_AUTO 0
 #define GQHIP_FILTER_FP32 1
+#define GQHIP_FILTER_BF16 2
 int gqhip_set_filter(int kind);
 int gqhip_get_filter(void);
 
 /* Diagnostics: launch plan and workspace layout of the fused arg-max for a shape.  out8 = { byte offset of the
- * candidate records, code splits, tiles per candidate group, tiles per split, 1 if split-bf16, coefficient of the
+ * candidate records, code splits, tiles per candidate group, tiles per split, filter (0 fp32, 1 split-bf16, 2 fp16 + fp8), coefficient of the
  * filter error bound (E_f = coeff * 2^-24 * T), row tiles per wave, waves per filter block }. */
 int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8);
 

@@ -11,9 +11,10 @@ from oracle import gq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "fp32"])
+@pytest.fixture(autouse=True, params=["auto", "bf16", "fp32"])
 def filter_kind(request):
-    """Every test of this module runs with both filter kernels (split-bf16 and fp32 MFMA); same indices."""
+    """Every test of this module runs with all three filter selections ("auto": fp16 + fp8 at dim 16, split-bf16 at the other
+    MFMA dims; "bf16": split-bf16 everywhere; "fp32": the fp32 MFMA filter); same indices."""
     from pit_hip import _lib
 
     _lib.set_filter(request.param)
@@ -234,7 +235,7 @@ def test_filter_value_error_within_the_bound_the_rerank_assumes(dim, rows, n, fi
     _lib.gq_argmax(mu.to(dev), sd.to(dev), torch.from_numpy(cb).to(dev), 1.0, ws=ws)
     torch.cuda.synchronize()
     pl = _lib.debug_plan(rows, n, dim)
-    assert pl["bf16"] == (1 if filter_kind == "auto" else 0)
+    assert pl["bf16"] == {"auto": 2 if dim == 16 else 1, "bf16": 1, "fp32": 0}[filter_kind]
     m, ids = _lib.debug_records(ws, rows, n, dim)
     m1 = m[..., 0].cpu().numpy().astype(np.float64)            # [nsplit, rows]
     id1 = ids[..., 0].cpu().numpy()

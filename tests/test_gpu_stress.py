@@ -12,9 +12,10 @@ from oracle import gq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "fp32"])
+@pytest.fixture(autouse=True, params=["auto", "bf16", "fp32"])
 def filter_kind(request):
-    """Every test of this module runs with both filter kernels (split-bf16 and fp32 MFMA); same indices."""
+    """Every test of this module runs with all three filter selections ("auto": fp16 + fp8 at dim 16, split-bf16 at the other
+    MFMA dims; "bf16": split-bf16 everywhere; "fp32": the fp32 MFMA filter); same indices."""
     from pit_hip import _lib
 
     _lib.set_filter(request.param)

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--filter", default=None, choices=["auto", "fp32"], help="filter kernel (default: library default)")
+    ap.add_argument("--filter", default=None, choices=["auto", "fp32", "bf16"], help="filter kernel (default: library default)")
     a = ap.parse_args()
     if a.filter:
         _lib.set_filter(a.filter)
@@ -47,11 +47,13 @@ def main():
     torch.cuda.synchronize()
     fb, rr = _lib.debug_counters(ws)
     _lib.debug_enable(False)
-    bf16 = _lib.debug_plan(a.rows, a.n, a.dim)["bf16"] == 1
+    kind = _lib.debug_plan(a.rows, a.n, a.dim)["bf16"]     # 0 fp32 MFMA, 1 split-bf16, 2 fp16 + fp8
+    bf16 = kind >= 1
     tf = flops / kms / 1e9
-    rate = (f"{tf:.1f} algorithmic TFLOP/s = {tf/157.3:.2f}x the fp32 MFMA peak; executed 3x = {3*tf:.0f} TFLOP/s bf16 "
-            f"({3*tf/2500*100:.1f}% of 2500)") if bf16 else f"{tf:.1f} TFLOP/s ({tf/157.3*100:.1f}% of 157.3)"
-    print(f"rows={a.rows} dim={a.dim} n={a.n}: {'split-bf16' if bf16 else 'fp32'} filter kernel {kms*1e3:.1f} us avg over "
+    ex = 3 if kind == 1 else 2       # bf16-rate MACs executed per algorithmic MAC (fp16 + fp8: 1 fp16 + 2 fp8 at twice the rate)
+    rate = (f"{tf:.1f} algorithmic TFLOP/s = {tf/157.3:.2f}x the fp32 MFMA peak; executed {ex}x = {ex*tf:.0f} TFLOP/s bf16-equivalent "
+            f"({ex*tf/2500*100:.1f}% of 2500)") if bf16 else f"{tf:.1f} TFLOP/s ({tf/157.3*100:.1f}% of 157.3)"
+    print(f"rows={a.rows} dim={a.dim} n={a.n}: {('fp32', 'split-bf16', 'fp16+fp8')[kind]} filter kernel {kms*1e3:.1f} us avg over "
           f"{launches} launches -> {rate}; "
           f"whole call wall {wall*1e6:.1f} us; fallback rows {fb}, re-ranked half-tiles/row {rr/a.rows:.3f}")
 

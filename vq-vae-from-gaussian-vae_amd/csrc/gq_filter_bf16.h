@@ -38,6 +38,7 @@ struct FilterBfParams {
   int nsplit, tiles_total, tiles_per_split;
   WsHeader *hdr;
   void *dbg;            // diagnostic builds only
+  const float *rowscale;   // MIXED: [rows] 2^e_r, the records leave the kernel multiplied by it (true units)
 };
 
 // round-to-nearest-even fp32 -> bf16 (as the upper 16 bits); finite inputs (non-finite rows / codebooks never
@@ -94,19 +95,65 @@ __device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[BfLayout<NV>::N
   }
 }
 
+// ---- MIXED (round 2): the same filter value from ONE fp16 product and fp8 corrections.  Every operand q is split as
+// q = q_h + q_l with q_h = fp16(q) (|q_l| <= 2^-12 |q|):
+//     A s  =  A_h s_h  +  A_h s_l  +  A_l s_h  (+ A_l s_l <= 2^-24 |A s|)
+// The main product A_h s_h runs on v_mfma_f32_32x32x16_f16 (two K = 16 steps for the 32 slots of dim 16); both
+// correction types together are ONE v_mfma_scale_f32_32x32x64_f8f6f4 with OCP e4m3 operands: K block 0 = (s_l 2^11) x
+// (A_h 2^-6), K block 1 = s_h x (A_l 2^6), the E8M0 block scales 2^-11 2^6 and 2^-6 put them back (constants: the row's
+// coefficients are normalised by a power of two 2^-e_r in gq_prep_kernel so that their largest is in [2^13, 2^14); the
+// record values leave this kernel multiplied by 2^e_r).  A correction is 2^-11 of its product and an e4m3 operand carries
+// a relative rounding error <= 2^-4, so each correction type is accurate to 2^-15 |A s|: representation error <= 1070 u
+// per product (u = 2^-24) against 196 u for the split-bf16 form -- a wider re-rank margin (`ef_coeff` 1340, incl. 4 u per
+// accumulation step of the main product and 2 u per step of the corrections), the same indices.  MFMA passes per tile
+// and row tile: 2 x 8 + 16 = 32 instead of 6 x 8 = 48 (the block-scaled fp8 instruction runs K = 64 in 16 passes).
+// Measured layout of the scaled instruction (tools/mfma_f8_layout.hip): byte j of lane (r, h) is k = 16 h + (j & 15) +
+// 32 (j >> 4) -- the first 16 bytes belong to K block 0, the last 16 to block 1 --, and block b of row / column r takes
+// its scale from lane r + 32 b.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ i32x8 cat_u32x4(u32x4 a, u32x4 b) {
+  return i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
+}
+
+// MFMAs [S0, S1) of one tile (3 per row tile: fp16 step 0, fp16 step 1, scaled fp8 corrections)
+template <int RT, int S0, int S1>
+__device__ __forceinline__ void tile_mfma_mixed(const u32x4 (&cv)[4], const u32x4 (&rv)[RT][4], f32x16 (&d)[RT], int sa,
+                                                int sb) {
+  if constexpr (S0 == 0) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      d[rt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int s = S0; s < S1; ++s) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (s < 2)
+        d[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8m, cv[s]), __builtin_bit_cast(f16x8m, rv[rt][s]),
+                                                       d[rt], 0, 0, 0);
+      else
+        d[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat_u32x4(cv[2], cv[3]), cat_u32x4(rv[rt][2], rv[rt][3]), d[rt],
+                                                                0, 0, 0, sa, 0, sb);
+    }
+  }
+}
+
 // WAVES = 8: one 512-thread block per CU, so the two waves that share a SIMD belong to the SAME block and meet at
 // every chunk barrier.  With two independent 4-wave blocks per CU the SIMD's arbiter favours one of them: it
 // finishes at ~70 % of the kernel time and the other runs the rest alone, without a partner to hide its LDS
 // waits and epilogues behind (measured per block with GQHIP_CLOCK_STAMPS: 104 / 149 us).  One block per CU also
 // halves the L2 -> LDS staging traffic (one chunk copy serves 8 waves).
-template <int NV, int RT, int CT, int GT, int WAVES>
+template <int NV, int RT, int CT, int GT, int WAVES, bool MIXED = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
+  static_assert(!MIXED || NV == 2, "fp16 + fp8 filter: dim 16");
   constexpr int NCV = BfLayout<NV>::NCV;      // code (and row) vectors per tile
   constexpr int TILE_Q = NCV * 64;            // 16-byte slots per tile
   constexpr int CHUNK_Q = CT * TILE_Q;
   constexpr int NT = 64 * WAVES;              // threads per block
   constexpr int R4 = CHUNK_Q / NT;            // 16-byte loads per thread per chunk
-  constexpr int NM = BfLayout<NV>::NM;        // MFMAs per tile and row tile
+  constexpr int NM = MIXED ? 3 : BfLayout<NV>::NM;   // MFMAs per tile and row tile
   // candidate tracker depth: top-4 (ids of three), except in the packed dim-4 kernel, which is bound by its
   // epilogue's VALU work (top-3 there: +18 % filter time otherwise, measured)
   constexpr bool TOP4 = NV > 0;
@@ -135,6 +182,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     for (int v = 0; v < NCV; ++v) rv[rt][v] = p.rowimg[((long)row * NCV + v) * 2 + h];
   }
 
+  // E8M0 block scales of the corrections' MFMA (MIXED): lanes < 32 hold the scale of K block 0, the others of block 1
+  const int sa = lane < 32 ? 127 - 11 : 127, sb = lane < 32 ? 127 + 6 : 127 - 6;
+  auto tile_mfma = [&](auto s0_tag, auto s1_tag, const u32x4 (&cvx)[NCV], f32x16 (&dx)[RT]) {
+    constexpr int A0 = decltype(s0_tag)::value, A1 = decltype(s1_tag)::value;
+    if constexpr (MIXED) tile_mfma_mixed<RT, A0, A1>(cvx, rv, dx, sa, sb);
+    else tile_mfma_bf16<NV, RT, A0, A1>(cvx, rv, dx);
+  };
+  using IC0 = std::integral_constant<int, 0>;
+  using ICNM = std::integral_constant<int, NM>;
   const float NEG_INF = -__builtin_inff();
   float m1[RT], m2[RT], m3[RT], m4[RT], tpend[RT];
   int i1[RT], i2[RT], i3[RT];
@@ -194,6 +250,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   constexpr int S0 = NM >= 6 ? 2 : 1;   // MFMA steps issued before the previous tile's epilogue
+  using ICS0 = std::integral_constant<int, S0>;
   // Staging schedule of a full chunk (round 2, after the ablation in tools/abl_filter.sh: with the copy of the next chunk
   // at the chunk's end -- 8 ds_write_b128 per thread, barrier, first operand reads -- the matrix pipes drained at every
   // chunk boundary: 137 us without the staging, 143 without the barriers, 155-164 with both):
@@ -237,9 +294,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         // every tile began with its own operand reads and lgkmcnt waits, the prefetch existed only in the source)
         __builtin_amdgcn_sched_barrier(0);
         f32x16 d[RT];
-        tile_mfma_bf16<NV, RT, 0, S0>(cv, rv, d);
+        tile_mfma(IC0{}, ICS0{}, cv, d);
         fold(dprev, tprev, PREV_CLOSES);
-        tile_mfma_bf16<NV, RT, S0, NM>(cv, rv, d);
+        tile_mfma(ICS0{}, ICNM{}, cv, d);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) dprev[rt] = d[rt];
         tprev = tile0 + TT;
@@ -282,7 +339,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         u32x4 cw[NCV];
         read_ops(base + tt * TILE_Q, cw);
         f32x16 d[RT];
-        tile_mfma_bf16<NV, RT, 0, NM>(cw, rv, d);
+        tile_mfma(IC0{}, ICNM{}, cw, d);
         fold(d, tile0 + tt, ((tile0 + tt) % GT) == GT - 1);
       }
     }
@@ -303,7 +360,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     u32x4 cv[NCV];
     read_ops(p.cbimg + (long)tile * TILE_Q + h * 32 + c, cv);
     f32x16 d[RT];
-    tile_mfma_bf16<NV, RT, 0, NM>(cv, rv, d);
+    tile_mfma(IC0{}, ICNM{}, cv, d);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -344,6 +401,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     }
     const int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;
     if (h == 0 && row < p.rows) {
+      if constexpr (MIXED) {      // back to true units: the row's coefficients were normalised by 2^-e_r
+        const float rs = p.rowscale[row];
+        a1 *= rs; a2v *= rs; a3 *= rs; a4 *= rs;
+      }
       Rec r;
       r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.m4 = a4; r.id1 = j1; r.id2 = j2; r.id3 = j3;
       r.pad = 0;

@@ -36,6 +36,7 @@ struct PrepParams {
   double *rowsum;            // [rows, 4]
   float *coef;               // [rows, 2, dim]: the fp32 filter coefficients A | B (the re-rank's pre-filter reads them)
   u32x4 *rowimg;             // [rows][NVEC][2] or NULL (fp32 filter: no images)
+  float *rowscale;           // [rows] (MIXED images only): 2^e_r, the power of two the row's coefficients were divided by
   const float *cb;           // [n, dim]
   u32x4 *cbimg;              // [tiles_total + CT][NVEC][2][32] or NULL
   WsHeader *hdr;
@@ -46,9 +47,33 @@ struct PrepParams {
   OutMap omap;               // module layout (mode 1 BCHW, 2 BLC; 0: plain rows)
 };
 
-template <int MODE, int DIM, bool FROM_Z>
+// fp8 (OCP e4m3) of two floats, packed into the low 16 bits (values in range by construction; RNE)
+__device__ __forceinline__ unsigned fp8x2(float a, float b) {
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+
+// Power-of-two normalisation of a row's filter coefficients for the MIXED (fp16 + fp8) images: returns s = 2^-e with
+// max|c| * s in [2^13, 2^14), or NaN when the largest coefficient is 0, non-finite or outside [2^-100, 2^100] (such a row
+// is poisoned through its bound sums and decided by the exhaustive stages).
+__device__ __forceinline__ float mixed_row_scale(const float *coef, int n) {
+  float amax = 0.0f;
+  bool nan = false;
+  for (int i = 0; i < n; ++i) {
+    const float a = fabsf(coef[i]);
+    nan = nan || (a != a);
+    amax = __builtin_fmaxf(amax, a);
+  }
+  if (nan || !(amax >= 7.8886090522101181e-31f) || !(amax <= 1.2676506002282294e30f)) return __builtin_nanf("");
+  int ex;
+  (void)frexpf(amax, &ex);            // amax = f * 2^ex, f in [0.5, 1)
+  return ldexpf(1.0f, 14 - ex);       // amax * s in [2^13, 2^14)
+}
+
+// MIXED (DIM 16, GQ only): the operand images of the fp16 + fp8 filter (gq_filter_bf16.h) instead of the split-bf16 ones.
+template <int MODE, int DIM, bool FROM_Z, bool MIXED = false>
 __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   static_assert(DIM == 4 || DIM == 8 || DIM == 16 || DIM == 32, "MFMA filter dims");
+  static_assert(!MIXED || (DIM == 16 && MODE == kModeGQ), "fp16 + fp8 images: dim 16, Gaussian score");
   constexpr bool PACKED = DIM == 4;
   constexpr int NV = PACKED ? 1 : DIM / 8;     // 8-slot groups per operand half
   constexpr int NVEC = PACKED ? 2 : 2 * NV;    // 16-byte vectors per (code | row, half) in an image
@@ -73,6 +98,54 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
         const int tile = (int)(t >> 6), c = (int)t & 31, h = (int)(t >> 5) & 1;
         const long code = (long)tile * 32 + c;
         u32x4 *dst = p.cbimg + (long)tile * (NVEC * 64) + h * 32 + c;
+        if constexpr (MIXED) {
+          // slots: [0, 16) squares of the dims, [16, 32) their values.  Vector 0 / 1: fp16 h parts of slots 8h.. / 16 + 8h..
+          // (the operands of the two K = 16 steps of the main product); vector 2: fp8 of the fp16 residuals * 2^11 of
+          // slots 16h .. 16h + 15, vector 3: fp8 of the values of the same slots (K blocks 0 and 1 of the scaled MFMA)
+          float nv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            nv[k] = code < p.n ? p.cb[code * 16 + k] : 0.0f;
+            const float a = fabsf(nv[k]);
+            amax = (a != a) ? __builtin_inff() : __builtin_fmaxf(amax, a);
+          }
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+          h8 v0, v1;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float x = nv[8 * h + k];
+            float sq = x * x;
+            asm volatile("" : "+v"(sq));          // the fp32 square is the feature (no fused multiply-convert)
+            v0[k] = (_Float16)sq;
+            v1[k] = (_Float16)x;
+          }
+          u32x4 v2, v3;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            unsigned lo2 = 0, lo3 = 0, hi2 = 0, hi3 = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float t[2], r[2];
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                const float x = nv[4 * w + 2 * e + q];
+                float tt = h == 0 ? x * x : x;
+                asm volatile("" : "+v"(tt));
+                t[q] = tt;
+                r[q] = (tt - (float)(_Float16)tt) * 2048.0f;
+              }
+              if (e == 0) { lo2 = fp8x2(r[0], r[1]); lo3 = fp8x2(t[0], t[1]); }
+              else { hi2 = fp8x2(r[0], r[1]); hi3 = fp8x2(t[0], t[1]); }
+            }
+            v2[w] = lo2 | (hi2 << 16);
+            v3[w] = lo3 | (hi3 << 16);
+          }
+          dst[0] = __builtin_bit_cast(u32x4, v0);
+          dst[64] = __builtin_bit_cast(u32x4, v1);
+          dst[128] = v2;
+          dst[192] = v3;
+          continue;
+        }
 #pragma unroll
         for (int m = 0; m < NV; ++m) {
           unsigned hi[8], lo[8];
@@ -227,7 +300,50 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; ++i) acc += s_sum[r * DIM + i][q];
+    if constexpr (MIXED) {
+      const float sc = mixed_row_scale(&s_coef[r][0], 2 * DIM);
+      if (sc != sc) acc = __builtin_nan("");     // no usable normalisation: the row's bound is NaN -> undecided
+    }
     p.rowsum[(row0 + r) * 4 + q] = acc;
+  }
+  if constexpr (MIXED) {
+    if (p.rowimg && tid < RB * 8) {
+      // row image: vector 0 / 1: fp16 h parts of the normalised A (dims 8h..) / B (dims 8h..); vector 2: fp8 of those h
+      // parts * 2^-6 for slots 16h .. 16h + 15 (h = 0: A of all dims, h = 1: B), vector 3: fp8 of the fp16 residuals * 2^6
+      const int r = tid / 8, v = (tid / 2) % 4, h = tid % 2;
+      if (row0 + r < p.rows) {
+        float sc = mixed_row_scale(&s_coef[r][0], 2 * DIM);
+        if (v == 0 && h == 0) p.rowscale[row0 + r] = sc != sc ? sc : 1.0f / sc;     // 2^e_r (exact)
+        if (sc != sc) sc = 0.0f;
+        u32x4 out;
+        if (v < 2) {
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+          h8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = (_Float16)(s_coef[r][16 * v + 8 * h + k] * sc);
+          out = __builtin_bit_cast(u32x4, o);
+        } else {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float t[2];
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                const float x = s_coef[r][16 * h + 4 * w + 2 * e + q] * sc;
+                const float xh = (float)(_Float16)x;
+                t[q] = v == 2 ? xh * 0.015625f : (x - xh) * 64.0f;
+              }
+              if (e == 0) lo = fp8x2(t[0], t[1]); else hi = fp8x2(t[0], t[1]);
+            }
+            out[w] = lo | (hi << 16);
+          }
+        }
+        p.rowimg[(row0 + r) * 8 + v * 2 + h] = out;
+      }
+    }
+    return;
   }
   if (p.rowimg && tid < RB * NVEC * 2) {
     const int r = tid / (NVEC * 2), v = (tid / 2) % NVEC, h = tid % 2;

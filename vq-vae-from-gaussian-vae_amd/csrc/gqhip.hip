@@ -53,16 +53,22 @@ struct Plan {
   int waves;            // waves per block: 8 (one block per CU) for the split-bf16 filter, else 4
   // second level of the cascade behind the split-bf16 filter: the fp32 MFMA filter (RT 1) on the undecided rows
   int nsplit2, tiles_per_split2, gt2;
+  bool mixed;           // dim 16, Gaussian score: fp16 main product + fp8 corrections instead of three bf16 products
 };
 
-// Filter selection: 0 = auto (split-bf16 where it applies: dims 8/16/32), 1 = always the fp32 MFMA filter.
+constexpr float kMixedEfCoeff = 1340.0f;   // gq_filter_bf16.h: 1070 (representation) + 4 * 32 + 2 * 64 (accumulation) + slack
+constexpr float kMixedN1Limit = 16.0f;
+
+// Filter selection: 0 = auto (fp16 + fp8 at dim 16 / Gaussian score, split-bf16 at the other MFMA dims), 1 = always the
+// fp32 MFMA filter, 2 = split-bf16 wherever it applies (no fp16 + fp8).
 // Initial value from GQHIP_FILTER=fp32|bf16, changed at run time by gqhip_set_filter().  Both filters feed the
 // same exact re-rank, so the choice never changes an index.
 std::atomic<int> g_filter_kind{[] {
   const char *e = getenv("GQHIP_FILTER");
-  return (e && (e[0] == 'f' || e[0] == 'F')) ? 1 : 0;
+  return (e && (e[0] == 'f' || e[0] == 'F')) ? 1 : ((e && (e[0] == 'b' || e[0] == 'B')) ? 2 : 0);
 }()};
-bool want_bf16_filter() { return g_filter_kind.load(std::memory_order_relaxed) == 0; }
+bool want_bf16_filter() { return g_filter_kind.load(std::memory_order_relaxed) != 1; }
+bool want_mixed_filter() { return g_filter_kind.load(std::memory_order_relaxed) == 0; }
 
 Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   Plan pl{};
@@ -106,6 +112,7 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   }
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
+  pl.mixed = pl.bf16 && want_mixed_filter() && dim == 16 && pl.waves == 8 && pl.ct == 16 && pl.gt == 4;
   pl.gt2 = dim <= 8 ? 4 : 2;
   int s2 = pl.tiles_total < 16 ? pl.tiles_total : 16;          // 16 splits: 4096 codes per block at N = 65 536
   pl.tiles_per_split2 = ((pl.tiles_total + s2 - 1) / s2 + pl.gt2 - 1) / pl.gt2 * pl.gt2;
@@ -116,7 +123,7 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WsLayout {
-  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, rowsum, coef, cbimg, rowimg, total;
+  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, rowsum, coef, cbimg, rowimg, rowscale, total;
 };
 
 WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
@@ -139,6 +146,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   const int64_t nvec = dim == 4 ? 2 : dim / 4;
   w.cbimg = off;  off += pl.bf16 ? align256((int64_t)(pl.tiles_total + pl.ct) * nvec * 64 * 16) : 0;
   w.rowimg = off; off += pl.bf16 ? align256(rows * nvec * 2 * 16) : 0;
+  w.rowscale = off; off += pl.mixed ? align256(4 * rows) : 0;
   w.total = off;
   return w;
 }
@@ -230,7 +238,7 @@ int launch_rerank(const RerankParams &rp, int64_t rows, int dim, hipStream_t st)
 }
 
 template <int MODE>
-int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, hipStream_t st) {
+int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool mixed, hipStream_t st) {
   const dim3 grid((unsigned)(pl.row_blocks * pl.nsplit));
   const dim3 fblock((unsigned)(64 * pl.waves));
   ProfScope prof;
@@ -253,7 +261,13 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, hipStr
       case 4: GQ_LAUNCH_BF(0, 2, 8); break;
       case 8: GQ_LAUNCH_BF(1, 2, 8); break;
       case 16:
-        if (pl.ct == 16 && pl.gt == 2) GQ_LAUNCH_BF1(2, 2, 16, 2, 8);
+        if (mixed) {
+          if (prof.on)
+            hipExtLaunchKernelGGL((gq_filter_bf16_kernel<2, 2, 16, 4, 8, true>), grid, fblock, 0, st, prof.a, prof.b, 0, fp);
+          else
+            hipLaunchKernelGGL((gq_filter_bf16_kernel<2, 2, 16, 4, 8, true>), grid, fblock, 0, st, fp);
+        }
+        else if (pl.ct == 16 && pl.gt == 2) GQ_LAUNCH_BF1(2, 2, 16, 2, 8);
         else if (pl.ct == 16 && pl.gt == 8) GQ_LAUNCH_BF1(2, 2, 16, 8, 8);
         else if (pl.ct == 16 && pl.gt == 4) GQ_LAUNCH_BF1(2, 2, 16, 4, 8);
         else if (pl.ct == 16) GQ_LAUNCH_BF1(2, 2, 16, 1, 8);
@@ -265,7 +279,15 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, hipStr
     switch (dim) {
       case 4: GQ_LAUNCH_BF(0, 1, 8); break;
       case 8: GQ_LAUNCH_BF(1, 1, 8); break;
-      case 16: GQ_LAUNCH_BF(2, 1, 8); break;
+      case 16:
+        if (mixed) {
+          if (prof.on)
+            hipExtLaunchKernelGGL((gq_filter_bf16_kernel<2, 1, 16, 4, 8, true>), grid, fblock, 0, st, prof.a, prof.b, 0, fp);
+          else
+            hipLaunchKernelGGL((gq_filter_bf16_kernel<2, 1, 16, 4, 8, true>), grid, fblock, 0, st, fp);
+        }
+        else GQ_LAUNCH_BF(2, 1, 8);
+        break;
       default: GQ_LAUNCH_BF(4, 1, 4); break;
     }
   }
@@ -323,8 +345,14 @@ struct PrepInput {
 };
 
 template <int MODE, bool FROM_Z>
-int launch_prep(const PrepParams &pp, int dim, hipStream_t st) {
+int launch_prep(const PrepParams &pp, int dim, bool mixed, hipStream_t st) {
   const dim3 grid((unsigned)(pp.row_blocks + kPrepCodeBlocks));
+  if constexpr (MODE == kModeGQ) {
+    if (mixed && dim == 16) {
+      hipLaunchKernelGGL((gq_prep_kernel<MODE, 16, FROM_Z, true>), grid, dim3(256), 0, st, pp);
+      return check_launch();
+    }
+  }
   switch (dim) {
     case 4: hipLaunchKernelGGL((gq_prep_kernel<MODE, 4, FROM_Z>), grid, dim3(256), 0, st, pp); break;
     case 8: hipLaunchKernelGGL((gq_prep_kernel<MODE, 8, FROM_Z>), grid, dim3(256), 0, st, pp); break;
@@ -370,7 +398,9 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   rp.level = 1;
   rp.spread = reinterpret_cast<SpreadSlot *>(ws + w.spread);
   rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
+  const bool mixed = pl.mixed && MODE == kModeGQ;
   rp.ef_coeff = pl.bf16 ? (float)(dim == 4 ? 332 : 220 + 24 * dim) : (float)(2 * dim + 4);
+  if (mixed) { rp.ef_coeff = kMixedEfCoeff; rp.n1_limit = kMixedN1Limit; }
   static const double env_ef = getenv("GQHIP_EF_COEFF") ? atof(getenv("GQHIP_EF_COEFF")) : 0.0;   // diagnostics
   if (env_ef > 0.0) rp.ef_coeff = (float)env_ef;
   rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
@@ -407,7 +437,8 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   pp.hdr = hdr; pp.rows = rows; pp.n = (int)n; pp.tiles_total = pl.tiles_total;
   pp.row_blocks = (int)((rows * dim + 255) / 256);
   pp.beta = (float)beta; pp.omap = omap;
-  int rc = from_z ? launch_prep<MODE, true>(pp, (int)dim, st) : launch_prep<MODE, false>(pp, (int)dim, st);
+  pp.rowscale = mixed ? reinterpret_cast<float *>(ws + w.rowscale) : nullptr;
+  int rc = from_z ? launch_prep<MODE, true>(pp, (int)dim, mixed, st) : launch_prep<MODE, false>(pp, (int)dim, mixed, st);
   if (rc != GQHIP_OK) return rc;
 
   // ---- launch 2: the filter ---------------------------------------------------------------------------------
@@ -420,7 +451,8 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
     fp.hdr = hdr;
     fp.dbg = ws + w.rec2;   // diagnostic builds only (the cascade's records: unused until the tail kernel)
-    rc = launch_filter_bf16<MODE>(pl, fp, (int)dim, st);
+    fp.rowscale = mixed ? reinterpret_cast<const float *>(ws + w.rowscale) : nullptr;
+    rc = launch_filter_bf16<MODE>(pl, fp, (int)dim, mixed, st);
     if (rc != GQHIP_OK) return rc;
     // Cascade: when more than kCascadeMin rows are undecided (ill-conditioned inputs: the split-bf16 margin is ~16x
     // the fp32 one), the tail kernel sends them through the fp32 MFMA filter + re-rank before the fp64 second stage.
@@ -450,7 +482,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   RerankParams r2 = rp;
   if (pl.bf16) {
     r2.rec = reinterpret_cast<const Rec *>(ws + w.rec2);
-    r2.nsplit = pl.nsplit2; r2.gt = pl.gt2; r2.ef_coeff = (float)(2 * dim + 4);
+    r2.nsplit = pl.nsplit2; r2.gt = pl.gt2; r2.ef_coeff = (float)(2 * dim + 4); r2.n1_limit = 0.f;
   }
   r2.level = 2;
   return launch_tail<MODE>(r2, f2, (int)dim, st);
@@ -476,7 +508,7 @@ const char *gqhip_status_string(int s) {
 int gqhip_last_hip_error(void) { return g_last_hip_error; }
 
 int gqhip_set_filter(int kind) {
-  if (kind != GQHIP_FILTER_AUTO && kind != GQHIP_FILTER_FP32) return GQHIP_ERR_INVALID_ARG;
+  if (kind != GQHIP_FILTER_AUTO && kind != GQHIP_FILTER_FP32 && kind != GQHIP_FILTER_BF16) return GQHIP_ERR_INVALID_ARG;
   g_filter_kind.store(kind, std::memory_order_relaxed);
   return GQHIP_OK;
 }
@@ -488,7 +520,9 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
   const Plan pl = make_plan(rows, n, dim);
   const WsLayout w = ws_layout(rows, n, dim);
   out8[0] = w.rec; out8[1] = pl.mfma ? pl.nsplit : 0; out8[2] = pl.gt; out8[3] = pl.tiles_per_split;
-  out8[4] = pl.bf16 ? 1 : 0; out8[5] = pl.bf16 ? (dim == 4 ? 332 : 220 + 24 * dim) : 2 * dim + 4; out8[6] = pl.rt; out8[7] = pl.waves;
+  out8[4] = pl.mixed ? 2 : (pl.bf16 ? 1 : 0);   // 0 fp32 MFMA filter, 1 split-bf16, 2 fp16 + fp8 (Gaussian score)
+  out8[5] = pl.mixed ? (int)kMixedEfCoeff : (pl.bf16 ? (dim == 4 ? 332 : 220 + 24 * dim) : 2 * dim + 4);
+  out8[6] = pl.rt; out8[7] = pl.waves;
   return GQHIP_OK;
 }
 

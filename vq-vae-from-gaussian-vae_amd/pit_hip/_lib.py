@@ -835,12 +835,13 @@ def debug_enable(on: bool) -> None:
     lib().gqhip_debug_enable(1 if on else 0)
 
 
-FILTER_KINDS = {"auto": 0, "fp32": 1}
+FILTER_KINDS = {"auto": 0, "fp32": 1, "bf16": 2}
 
 
 def set_filter(kind: str) -> None:
-    """"auto": split-bf16 MFMA filter (dims 4/8/16/32; other dims use the exhaustive kernel either way); "fp32": always
-    the fp32 MFMA filter.  Process-wide; indices are identical either way (the exact re-rank decides)."""
+    """"auto": fp16 + fp8 MFMA filter at dim 16 (Gaussian score), split-bf16 at the other MFMA dims and for VQ (other dims use
+    the exhaustive kernel either way); "fp32": always the fp32 MFMA filter; "bf16": split-bf16 wherever it applies.
+    Process-wide; indices are identical whichever runs (the exact re-rank decides)."""
     if kind not in FILTER_KINDS:
         raise GqHipError(f"unknown filter {kind!r} (expected one of {sorted(FILTER_KINDS)})")
     _check(lib().gqhip_set_filter(FILTER_KINDS[kind]), "gqhip_set_filter")
