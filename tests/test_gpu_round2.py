@@ -858,3 +858,43 @@ def test_attn_block_f16x3_and_fp32_routes_agree():
     assert (s0 is None) == (s1 is None)
     if s0 is not None:
         assert torch.allclose(s0[0], s1[0], rtol=1e-5, atol=1e-2)
+
+
+@pytest.mark.parametrize("cb_scale,expect_all_listed", [(1.0, False), (3.0, False), (3.6, True), (40.0, True), (0.2, True)])
+def test_fp16_fp8_filter_codebook_range_and_degenerate_rows(cb_scale, expect_all_listed):
+    """The fp16 + fp8 filter (dim 16, "auto") assumes 1 <= max|codebook| <= 16 for its operand formats and its bound: any other
+    codebook must send every row through the cascade (fp32 filter, fp64 stage) -- same indices as the oracle either way.  Rows whose coefficients
+    cannot be normalised (sd = 1, mu = 0 with beta = 1: every coefficient is zero) and rows with coefficients spread over
+    many decades are decided exactly too."""
+    from oracle import gq_oracle as O
+    from pit_hip import _lib
+
+    assert _lib.get_filter() == "auto"
+    rows, dim, n = 1536, 16, 8192
+    g = torch.Generator().manual_seed(77)
+    mu = 0.9 * torch.randn(rows, dim, generator=g)
+    sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(rows, dim, generator=g)))
+    mu[:8] = 0.0
+    sd[:8] = 1.0                                           # A = B = 0: no normalisation exists
+    sd[8:40] = torch.exp(torch.rand(32, dim, generator=g) * 16.0 - 11.0)   # sigmas from 1.7e-5 to 150 inside one row
+    mu[8:40] *= 4.0
+    cb = (O.codebook(n, dim, 42) * np.float32(cb_scale)).astype(np.float32)
+    assert _lib.debug_plan(rows, n, dim)["bf16"] == 2
+    lsd = O.torch_log(sd.numpy())
+    ws = _lib.Workspace()
+    _lib.debug_enable(True)
+    try:
+        idx, zhat = _lib.gq_argmax(mu.to(DEV), sd.to(DEV), torch.from_numpy(cb).to(DEV), 1.0,
+                                   logsd=torch.from_numpy(lsd).to(DEV), ws=ws)
+        torch.cuda.synchronize()
+        listed, _ = _lib.debug_counters(ws)
+    finally:
+        _lib.debug_enable(False)
+    ref, _ = O.argmax_rows(mu.numpy(), sd.numpy(), cb, 1.0, logstd=lsd)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(zhat.cpu().numpy(), cb[ref])
+    print(f"codebook x{cb_scale:g} (max {np.abs(cb).max():.1f}): {listed} of {rows} rows listed for the cascade")
+    if expect_all_listed:
+        assert listed == rows
+    else:
+        assert 8 <= listed < rows // 4

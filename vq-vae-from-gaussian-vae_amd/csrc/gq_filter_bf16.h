@@ -102,10 +102,11 @@ __device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[BfLayout<NV>::N
 // correction types together are ONE v_mfma_scale_f32_32x32x64_f8f6f4 with OCP e4m3 operands: K block 0 = (s_l 2^11) x
 // (A_h 2^-6), K block 1 = s_h x (A_l 2^6), the E8M0 block scales 2^-11 2^6 and 2^-6 put them back (constants: the row's
 // coefficients are normalised by a power of two 2^-e_r in gq_prep_kernel so that their largest is in [2^13, 2^14); the
-// record values leave this kernel multiplied by 2^e_r).  A correction is 2^-11 of its product and an e4m3 operand carries
-// a relative rounding error <= 2^-4, so each correction type is accurate to 2^-15 |A s|: representation error <= 1070 u
-// per product (u = 2^-24) against 196 u for the split-bf16 form -- a wider re-rank margin (`ef_coeff` 1340, incl. 4 u per
-// accumulation step of the main product and 2 u per step of the corrections), the same indices.  MFMA passes per tile
+// record values leave this kernel multiplied by 2^e_r).  A correction is at most 2^-11 of its product (fp16: 11 significant
+// bits) and an e4m3 operand carries a relative rounding error <= 2^-4, so each correction type is accurate to
+// (2^-3 + 2^-8) 2^-11 |A s| = 1057 u |A s| (u = 2^-24): representation error <= 2130 u per product against 196 u for the
+// split-bf16 form -- a wider re-rank margin (`ef_coeff` 2450, incl. 4 u per accumulation step of the main product and 2 u
+// per step of the corrections; derivation in DESIGN.md section 3), the same indices.  MFMA passes per tile
 // and row tile: 2 x 8 + 16 = 32 instead of 6 x 8 = 48 (the block-scaled fp8 instruction runs K = 64 in 16 passes).
 // Measured layout of the scaled instruction (tools/mfma_f8_layout.hip): byte j of lane (r, h) is k = 16 h + (j & 15) +
 // 32 (j >> 4) -- the first 16 bytes belong to K block 0, the last 16 to block 1 --, and block b of row / column r takes

@@ -84,9 +84,10 @@ struct RerankParams {
   int nsplit;
   int gt;             // tiles per candidate group -- must match the filter's GT
   float ef_coeff;     // filter error bound E_f = ef_coeff * 2^-24 * T  (fp32 filter: 2 dim + 4; split-bf16: 220 + 24 dim;
-                      // fp16 + fp8: 1340)
-  float n1_limit;     // > 0: the filter's operand formats assume max|cb| <= n1_limit (fp16 + fp8 images: 16); a larger
-                      // codebook makes every row undecided (cascade: fp32 filter, fp64 second stage)
+                      // fp16 + fp8: 2450)
+  float n1_limit;     // > 0: the filter's operand formats assume 1 <= max|cb| <= n1_limit (fp16 + fp8 images: 16; below 1 the
+                      // absolute errors of fp8-subnormal operands are not covered by the bound); any other codebook makes
+                      // every row undecided (cascade: fp32 filter, fp64 second stage)
   int all_rows;       // exhaustive kernel: process every row (no filter ran)
   int stats;          // count re-ranked half-pairs (debug)
   OutMap omap;
@@ -319,7 +320,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   const double margin = 2.5 * ((double)p.ef_coeff * u * T + Er) + 1e-30;      // around the filter's row maximum
   const float margin32 = (float)(2.5 * ((2.0 * DIM + 4.0) * u * T + Er) * 1.0000002 + 1e-30);   // around pass 1's F (rounded up)
   bool bad = !(N1 == N1) || N1 > 1e18 || !(T < 1e30) || !(G < 1e30) || !(margin < 1e30);
-  if (p.level == 1 && p.n1_limit > 0.f && !(N1f <= p.n1_limit)) bad = true;
+  if (p.level == 1 && p.n1_limit > 0.f && !(N1f <= p.n1_limit && N1f >= 1.0f)) bad = true;
 
   float fmax = NEG_INF;
 #pragma unroll

@@ -56,8 +56,12 @@ struct Plan {
   bool mixed;           // dim 16, Gaussian score: fp16 main product + fp8 corrections instead of three bf16 products
 };
 
-constexpr float kMixedEfCoeff = 1340.0f;   // gq_filter_bf16.h: 1070 (representation) + 4 * 32 + 2 * 64 (accumulation) + slack
-constexpr float kMixedN1Limit = 16.0f;
+// gq_filter_bf16.h / DESIGN.md section 3: 2 x 1057 (the two fp8 correction types: (2^-3 + 2^-8) relative on a term of at most
+// 2^-11 (1 + 2^-11) |A s|) + 4 (dropped A_l s_l) + 1 (fp32 square) + 42 (operands in the fp8 / fp16 subnormal ranges: absolute
+// errors, bounded against T for 1 <= max|cb| <= 16) + 4 * 32 + 2 * 64 (accumulation steps of the main product / of the
+// corrections) = 2417, rounded up
+constexpr float kMixedEfCoeff = 2450.0f;
+constexpr float kMixedN1Limit = 16.0f;   // ... and max|cb| >= 1 (gq_rerank.h)
 
 // Filter selection: 0 = auto (fp16 + fp8 at dim 16 / Gaussian score, split-bf16 at the other MFMA dims), 1 = always the
 // fp32 MFMA filter, 2 = split-bf16 wherever it applies (no fp16 + fp8).
