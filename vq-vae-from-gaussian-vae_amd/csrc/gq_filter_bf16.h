@@ -381,6 +381,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   for (int rt = 0; rt < RT; ++rt) {
     float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt], a4 = m4[rt];
     int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h, j3 = i3[rt] * 2 + h;   // half-group ids
+    if constexpr (MIXED) {
+      // One record per LANE HALF (the re-rank sees 2 nsplit "splits"): the wider margin of this filter makes "a fourth
+      // group of one record within the margin" -- an undecided row: ~12 us of fp64 second stage for a lone row -- about
+      // as likely as not per call with merged records (1 row in 16 384 at config 2); half the codes per record makes it
+      // ~8x rarer, and the merge below is not needed.
+      const int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;
+      if (row < p.rows) {
+        const float rs = p.rowscale[row];      // back to true units: the row's coefficients were normalised by 2^-e_r
+        Rec r;
+        r.m1 = a1 * rs; r.m2 = a2v * rs; r.m3 = a3 * rs; r.m4 = a4 * rs; r.id1 = j1; r.id2 = j2; r.id3 = j3;
+        r.pad = 0;
+        p.rec[(long)(split * 2 + h) * p.rows + row] = r;
+      }
+      continue;
+    }
     if constexpr (TOP4) {
       const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2v, 32), b3 = __shfl_xor(a3, 32), b4 = __shfl_xor(a4, 32);
       const int k1 = __shfl_xor(j1, 32), k2 = __shfl_xor(j2, 32), k3 = __shfl_xor(j3, 32);
@@ -402,10 +417,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     }
     const int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;
     if (h == 0 && row < p.rows) {
-      if constexpr (MIXED) {      // back to true units: the row's coefficients were normalised by 2^-e_r
-        const float rs = p.rowscale[row];
-        a1 *= rs; a2v *= rs; a3 *= rs; a4 *= rs;
-      }
       Rec r;
       r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.m4 = a4; r.id1 = j1; r.id2 = j2; r.id3 = j3;
       r.pad = 0;

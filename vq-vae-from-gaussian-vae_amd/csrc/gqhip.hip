@@ -117,6 +117,12 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   pl.mixed = pl.bf16 && want_mixed_filter() && dim == 16 && pl.waves == 8 && pl.ct == 16 && pl.gt == 4;
+  if (pl.mixed && pl.nsplit > kMaxSplit / 2) {
+    // the fp16 + fp8 filter leaves one record per lane half: 2 nsplit record sets for the re-rank (<= kMaxSplit)
+    const int s3 = kMaxSplit / 2;
+    pl.tiles_per_split = ((pl.tiles_total + s3 - 1) / s3 + pl.gt - 1) / pl.gt * pl.gt;
+    pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
+  }
   pl.gt2 = dim <= 8 ? 4 : 2;
   int s2 = pl.tiles_total < 16 ? pl.tiles_total : 16;          // 16 splits: 4096 codes per block at N = 65 536
   pl.tiles_per_split2 = ((pl.tiles_total + s2 - 1) / s2 + pl.gt2 - 1) / pl.gt2 * pl.gt2;
@@ -135,7 +141,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   WsLayout w{};
   int64_t off = 0;
   w.hdr = off; off += (int64_t)sizeof(WsHeader);
-  w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit : 0));
+  w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit * (pl.mixed ? 2 : 1) : 0));
   w.fb = off;  off += align256(4 * rows);
   // cascade behind the split-bf16 filter: list B + the second-level fp32 filter's records (kCascadeSplit splits)
   w.fb2 = off;  off += pl.bf16 ? align256(4 * rows) : 0;
@@ -407,7 +413,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   if (mixed) { rp.ef_coeff = kMixedEfCoeff; rp.n1_limit = kMixedN1Limit; }
   static const double env_ef = getenv("GQHIP_EF_COEFF") ? atof(getenv("GQHIP_EF_COEFF")) : 0.0;   // diagnostics
   if (env_ef > 0.0) rp.ef_coeff = (float)env_ef;
-  rp.beta = (float)beta; rp.nsplit = pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
+  rp.beta = (float)beta; rp.nsplit = mixed ? 2 * pl.nsplit : pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
 
   if (!pl.mfma) {
@@ -523,7 +529,8 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
   if (!out8 || rows < 1 || n < 1 || dim < 1 || dim > kMaxDim) return GQHIP_ERR_INVALID_ARG;
   const Plan pl = make_plan(rows, n, dim);
   const WsLayout w = ws_layout(rows, n, dim);
-  out8[0] = w.rec; out8[1] = pl.mfma ? pl.nsplit : 0; out8[2] = pl.gt; out8[3] = pl.tiles_per_split;
+  out8[0] = w.rec; out8[1] = pl.mfma ? pl.nsplit * (pl.mixed ? 2 : 1) : 0;   // record sets per row (fp16 + fp8: one per lane half)
+  out8[2] = pl.gt; out8[3] = pl.tiles_per_split;
   out8[4] = pl.mixed ? 2 : (pl.bf16 ? 1 : 0);   // 0 fp32 MFMA filter, 1 split-bf16, 2 fp16 + fp8 (Gaussian score)
   out8[5] = pl.mixed ? (int)kMixedEfCoeff : (pl.bf16 ? (dim == 4 ? 332 : 220 + 24 * dim) : 2 * dim + 4);
   out8[6] = pl.rt; out8[7] = pl.waves;
