@@ -558,14 +558,15 @@ def main():
                        "global_batch": args.batch * world, "rows_per_step_per_gpu": rows,
                        "weights": "seeded random init (seed 1234), no checkpoint offline",
                        "parallelism": f"dp{world} image-sharded, one packed all_gather/step"},
-            "gemm_precision": "fp32 results end to end.  The 3x3 convolutions of the 256x256 level and of the encoder's 128x128 "
-                              "level run as libgqhip's direct implicit GEMM on the fp16 matrix cores, the Winograd / sub-pixel GEMMs of "
-                              "the other levels as ONE fp16 hipBLASLt GEMM over a K axis of split products -- both with fp32 accumulation "
-                              "of the three products of two-term fp16 splits of both operands (22-bit significands, power-of-two scales "
-                              "from a rigorous GroupNorm bound): measured error 2.3-2.9e-7 of sum|a||b| vs 2.6-3.5e-7 for hipBLASLt's own "
-                              "fp32 GEMM, which on gfx950 is itself a split-bf16 emulation (tools/conv3_bench.py, tools/bmm_bf16x3.py, "
-                              "tests/test_gpu_round2.py); conv_out: fp32 FMAs; attention GEMMs: hipBLASLt fp32; the remaining "
-                              "convolutions (1x1, stride 2, conv_in): MIOpen native fp32 MFMA",
+            "gemm_precision": "fp32 results end to end.  Every wide convolution and GEMM of the conv stack runs on the fp16 matrix "
+                              "cores with fp32 accumulation of the three products of two-term fp16 splits of both operands (22-bit "
+                              "significands, power-of-two scales from rigorous bounds): libgqhip's direct implicit GEMM for the 3x3 "
+                              "convolutions of the 256x256 level and the encoder's 128x128 level, its 1x1 / stride-2 kernels, its own "
+                              "Winograd GEMM at the 256-channel level; ONE fp16 hipBLASLt GEMM over a K axis of split products for the "
+                              "other Winograd / sub-pixel GEMMs and for the two attention GEMMs.  Measured error 1.8-2.9e-7 of sum|a||b| "
+                              "vs 2.6-3.5e-7 for hipBLASLt's own fp32 GEMM, which on gfx950 is itself a split-bf16 emulation "
+                              "(tools/conv3_bench.py, tools/bmm_bf16x3.py, tools/wino_gemm2_bench.py, tests/test_gpu_round2.py); "
+                              "conv_out: fp32 FMAs; conv_in and the encoder's conv_out: MIOpen native fp32 MFMA",
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "dist_backend": args.dist_backend if world > 1 else None,
             "gather_ms": {"p50": pick(gather_ms, 0.5), "p90": pick(gather_ms, 0.9),
