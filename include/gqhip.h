@@ -263,6 +263,15 @@ int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf,
 int conv3x3s2_f16x3(const float *x, const void *Wf, const float *scales_dev_or_null, float scale, float mscale,
                     const float *bias_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t Hin, int64_t Win,
                     int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
+/* The reference's Upsample (pit/modules/unet.py:60-73: nearest x2, then conv 3x3) Cin -> Cout (128, 256 or 512) as its sub-pixel
+ * form computed directly: output phase (a, b) = a 2x2 convolution of the low-resolution input with the phase weights (sums of
+ * the 3x3 taps landing on the same source pixel), fp16 x 3, one kernel: no patch matrix, no pixel-shuffle pass.
+ * x [B, H, W, Cin] fp32 (not normalised; scale as for conv1x1_f16x3), y [B, 2H, 2W, Cout] = conv * mscale + bias; stats_out
+ * optional (GroupNorm statistics of y).  H % 8 == 0, W % 32 == 0, Cin % 16 == 0.  Wf [4, 4 Cin/16, Cout/32, 2, 64, 8]:
+ * operand-order phase weights, [phase 2a + b][chunk][tap 2u + v], tap (u, v) reading x[i - 1 + a + u][j - 1 + b + v]. */
+int upconv2x_f16x3(const float *x, const void *Wf, const float *scales_dev_or_null, float scale, float mscale,
+                   const float *bias_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t H, int64_t W,
+                   int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
 /* 3x3 convolution (stride 1, zero padding 1) into 1..4 channels with GroupNorm (+ SiLU) of the input fused in, fp32 FMAs:
  * the decoder's conv_out(swish(norm_out(h))) (reference pit/modules/unet.py:585-587).  x [B, H, W, Cin] fp32, w_ohwi
  * [Cout, 3, 3, Cin] fp32, y [B, H, W, Cout].  H % 16 == 0, W % 16 == 0, Cin % 32 == 0, Cin <= 512. */

@@ -898,3 +898,42 @@ def test_fp16_fp8_filter_codebook_range_and_degenerate_rows(cb_scale, expect_all
         assert listed == rows
     else:
         assert 8 <= listed < rows // 4
+
+
+def test_upconv2x_direct_matches_fp64_and_the_library_route():
+    """Upsample (nearest x2 + conv 3x3, unet.py:60-73) as libgqhip's direct sub-pixel fp16 x 3 convolution: against an fp64
+    convolution of the upsampled tensor (error at the level of the library route: im2col + fp16 x 3 GEMM + pixel shuffle), the
+    statistics it leaves equal those of its output, bias included; shapes of all three decoder levels, borders included."""
+    import torch.nn.functional as F
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(31)
+    for ch, B, H, W in ((512, 2, 32, 32), (256, 2, 24, 64), (512, 1, 8, 32)):
+        up = U.Upsample(ch).to(DEV).eval().to(memory_format=torch.channels_last)
+        x = (3.0 * torch.randn(B, ch, H, W, device=DEV)).contiguous(memory_format=torch.channels_last)
+        x._gn_stats = (_lib.gn_stats(x, 32), 32)
+        with torch.no_grad():
+            ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), up.conv.weight.double(),
+                           up.conv.bias.double(), 1, 1)
+            scale = float(ref.abs().mean())
+            old = U.DIRECT_UPCONV
+            try:
+                U.DIRECT_UPCONV = False
+                y_lib, pb = up(x)
+                y_lib = y_lib + pb[None, :, None, None]
+                U.DIRECT_UPCONV = True
+                y_dir, pb2 = up(x)
+            finally:
+                U.DIRECT_UPCONV = old
+        assert pb2 is None and tuple(y_dir.shape) == (B, ch, 2 * H, 2 * W)
+        e_lib = float((y_lib.double() - ref).abs().max()) / scale
+        e_dir = float((y_dir.double() - ref).abs().max()) / scale
+        print(f"upsample {ch} ch {H}x{W}: library route {e_lib:.2e}, direct {e_dir:.2e} (of mean |y|)")
+        assert e_dir <= 1.5 * e_lib + 1e-6, (e_dir, e_lib)
+        st, groups = y_dir._gn_stats
+        assert groups == 32 and torch.allclose(st, _lib.gn_stats(y_dir.contiguous(memory_format=torch.channels_last), 32), rtol=1e-6, atol=1e-3)
+    # shapes the kernel does not tile are refused by the binding (the module then takes the library route)
+    wf, us = _lib.upconv_weights_f16(torch.randn(4 * 128, 4 * 128, device=DEV), 128, 128)
+    with pytest.raises(_lib.GqHipError):
+        _lib.upconv2x_direct(torch.randn(1, 128, 12, 32, device=DEV).contiguous(memory_format=torch.channels_last), wf, us, 10.0)

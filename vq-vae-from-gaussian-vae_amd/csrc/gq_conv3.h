@@ -650,6 +650,147 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(const Conv3S2Pa
   conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
 }
 
+// ---- "nearest x2 upsample, then 3x3 convolution" (Upsample, unet.py:60-73) as its sub-pixel form, computed directly: output
+// phase (a, b) = (oy & 1, ox & 1) is a 2x2 convolution of the LOW-resolution input,
+//     y[2i + a][2j + b] = sum_{u, v in {0,1}} Wp[a][b][u][v] x[i - 1 + a + u][j - 1 + b + v]     (zero outside the image),
+// with Wp = the sums of the 3x3 taps that land on the same source pixel (a = 0: rows {0}, {1,2}; a = 1: {0,1}, {2}).  The
+// library route wrote the 2x2 patches as a [rows, 12 Cin] fp16 matrix (1.6 GB at 16 x 128^2 x 256), multiplied it by all four
+// phases at once and interleaved the result with a pixel-shuffle pass (1 GB read + 1 GB written); here a block computes 8 x 32
+// low-resolution positions x 128 output channels of ONE phase with the machinery of the stride-2 kernel above (9 x 33 patch,
+// four taps per 16-channel chunk), reads x four times out of L2 / the Infinity Cache instead, writes every output pixel once
+// and leaves the GroupNorm statistics of the result (the next ResnetBlock's norm1 needs them).  gridDim.y = 4 phases.
+// Wf: [phase 2a + b][chunk][tap 2u + v][cout/32][2][64][8] -- _lib.upconv_weights_f16.
+struct Upconv2Params {
+  Conv3Params c;            // H, W: INPUT (low-resolution) size, tiles over it; y is [B][2H][2W][cout]
+  const float *x;           // [B][H][W][cin]
+  const float *scales_dev;  // {scale, 1 / (scale * u_scale)} or null
+  float scale;
+  int cin;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256, 2) void upconv2x_f16x3_kernel(const Upconv2Params pp) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  Conv3Params p = pp.c;
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kC3Buf];
+  __shared__ double red[2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  Conv3Tile t;
+  if (!conv3_tile(p, t)) return;
+  const int pa = (int)blockIdx.y >> 1, pb = (int)blockIdx.y & 1;
+  if (tid < 128) red[tid] = 0.0;
+  const float scale = pp.scales_dev ? pp.scales_dev[0] : pp.scale;
+  if (pp.scales_dev) p.mscale = pp.scales_dev[1];
+  const int cin = pp.cin, nch = p.nch, H = p.H, W = p.W;
+  constexpr int PR = kC3TH + 1, PC = kC3TW + 1, NP = 5;      // patch 9 x 33 pixels; pieces per thread (297 x 4 / 256)
+  const int w = tid & 3, qs = tid >> 2;
+  const float *xb = pp.x + t.b * (long)H * W * cin + 4 * w;
+  int goff[NP], loff[NP];
+  unsigned inb = 0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int q = qs + 64 * i;
+    const int qq = q < PR * PC ? q : PR * PC - 1;
+    const int R = qq / PC, X = qq % PC;
+    const int gy = t.y0 + R + pa - 1, gx = t.x0 + X + pb - 1;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    goff[i] = (cy * W + cx) * cin;
+    loff[i] = q < PR * PC ? conv3_lds_off(R, X, w >> 1) + 8 * (w & 1) : -1;
+    inb |= (unsigned)(in ? 1 : 0) << i;
+  }
+  f32x4 st[NP];
+  auto issue = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) st[i] = *reinterpret_cast<const f32x4 *>(xb + goff[i] + chunk * 16);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (loff[i] < 0) continue;
+      const f32x4 v = st[i] * (((inb >> i) & 1) ? scale : 0.f);
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)v[e];
+        lo[e] = (_Float16)(v[e] - (float)hi[e]);
+      }
+      unsigned char *d = sA + buf * kC3Buf + loff[i];
+      *reinterpret_cast<f16x4 *>(d) = hi;
+      *reinterpret_cast<f16x4 *>(d + kC3Plane) = lo;
+    }
+  };
+  f32x16 acc[4][2];
+  GQ_C3_ZERO_ACC(acc);
+  int aoff[2];
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx) aoff[dx] = conv3_lds_off(4 * wm, c + dx, h);
+  const long wstep = (long)p.nnb * (512 * 16);   // bytes per k-step
+  const int nks = 4 * nch;
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + (long)blockIdx.y * nks * wstep +
+                               (4 * t.nb + 2 * wn) * 128 * 16;
+  const int wl = lane * 16;
+  f16x8 bq[4], bn[4];
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+    const unsigned char *s = wbase + ks * wstep;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
+  };
+  load_b(0, bq);
+  issue(0);
+  commit(0);
+  __syncthreads();
+  int ks = 0;
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const bool more = chunk + 1 < nch;
+    if (more) issue(chunk + 1);
+    const unsigned char *A = sA + (chunk & 1) * kC3Buf;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {           // tap (u, v) = (ti >> 1, ti & 1)
+      load_b(ks + 1 < nks ? ks + 1 : ks, bn);
+      conv3_tap(A + aoff[ti & 1], ti >> 1, bq, acc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bq[k] = bn[k];
+      ++ks;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) commit((chunk + 1) & 1);
+    __syncthreads();
+  }
+  // ---- epilogue: register r of lane (c, h) = low-resolution position (y0 + 4 wm + rr, x0 + (r & 3) + 8 (r >> 2) + 4 h), i.e.
+  // output pixel (2 y + pa, 2 x + pb); channel (2 wn + j) * 32 + c: every store instruction still writes 128-byte runs ----
+  float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+  constexpr int cout = COUT;
+  const long W2 = 2L * W;
+  const long pix0 = ((t.b * 2L * H + 2 * (t.y0 + 4 * wm) + pa) * W2 + 2 * (t.x0 + 4 * h) + pb) * cout + t.nb * 128;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = (2 * wn + j) * 32 + c;
+    const float pbias = p.bias ? p.bias[t.nb * 128 + n] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[rr][j][r] * p.mscale + pbias;
+        p.y[pix0 + ((long)rr * 2 * W2 + 2 * ((r & 3) + 8 * (r >> 2))) * cout + n] = v;
+        s[j] += v;
+        ss[j] += v * v;
+      }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = ((2 * wn + j) * 32 + c) / p.cpg;      // group within this block's 128 channels
+      atomicAdd(&red[2 * g], (double)s[j]);
+      atomicAdd(&red[2 * g + 1], (double)ss[j]);
+    }
+    __syncthreads();
+    const int gpb = 128 / p.cpg, groups = cout / p.cpg;    // groups per block, per image
+    if (tid < 2 * gpb) atomicAdd(&p.stats[2 * (t.b * groups + t.nb * gpb) + tid], red[tid]);
+  }
+}
+
 // ---- 3x3 convolution (stride 1, zero padding 1) into a handful of channels (conv_out: 128 -> 3, unet.py:585-587) with the
 // GroupNorm + SiLU of its input fused in: fp32 FMAs on the vector ALU.  With 3 output channels there is no GEMM to speak of
 // (3456 FMAs per pixel, 7 GFLOP per 16 x 256 x 256 batch) and the job is to read the activation once: MIOpen's implicit GEMM

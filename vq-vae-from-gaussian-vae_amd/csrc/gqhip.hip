@@ -1089,6 +1089,29 @@ int conv3x3s2_f16x3(const float *x, const void *Wf, const float *scales_dev_or_n
   return check_launch();
 }
 
+int upconv2x_f16x3(const float *x, const void *Wf, const float *scales_dev_or_null, float scale, float mscale,
+                   const float *bias_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t H, int64_t W,
+                   int64_t Cin, int64_t Cout, int64_t groups_out, void *stream) {
+  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 16 || Cin % 16 != 0 ||
+      (Cout != 128 && Cout != 256 && Cout != 512) || H * W > (1 << 22) || (!scales_dev_or_null && !(scale > 0.f)))
+    return GQHIP_ERR_INVALID_ARG;
+  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
+    return check_launch();
+  Upconv2Params gp{};
+  Conv3Params &cp = gp.c;
+  conv3_fill(cp, Wf, bias_or_null, nullptr, y, stats_out_or_null, B, H, W, Cin, Cout, groups_out, mscale);
+  gp.x = x; gp.scales_dev = scales_dev_or_null; gp.scale = scale; gp.cin = (int)Cin;
+  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb), 4);
+  if (Cout == 128) hipLaunchKernelGGL(upconv2x_f16x3_kernel<128>, grid, dim3(256), 0, st, gp);
+  else if (Cout == 256) hipLaunchKernelGGL(upconv2x_f16x3_kernel<256>, grid, dim3(256), 0, st, gp);
+  else hipLaunchKernelGGL(upconv2x_f16x3_kernel<512>, grid, dim3(256), 0, st, gp);
+  return check_launch();
+}
+
 int conv3x3_gn_small_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                          const double *stats_in, int64_t groups_in, double eps, int apply_silu, const float *w_ohwi,
                          const float *bias_or_null, float *y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,

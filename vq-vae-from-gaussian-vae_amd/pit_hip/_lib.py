@@ -61,6 +61,8 @@ _SIGNATURES = {
     "wino_in_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
     "wino_gemm_c128_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "wino_gemm_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "upconv2x_f16x3": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
+                                      _vp]),
     "attn_split_qkv_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float, _vp]),
     "attn_softmax_split_f16x3": (ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_float, _vp]),
     "wino_in_gn_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
@@ -709,6 +711,46 @@ def conv3x3s2_direct(x, wf, u_scale: float, scale, bias=None, stats_groups: int 
         ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
         _check(lib().conv3x3s2_f16x3(x.data_ptr(), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), y.data_ptr(),
                                      _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1), _stream()), "conv3x3s2_f16x3")
+    return (y, ostats) if stats_groups else y
+
+
+def upconv_weights_f16(phase_matrix, cin: int, cout: int):
+    """Operand-order fp16 x 3 weights of upconv2x_direct from the sub-pixel phase matrix [4 Cin, 4 Cout] (row (2u + v) Cin + ci,
+    column (2a + b) Cout + co: Upsample._phase_weights): (Wf [4, 4 Cin/16, Cout/32, 2, 64, 8] fp16 -- [phase][chunk * 4 + tap]
+    [column tile][plane][lane (hh, c)][e] = plane[tap, 16 chunk + 8 hh + e, phase, 32 tile + c] --, u_scale)."""
+    if cout not in (128, 256, 512) or cin % 16 or tuple(phase_matrix.shape) != (4 * cin, 4 * cout):
+        raise GqHipError("upconv_weights_f16 needs the [4 Cin, 4 Cout] phase matrix, Cin % 16 == 0, Cout in (128, 256, 512)")
+    w = phase_matrix.detach().float()
+    amax = float(w.abs().max())
+    u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0
+    ws = w * u_scale
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    planes = torch.stack([hi, lo], 0).reshape(2, 4, cin // 16, 2, 8, 4, cout // 32, 32)   # [pl, tap, chunk, hh, e, phase, nt, c]
+    wf = planes.permute(5, 2, 1, 6, 0, 3, 7, 4).reshape(4, 4 * (cin // 16), cout // 32, 2, 64, 8)
+    return wf.contiguous(), u_scale
+
+
+def upconv2x_direct(x, wf, u_scale: float, scale, bias=None, stats_groups: int = 0):
+    """The reference's Upsample (nearest x2 + conv 3x3) of a channels_last fp32 HIP tensor as the direct sub-pixel fp16 x 3
+    convolution (gqhip.h:upconv2x_f16x3).  ``wf, u_scale`` from upconv_weights_f16; ``scale``: a float bound >= max|x| or the
+    device float[2] of f16_scales.  Returns y [B, Cout, 2H, 2W] (+ bias), or (y, statistics of y)."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 16 or x.shape[2] % 8 or x.shape[3] % 32:
+        raise GqHipError("upconv2x_direct needs a dense channels_last fp32 HIP tensor, C % 16 == 0, H % 8 == 0, W % 32 == 0")
+    B, C, H, W = x.shape
+    cout = wf.shape[2] * 32
+    if wf.shape[0] != 4 or wf.shape[1] != 4 * (C // 16):
+        raise GqHipError("upconv2x_direct: weights do not match the input channels")
+    if torch.is_tensor(scale):
+        sdev, v_scale, mscale = scale.data_ptr(), 0.0, 0.0
+    else:
+        v_scale = min(2.0 ** math.floor(math.log2(32768.0 / max(float(scale), 1e-30))), 2.0 ** 14)
+        sdev, mscale = None, 1.0 / (v_scale * u_scale)
+    with torch.cuda.device(x.device):
+        y = torch.empty((B, cout, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+        _check(lib().upconv2x_f16x3(x.data_ptr(), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), y.data_ptr(),
+                                    _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1), _stream()), "upconv2x_f16x3")
     return (y, ostats) if stats_groups else y
 
 

@@ -303,7 +303,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
-        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkb_key", "_qkv_wf_key", "_s2_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_gb_key"):
+        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkb_key", "_qkv_wf_key", "_s2_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_phase_direct_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -373,6 +373,7 @@ FUSED_WINO_GN_F4 = True
 # also in the encoder: measured perturbation of z 4.2e-6 vs the CPU reference (direct MIOpen convs: 3.4e-6), no index
 # change on the CPU golden nor on 16 384 rows against the direct-conv encoder (tools/encoder_winograd_check.py)
 WINOGRAD_ENCODER = True
+DIRECT_UPCONV = True     # ... computed directly by libgqhip's upconv2x_f16x3 (one kernel; else im2col + library GEMM + pixel shuffle)
 SUBPIXEL_UPCONV = True   # Upsample: nearest x2 + conv3x3 as four 2x2 phase convs of the low-res input (2.25x fewer flops)
 FUSED_QKV = True         # attention: q, k, v as one GEMM with fused biases (channels_last)
 FUSED_ADD_STATS = True   # residual add also produces the next GroupNorm's statistics (channels_last only)
@@ -677,6 +678,20 @@ class Upsample(nn.Module):
 
             b, c, h, w = x.shape
             st = getattr(x, "_gn_stats", None)
+            cout = self.conv.out_channels
+            if (DIRECT_UPCONV and st is not None and cout in (128, 256, 512) and c % 16 == 0 and h % 8 == 0 and w % 32 == 0
+                    and self.conv.bias is not None and _lib.gn_nhwc_ok(cout, GN_GROUPS)):
+                # ... computed directly (libgqhip's upconv2x_f16x3: one kernel per Upsample, no patch matrix, no pixel-shuffle
+                # pass), with the bias added and the statistics of the next ResnetBlock's norm1 left behind
+                wm = self._phase_weights()
+                if getattr(self, "_phase_direct_key", None) != self._phase_key:
+                    self._phase_wf, self._phase_wf_us = _lib.upconv_weights_f16(wm, c, cout)
+                    self._phase_direct_key = self._phase_key
+                scales = _lib.f16_scales(st[0], 1.0, self._phase_wf_us)
+                y, ostats = _lib.upconv2x_direct(x, self._phase_wf, self._phase_wf_us, scales, bias=self.conv.bias,
+                                                 stats_groups=GN_GROUPS)
+                y._gn_stats = (ostats, GN_GROUPS)
+                return y, None
             if WINOGRAD_F16X3 and st is not None:
                 # the GEMM as fp16 x 3 over K (see WINOGRAD_F16X3); the activation's scale comes, on the device, from the
                 # GroupNorm statistics its producer left behind (sqrt of a group's sum of squares bounds its largest element)
