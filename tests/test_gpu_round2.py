@@ -470,7 +470,7 @@ def test_gn_act_bound_is_a_bound_and_unet_agrees_with_fp32_gemms():
     assert d_dec <= 2e-5 and d_enc <= 2e-5
 
 
-def test_subpixel_upconv_f16x3_matches_fp32_route():
+def test_subpixel_upconv_f16x3_matches_fp32_route(request):
     """Upsample (nearest x2 + conv3x3) through the fp16 x 3 GEMM with device-side scales from the GroupNorm statistics:
     same accuracy against an fp64 reference as the fp32-GEMM route, also when the tensor carries a huge outlier (the
     bound is rigorous: sqrt of the group's sum of squares)."""
@@ -479,6 +479,8 @@ def test_subpixel_upconv_f16x3_matches_fp32_route():
     from pit_hip.modules import unet as U
 
     torch.manual_seed(8)
+    U.DIRECT_UPCONV = False          # this test is about the library route (im2col + fp16 x 3 GEMM + pixel shuffle)
+    request.addfinalizer(lambda: setattr(U, "DIRECT_UPCONV", True))
     for ch, H, W, outlier in ((256, 16, 16, 0.0), (512, 8, 12, 0.0), (128, 32, 32, 3e4)):
         up = U.Upsample(ch).eval().to(DEV).to(memory_format=torch.channels_last)
         x = torch.randn(2, ch, H, W)
@@ -909,9 +911,12 @@ def test_upconv2x_direct_matches_fp64_and_the_library_route():
     from pit_hip.modules import unet as U
 
     torch.manual_seed(31)
-    for ch, B, H, W in ((512, 2, 32, 32), (256, 2, 24, 64), (512, 1, 8, 32)):
+    for ch, B, H, W, outlier in ((512, 2, 32, 32, 0.0), (256, 2, 24, 64, 0.0), (512, 1, 8, 32, 0.0), (128, 2, 32, 32, 3e4)):
         up = U.Upsample(ch).to(DEV).eval().to(memory_format=torch.channels_last)
-        x = (3.0 * torch.randn(B, ch, H, W, device=DEV)).contiguous(memory_format=torch.channels_last)
+        x = 3.0 * torch.randn(B, ch, H, W, device=DEV)
+        if outlier:
+            x[1, 7, 3, 5] = outlier     # the device-side scale comes from a rigorous bound: no overflow, same accuracy elsewhere
+        x = x.contiguous(memory_format=torch.channels_last)
         x._gn_stats = (_lib.gn_stats(x, 32), 32)
         with torch.no_grad():
             ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), up.conv.weight.double(),
