@@ -234,4 +234,103 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_f16x2_kernel(const WinoGemm2
     }
 }
 
+// ---- the same GEMM with 256 x 256 block tiles for the 512-channel levels: 8 waves (2 x 4: wave = 128 rows x 64 columns), ONE
+// block per CU, a stage = 64 k of both planes (64 KiB, 96 MFMAs per wave between barriers), double buffered (2 x 64.25 KiB of
+// LDS).  Against the 256 x 128 form: every row tile is read once per TWO column blocks of a 512-column output instead of
+// once per four, the loads of the next stage have 96 instead of 48 MFMAs per wave to land, half the barriers.
+__global__ __launch_bounds__(512, 1) void wino_gemm_f16x2_w8_kernel(const WinoGemm2Params p) {
+  // eight (k16 chunk, plane) regions, 32 bytes apart modulo 256: the loader's ds_write_b128 of 16 lanes (one row: 16 pieces,
+  // two per region) covers all 64 banks
+  constexpr int kPlane = 256 * 32 + 32, kChunk = 2 * kPlane, kStage = 4 * kChunk;
+  static_assert(kChunk % 256 == 64 && kPlane % 256 == 32, "region stagger");
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kStage];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+  const long vb = blockIdx.x, kq = vb >> 3;
+  const int nb = (int)(kq % p.nnb);                 // nnb = cout / 256 here
+  const long tile = (vb & 7) * p.tiles_per_xcd + kq / p.nnb;
+  if (tile >= p.ntile_total) return;
+  const long pos = tile / p.mtiles, m0 = (tile % p.mtiles) * 256;
+  const int cin = p.cin, nst = cin / 64;
+  // loader: thread -> 16-byte piece w16 = tid & 15 of a row's stage (plane w16 >> 3, k16 chunk (w16 >> 1) & 3, half w16 & 1),
+  // rows (tid >> 4) + 32 i
+  const int w16 = tid & 15, r0 = tid >> 4, pl = w16 >> 3, jc = (w16 >> 1) & 3, jh = w16 & 1;
+  const _Float16 *src = p.V2 + ((pos * p.tiles + m0 + r0) * 2L * cin) + pl * cin + 16 * jc + 8 * jh;
+  const int loff = jc * kChunk + pl * kPlane + r0 * 32 + 16 * (jh ^ ((r0 >> 3) & 1));
+  const long rstride = 64L * cin;   // 32 rows, halfs
+  f16x8 st[8];
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = *reinterpret_cast<const f16x8 *>(src + i * rstride + stage * 64);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f16x8 *>(sA + buf * kStage + loff + i * 1024) = st[i];
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      acc[rr][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int aoff = (4 * wm) * 1024 + c * 32 + 16 * (h ^ ((c >> 3) & 1));
+  const long wstep = (long)(p.cout / 32) * 2048;   // bytes per k-step: column tiles x 2 planes x 1 KiB
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + pos * (cin / 16) * wstep +
+                               (8 * nb + 2 * wn) * 2048L;
+  const int wl = lane * 16;
+  f16x8 b0[4], b1[4];
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+    const unsigned char *s = wbase + ks * wstep;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
+  };
+  auto kstep = [&](const unsigned char *A, const f16x8 (&bq)[4]) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + aoff + rr * 1024);
+      const f16x8 al = *reinterpret_cast<const f16x8 *>(A + aoff + rr * 1024 + kPlane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j + 1], acc[rr][j], 0, 0, 0);
+        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[2 * j], acc[rr][j], 0, 0, 0);
+      }
+    }
+  };
+  const int nks = 4 * nst;
+  load_b(0, b0);
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const bool more = s + 1 < nst;
+    const unsigned char *A = sA + (s & 1) * kStage;
+    load_b(4 * s + 1, b1);
+    if (more) issue(s + 1);
+    kstep(A, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(4 * s + 2, b0);
+    kstep(A + kChunk, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(4 * s + 3, b1);
+    kstep(A + 2 * kChunk, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(4 * s + 4 < nks ? 4 * s + 4 : nks - 1, b0);
+    kstep(A + 3 * kChunk, b1);
+    if (more) commit((s + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  float *Mp = p.M + ((pos * p.tiles + m0 + 4 * wm * 32 + 4 * h) * (long)p.cout) + nb * 256 + c;
+  const long cs = p.cout;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float *base = Mp + (rr * 32L) * cs + (2 * wn + j) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) base[(long)((r & 3) + 8 * (r >> 2)) * cs] = acc[rr][j][r];
+    }
+}
+
 }  // namespace gqhip

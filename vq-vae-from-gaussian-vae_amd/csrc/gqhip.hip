@@ -861,9 +861,17 @@ int wino_gemm_f16x2(const void *V2, const void *Wf, float *M, int64_t P, int64_t
   wp.V2 = static_cast<const _Float16 *>(V2); wp.Wf = static_cast<const _Float16 *>(Wf); wp.M = M; wp.tiles = tiles;
   wp.cin = (int)Cin; wp.cout = (int)Cout; wp.nnb = (int)(Cout / 128);
   wp.mtiles = tiles / 256; wp.ntile_total = P * wp.mtiles; wp.tiles_per_xcd = (wp.ntile_total + 7) / 8;
+  // 256 x 256 tiles (8 waves, one block per CU) where the shape allows: Cin % 64 == 0, Cout % 256 == 0; GQHIP_WGEMM=128 keeps
+  // the 256 x 128 form (A/B)
+  static const int env_w = getenv("GQHIP_WGEMM") ? atoi(getenv("GQHIP_WGEMM")) : 0;
+  const bool wide = Cin % 64 == 0 && Cout % 256 == 0 && env_w != 128;
+  if (wide) wp.nnb = (int)(Cout / 256);
   const long blocks = 8 * wp.tiles_per_xcd * wp.nnb;
   if (blocks > 0x7fffffffL) return GQHIP_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(wino_gemm_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), wp);
+  if (wide)
+    hipLaunchKernelGGL(wino_gemm_f16x2_w8_kernel, dim3((unsigned)blocks), dim3(512), 0, static_cast<hipStream_t>(stream), wp);
+  else
+    hipLaunchKernelGGL(wino_gemm_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), wp);
   return check_launch();
 }
 
