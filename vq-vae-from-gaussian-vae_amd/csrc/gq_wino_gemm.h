@@ -278,46 +278,70 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_f16x2_w8_kernel(const WinoGe
   const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + pos * (cin / 16) * wstep +
                                (8 * nb + 2 * wn) * 2048L;
   const int wl = lane * 16;
-  f16x8 b0[4], b1[4];
+  // Weights: three register sets, loads TWO k-steps ahead.  vmcnt retires in order, so the consumer of a weight load also waits
+  // for every older load -- the 8 row loads of the next stage included: with one k-step of lead those had ~0.75 us to come back
+  // from HBM (ablation: without the row loads 266 instead of 323 us, without the weight loads 267, without both 220).
+  // A operands: the (h, l) pair of the next 32-row group is read from LDS before the six MFMAs of the current one (fenced:
+  // hipcc otherwise sinks the reads to their use).
+  const int nks = 4 * nst;
+  f16x8 bA[4], bB[4], bC[4];
   auto load_b = [&](int ks, f16x8 (&dst)[4]) {
-    const unsigned char *s = wbase + ks * wstep;
+    const unsigned char *s = wbase + (long)(ks < nks ? ks : nks - 1) * wstep;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
   };
-  auto kstep = [&](const unsigned char *A, const f16x8 (&bq)[4]) {
+  f16x8 ah, al, nh, nl;
+  auto read_a = [&](const unsigned char *A, int u, f16x8 &oh, f16x8 &ol) {     // unit u = (k-step u >> 2, row group u & 3)
+    const unsigned char *q = A + (u >> 2) * kChunk + aoff + (u & 3) * 1024;
+    oh = *reinterpret_cast<const f16x8 *>(q);
+    ol = *reinterpret_cast<const f16x8 *>(q + kPlane);
+  };
+  auto mfma6 = [&](int rr, const f16x8 (&bq)[4]) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + aoff + rr * 1024);
-      const f16x8 al = *reinterpret_cast<const f16x8 *>(A + aoff + rr * 1024 + kPlane);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
-        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j + 1], acc[rr][j], 0, 0, 0);
-        acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[2 * j], acc[rr][j], 0, 0, 0);
-      }
+    for (int j = 0; j < 2; ++j) {
+      acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
+      acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j + 1], acc[rr][j], 0, 0, 0);
+      acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[2 * j], acc[rr][j], 0, 0, 0);
     }
   };
-  const int nks = 4 * nst;
-  load_b(0, b0);
+  // one k-step: four row groups, the next unit's operands read ahead
+  auto kstep = [&](const unsigned char *A, int ks4, const f16x8 (&bq)[4], bool last_of_stage) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int u = 4 * ks4 + rr;
+      if (!(last_of_stage && rr == 3)) read_a(A, u + 1, nh, nl);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma6(rr, bq);
+      ah = nh;
+      al = nl;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  load_b(0, bA);
+  load_b(1, bB);
   issue(0);
   commit(0);
   __syncthreads();
   for (int s = 0; s < nst; ++s) {
     const bool more = s + 1 < nst;
     const unsigned char *A = sA + (s & 1) * kStage;
-    load_b(4 * s + 1, b1);
+    read_a(A, 0, ah, al);
+    load_b(4 * s + 2, bC);
     if (more) issue(s + 1);
-    kstep(A, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(4 * s + 2, b0);
-    kstep(A + kChunk, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(4 * s + 3, b1);
-    kstep(A + 2 * kChunk, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(4 * s + 4 < nks ? 4 * s + 4 : nks - 1, b0);
-    kstep(A + 3 * kChunk, b1);
+    kstep(A, 0, bA, false);
+    load_b(4 * s + 3, bA);
+    kstep(A, 1, bB, false);
+    load_b(4 * s + 4, bB);
+    kstep(A, 2, bC, false);
+    load_b(4 * s + 5, bC);
+    kstep(A, 3, bA, true);
     if (more) commit((s + 1) & 1);
+    // rotate: the next stage starts with k-step 4 s + 4 in bB and 4 s + 5 in bC
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bA[k] = bB[k];
+      bB[k] = bC[k];
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }

@@ -553,18 +553,22 @@ def attention_f16x3(qkv, q_bound: float, v_bound: float):
 
 
 def own_gemm_fits(positions: int, tiles: int, cout: int, cin: int = 256) -> bool:
-    """Where wino_gemm_f16x2 (256 x 128 blocks, two per CU) beats the library's K-concatenated GEMM: the 256-channel level,
-    whose GEMM is HBM-bound on V + M (1.05-1.10x alone, and the input transform writes 9 instead of 13.5 bytes per
-    element); at 512 channels the library's 256 x 256 tiles win (0.83-1.02x, tools/wino_gemm2_bench.py).  The grid must fill
-    whole rounds of the chip reasonably (36 x 1024 tiles x 512 channels = 576 blocks = 1.125 rounds would not)."""
+    """Where wino_gemm_f16x2 replaces the library's K-concatenated GEMM: wherever its grid (256 x 256 tiles at Cout % 256 == 0,
+    else 256 x 128) fills whole rounds of the chip reasonably (36 x 1024 tiles x 512 channels = 288 blocks = 1.125 rounds does
+    not).  Alone the kernel is 1.05-1.21x the library at 256 input channels and at 16 x 4096 tiles, 0.91-0.95x at the two largest
+    512-channel shapes (tools/wino_gemm2_bench.py) -- but its [h | l] operand also takes a third off what the input transform
+    writes, so the step as a whole is faster with it everywhere (33.9 -> 33.4 ms; OWN_GEMM_MAX_CH = 256 restores the old
+    policy)."""
     if OWN_GEMM_MAX_CH and (cin > OWN_GEMM_MAX_CH or cout > OWN_GEMM_MAX_CH):
         return False
-    blocks = positions * (tiles // 256) * (cout // 128)
-    rounds = blocks / 512.0
+    if cout % 256 == 0 and cin % 64 == 0:
+        rounds = positions * (tiles // 256) * (cout // 256) / 256.0      # 8-wave blocks, one per CU
+    else:
+        rounds = positions * (tiles // 256) * (cout // 128) / 512.0      # 4-wave blocks, two per CU
     return rounds >= 1.0 and rounds / math.ceil(rounds) >= 0.85
 
 
-OWN_GEMM_MAX_CH = 256   # 0: no channel limit (A/B switch)
+OWN_GEMM_MAX_CH = 0     # 0: no channel limit; 256: only the 256-channel level (A/B switch)
 
 
 def wino_weights_operand_order(h, l):

@@ -355,7 +355,8 @@ WINOGRAD_F16X3 = True
 # [h | l] operand (4 instead of 6 bytes per element of V): same splits and products as the library route
 WINOGRAD_C128_GEMM = True
 # ... and the 256- / 512-channel Winograd GEMMs through libgqhip's wino_gemm_f16x2 on the same [h | l] operand (weights in MFMA
-# operand order, three products in the kernel) where its grid fills the chip (_lib.own_gemm_fits); else the library GEMM
+# operand order, three products in the kernel) where its grid fills the chip (_lib.own_gemm_fits: everything but the
+# 32 x 32 levels' 36 x 1024-tile GEMMs); else the library GEMM over [h | h | l]
 WINOGRAD_OWN_GEMM = True
 # 3x3 convolutions into 128 channels (256 x 256 level) -- and, where the alternative is F(2x2,3x3) (the encoder), into 256
 # channels (128 x 128 level) -- as a direct fp16 x 3 implicit GEMM instead of Winograd: reads the activation once and
