@@ -5,6 +5,7 @@ and loud failure when tensors are not on a HIP device."""
 import ctypes
 import hashlib
 import json
+import math
 import os
 import re
 
@@ -316,3 +317,35 @@ def test_step_record_validates_shape_and_range():
         lay.pack(torch.tensor([[1, 2, 65536], [0, 7, 9]]), torch.zeros(2, 1))
     with pytest.raises(ValueError, match="layout"):
         lay.pack(torch.zeros(2, 4, dtype=torch.int64), torch.zeros(2, 1))
+
+
+def test_operand_order_weight_layouts_and_gemm_policy():
+    """Host-side repacking for libgqhip's fp16 x 3 kernels (no GPU): wino_weights_operand_order / upconv_weights_f16 put element
+    (k, n) where the kernels' MFMA B operands read it (lane (c, hh) of column tile nt holds k = 16 chunk + 8 hh .. + 7 of
+    column 32 nt + c), and own_gemm_fits keeps the GEMMs whose grid would leave the chip mostly idle on the library."""
+    import random
+
+    from pit_hip import _lib
+
+    rnd = random.Random(3)
+    h, l = torch.randn(3, 64, 256).half(), torch.randn(3, 64, 256).half()
+    wf = _lib.wino_weights_operand_order(h, l)
+    assert tuple(wf.shape) == (3, 4, 8, 2, 64, 8) and wf.dtype == torch.float16 and wf.is_contiguous()
+    for _ in range(500):
+        t, kc, nt, pl, hh, c, e = (rnd.randrange(n) for n in (3, 4, 8, 2, 2, 32, 8))
+        assert wf[t, kc, nt, pl, hh * 32 + c, e] == (h, l)[pl][t, kc * 16 + 8 * hh + e, nt * 32 + c]
+    cin, cout = 32, 128
+    m = torch.randn(2, 2, cin, 2, 2, cout)                    # [u, v, ci, a, b, co] as Upsample._phase_weights builds it
+    uf, us = _lib.upconv_weights_f16(m.reshape(4 * cin, 4 * cout), cin, cout)
+    assert tuple(uf.shape) == (4, 4 * (cin // 16), cout // 32, 2, 64, 8) and us > 0 and math.log2(us) == int(math.log2(us))
+    hi = (m * us).half()
+    lo = (m * us - hi.float()).half()
+    for _ in range(500):
+        ph, ch, tap, nt, pl, hh, c, e = (rnd.randrange(n) for n in (4, cin // 16, 4, cout // 32, 2, 2, 32, 8))
+        assert uf[ph, ch * 4 + tap, nt, pl, hh * 32 + c, e] == (hi, lo)[pl][tap >> 1, tap & 1, ch * 16 + 8 * hh + e, ph >> 1, ph & 1, nt * 32 + c]
+    with pytest.raises(_lib.GqHipError):
+        _lib.upconv_weights_f16(m.reshape(4 * cin, 4 * cout), cin, 96)
+    # the step's Winograd GEMM shapes (positions, tiles, Cout, Cin): only the 32 x 32 levels' 36 x 1024-tile GEMMs stay on the library
+    assert _lib.own_gemm_fits(36, 16384, 256, 256) and _lib.own_gemm_fits(36, 4096, 512, 512) and _lib.own_gemm_fits(16, 4096, 512, 512)
+    assert _lib.own_gemm_fits(16, 16384, 512, 256) and not _lib.own_gemm_fits(36, 1024, 512, 512) and not _lib.own_gemm_fits(16, 256, 512, 512)
+    assert set(_lib.FILTER_KINDS) == {"auto", "fp32", "bf16"}
