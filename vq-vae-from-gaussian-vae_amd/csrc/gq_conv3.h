@@ -731,13 +731,16 @@ __global__ __launch_bounds__(256, 2) void upconv2x_f16x3_kernel(const Upconv2Par
   const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.Wf) + (long)blockIdx.y * nks * wstep +
                                (4 * t.nb + 2 * wn) * 128 * 16;
   const int wl = lane * 16;
-  f16x8 bq[4], bn[4];
+  // weights two taps ahead (three register sets): vmcnt retires in order, so the consumer of a weight load also waits for the
+  // x loads of the next chunk issued before it -- with one tap of lead those had one tap (~0.75 us) to come back
+  f16x8 b0[4], b1[4], b2[4];
   auto load_b = [&](int ks, f16x8 (&dst)[4]) {
-    const unsigned char *s = wbase + ks * wstep;
+    const unsigned char *s = wbase + (long)(ks < nks ? ks : nks - 1) * wstep;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const f16x8 *>(s + k * 1024 + wl);
   };
-  load_b(0, bq);
+  load_b(0, b0);
+  load_b(1, b1);
   issue(0);
   commit(0);
   __syncthreads();
@@ -748,10 +751,13 @@ __global__ __launch_bounds__(256, 2) void upconv2x_f16x3_kernel(const Upconv2Par
     const unsigned char *A = sA + (chunk & 1) * kC3Buf;
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {           // tap (u, v) = (ti >> 1, ti & 1)
-      load_b(ks + 1 < nks ? ks + 1 : ks, bn);
-      conv3_tap(A + aoff[ti & 1], ti >> 1, bq, acc);
+      load_b(ks + 2, b2);
+      conv3_tap(A + aoff[ti & 1], ti >> 1, b0, acc);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) bq[k] = bn[k];
+      for (int k = 0; k < 4; ++k) {
+        b0[k] = b1[k];
+        b1[k] = b2[k];
+      }
       ++ks;
       __builtin_amdgcn_sched_barrier(0);
     }
