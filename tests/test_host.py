@@ -349,3 +349,56 @@ def test_operand_order_weight_layouts_and_gemm_policy():
     assert _lib.own_gemm_fits(36, 16384, 256, 256) and _lib.own_gemm_fits(36, 4096, 512, 512) and _lib.own_gemm_fits(16, 4096, 512, 512)
     assert _lib.own_gemm_fits(16, 16384, 512, 256) and not _lib.own_gemm_fits(36, 1024, 512, 512) and not _lib.own_gemm_fits(16, 256, 512, 512)
     assert set(_lib.FILTER_KINDS) == {"auto", "fp32", "bf16"}
+
+
+def test_fp16_fp8_filter_representation_error_is_inside_the_charged_bound():
+    """The fp16 + fp8 filter's operand arithmetic restated in numpy (per-row power-of-two normalisation,
+    fp16 h parts, e4m3 corrections (s_l 2^11) x (a_h 2^-6) and s_h x (a_l 2^6), exact accumulation) on operands built to
+    maximise the rounding errors -- every value just above a power of two plus the largest fp16 residual, residuals with the
+    largest e4m3 error, aligned signs, coefficients spread over 30 binades, codebooks at both ends of the allowed range: the
+    error of the filter value stays well inside the representation share (2450 - 256 accumulation steps) of the coefficient
+    the re-rank charges (csrc/gqhip.hip: kMixedEfCoeff)."""
+    rng = np.random.default_rng(1)
+    u, dim, n = 2.0 ** -24, 16, 2048
+
+    def e4m3(x):          # RNE to OCP e4m3: 3 mantissa bits, min normal 2^-6, subnormal step 2^-9, max 448
+        x = np.asarray(x, dtype=np.float64)
+        a = np.abs(x)
+        e = np.maximum(np.floor(np.log2(np.maximum(a, 1e-300))), -6)
+        step = 2.0 ** (e - 3)
+        return np.sign(x) * np.minimum(np.round(a / step) * step, 448.0)
+
+    def f16(x):
+        return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float64)
+
+    def worst_error(A, B, cb):
+        coef = np.concatenate([A, B], 1).astype(np.float32).astype(np.float64)
+        c32 = cb.astype(np.float32)
+        feat = np.concatenate([(c32 * c32).astype(np.float64), c32.astype(np.float64)], 1)
+        sc = 2.0 ** (14 - (np.floor(np.log2(np.abs(coef).max(1))) + 1))      # largest coefficient into [2^13, 2^14)
+        ch = coef * sc[:, None]
+        chh, sh = f16(ch), f16(feat)
+        chl, sl = ch - chh, feat - sh
+        ft = (chh @ sh.T + (e4m3(chh / 64) @ e4m3(sl * 2048).T) * (64 / 2048) + (e4m3(chl * 64) @ e4m3(feat).T) / 64) / sc[:, None]
+        N1 = np.abs(cb).max()
+        assert 1.0 <= N1 <= 16.0
+        T = (np.abs(coef[:, :dim]) * N1 * N1 + np.abs(coef[:, dim:]) * N1).sum(1)
+        return float((np.abs(ft - coef @ feat.T).max(1) / (u * T)).max())
+
+    def worst(shape, lo, hi):
+        k = rng.integers(lo, hi, shape)
+        return 2.0 ** k * (1 + 2.0 ** -11 * (1 + 2.0 ** -4 * rng.choice([1.0, 0.9375, 0.5], shape))) * rng.choice([-1, 1], shape)
+
+    cbw = np.abs(np.clip(worst((n, dim), -1, 2), -16, 16))
+    Aw, Bw = -np.abs(worst((256, dim), -2, 6)), np.abs(worst((256, dim), -2, 6))
+    cases = {
+        "aligned signs": (Aw, Bw, cbw),
+        "mixed signs": (Aw, worst((256, dim), -2, 6), cbw * rng.choice([-1, 1], cbw.shape)),
+        "30 binades in a row": (-np.abs(worst((256, dim), -20, 10)), np.abs(worst((256, dim), -20, 10)), cbw),
+        "codebook up to 16": (Aw, Bw, np.clip(cbw * 4, 1, 16)),
+        "codebook max 1": (Aw, Bw, cbw / cbw.max()),
+    }
+    for name, (A, B, cb) in cases.items():
+        err = worst_error(A, B, cb)
+        print(f"fp16 + fp8 representation error, {name}: {err:.0f} u T")
+        assert err < 2450 - 256, (name, err)
