@@ -942,3 +942,35 @@ def test_upconv2x_direct_matches_fp64_and_the_library_route():
     wf, us = _lib.upconv_weights_f16(torch.randn(4 * 128, 4 * 128, device=DEV), 128, 128)
     with pytest.raises(_lib.GqHipError):
         _lib.upconv2x_direct(torch.randn(1, 128, 12, 32, device=DEV).contiguous(memory_format=torch.channels_last), wf, us, 10.0)
+
+
+def test_bench_line_contract_small_run():
+    """`python bench.py` as the driver runs it (fresh process, N = 1) prints ONE JSON line with the contract's fields: metric /
+    value / unit / n_gpus / steps / warmup / ms_per_step / scaling / dtype / config.workload, the `roofline` object of the
+    dominant kernel (bound, achieved, peak, frac, traffic), `cpu_baseline` (two legs that agree bit for bit) and the in-run
+    `parity` figures (indices 100 % equal on the CPU encoder's z; end to end within the stated tolerance)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"], capture_output=True,
+                         text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "stages_ms"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["unit"] == "images/s" and line["value"] > 50 and abs(line["value"] * line["ms_per_step"] / 1e3 - 16) < 0.01
+    assert "workload" in line["config"] and "model" not in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and 0.05 < rf["frac"] < 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["traffic"] and rf["launches"] == 2
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["legs_agree_bit_for_bit"] is True
+    assert {leg["kind"] for leg in cb["legs"]} == {"torch-restatement", "c-oracle"}
+    par = line["parity"]
+    assert par["quantiser_same_z"]["indices_equal_frac"] == 1.0 and par["quantiser_same_z"]["zhat_bit_equal"] is True
+    assert par["indices_differing"] <= 2 and par["z_enc_max_abs_err"] <= 5e-5 and par["recon_psnr_db"] >= 60.0
