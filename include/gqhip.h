@@ -38,8 +38,18 @@
 extern "C" {
 #endif
 
-#define GQHIP_ABI_VERSION 4   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
-                               * 4: four-launch fused arg-max (no caller-cached max|cb|; noise / zhat_noquant in gq_quantize_z_f32), profile_reserve */
+#define GQHIP_ABI_VERSION 5   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
+                               * 4: four-launch fused arg-max (no caller-cached max|cb|; noise / zhat_noquant in gq_quantize_z_f32), profile_reserve;
+                               * 5: GroupNorm statistics as order-independent fixed-point records (gqhip_gnstat_t), conv3x3_f32 (fp32 matrix
+                               *    cores: conv_in / conv_out of the encoder and decoder), gqhip_debug_barrier / gqhip_debug_tail */
+
+/* GroupNorm statistics of one (image, group): GQHIP_GNSTAT_WORDS int64 words = {sum: 3 limbs, sum of squares: 3 limbs, poison,
+ * unused}; value = q0 2^-56 + q1 2^-16 + q2 2^24.  Every kernel that leaves statistics behind adds its threads' fp32 partial
+ * sums to these records with INTEGER atomics (exact, associative), so the statistics -- and everything normalised with them --
+ * are bit-identical from run to run whatever order the adds land in (csrc/gq_stats.h).  A `stats` argument below is an
+ * array of B * groups such records (64 bytes each), zeroed by the producing call. */
+typedef int64_t gqhip_gnstat_t;
+#define GQHIP_GNSTAT_WORDS 8
 
 typedef enum gqhip_status {
   GQHIP_OK = 0,
@@ -157,30 +167,44 @@ int fsq_dequant_f32(const int32_t *idx, const int32_t *levels_host, int64_t nlev
  * y = act( (x - mean_g) * rstd_g * gamma_c + beta_c ), act = SiLU when apply_silu != 0.
  * Replaces the GroupNorm -> swish pairs of pit/modules/unet.py:54-57,49-51,137-153,432-435
  * (three PyTorch kernels, five HBM passes) by a stats pass + one apply pass (three passes).
- * x, y [B, C, HW] fp32 contiguous (NCHW), groups | C; stats_ws: 2*B*groups doubles of
- * caller scratch.  x and y may alias.  pre_bias_or_null [C]: a per-channel bias still pending
+ * x, y [B, C, HW] fp32 contiguous (NCHW), groups | C; stats_ws: B*groups statistics records
+ * (GQHIP_GNSTAT_WORDS int64 each) of caller scratch.  x and y may alias.  pre_bias_or_null [C]: a per-channel bias still pending
  * on x (the producing conv was run without its bias) -- normalises x + pre_bias[c] without a
  * separate bias pass. */
 #define GQHIP_LAYOUT_NCHW 0   /* x[b][c][hw] */
 #define GQHIP_LAYOUT_NHWC 1   /* x[b][hw][c] (torch channels_last): needs (C/groups) % 4 == 0, (C/4) | 256 */
 int gn_silu_f32(const float *x, const float *gamma, const float *beta,
                 const float *pre_bias_or_null, float *y, int64_t B, int64_t C, int64_t HW,
-                int64_t groups, double eps, int apply_silu, int layout, double *stats_ws,
+                int64_t groups, double eps, int apply_silu, int layout, gqhip_gnstat_t *stats_ws,
                 void *stream);
 /* y = a + b (+ bias[c]): residual add with the pending conv biases folded in (unet.py:153). */
 int add_bias_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B,
                  int64_t C, int64_t HW, int layout, void *stream);
 
-/* NHWC only.  y = a + b (+ bias[c]) AND the GroupNorm statistics of y: stats_out[2*(b*groups+g)] = sum, [+1] = sum of
- * squares over the group (fp64; zeroed here).  The residual add of a ResnetBlock / AttnBlock (unet.py:160, :205) is
+/* NHWC only.  y = a + b (+ bias[c]) AND the GroupNorm statistics of y: record b*groups+g of stats_out = sum and sum of
+ * squares over the group (gqhip_gnstat_t records; zeroed here).  The residual add of a ResnetBlock / AttnBlock (unet.py:160, :205) is
  * always followed by a GroupNorm over the same tensor (unet.py:140, :190, :581): gn_apply_f32 then normalises from
  * these statistics without its own statistics pass.  Needs (C/groups) % 4 == 0, 256 % (C/4) == 0, groups <= 64. */
 int add_bias_stats_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B,
-                       int64_t C, int64_t HW, int64_t groups, double *stats_out, void *stream);
+                       int64_t C, int64_t HW, int64_t groups, gqhip_gnstat_t *stats_out, void *stream);
 
 /* NHWC only.  The apply pass of gn_silu_f32 with statistics computed earlier (by add_bias_stats_f32). */
 int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B, int64_t C,
-                 int64_t HW, int64_t groups, double eps, int apply_silu, const double *stats, void *stream);
+                 int64_t HW, int64_t groups, double eps, int apply_silu, const gqhip_gnstat_t *stats, void *stream);
+
+/* 3x3 convolution, stride 1, zero padding 1, NHWC fp32, on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: an exact fp32 FMA
+ * chain) with a FIXED summation order, so the result is bit-identical from run to run -- for the narrow ends of the conv
+ * stack, where the library's pick is a split-K kernel with floating-point atomics: the encoder's conv_out
+ * (pit/modules/unet.py:425-436: norm_out -> swish -> conv 512 -> 2 z_channels, the layer that produces z) and the decoder's
+ * conv_in (unet.py:487-489: z_channels -> 512).  stats != NULL: the input is act(GroupNorm(x + pre_bias)) applied while the
+ * patch is staged (gamma, beta [Cin]; stats = B * groups_in records; Cin <= 1024); act = SiLU when apply_silu != 0.
+ * wk: the weights in operand order [ceil(Cout/32)][9 taps][Cin/8][64 lanes][4]: element (t, tap, g, 32 h + j, m) =
+ * w[32 t + j][8 g + 4 h + m][tap / 3][tap % 3], zero for output channels >= Cout.  Any H, W (a block owns 32 pixels of a row); Cout % 4 == 0;
+ * Cin % 64 == 0 (K split over the four waves of a block, partial sums added in wave order) or, without GroupNorm,
+ * Cin in {8, 16, 32} (output channels split over the waves). */
+int conv3x3_f32(const float *x, const float *gamma_or_null, const float *beta_or_null, const float *pre_bias_or_null,
+                const gqhip_gnstat_t *stats_or_null, int64_t groups_in, double eps, int apply_silu, const float *wk,
+                const float *bias_or_null, float *y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, void *stream);
 
 /* Nearest-neighbour x2 upsample of an NHWC fp32 tensor: x [B, H, W, C] -> y [B, 2H, 2W, C], C % 4 == 0
  * (pit/modules/unet.py:69-73, `F.interpolate(scale_factor=2.0, mode="nearest")` in channels_last). */
@@ -226,7 +250,7 @@ int wino_gemm_f16x2(const void *V2, const void *Wf, float *M, int64_t P, int64_t
  *   conv3x3_gn_f16x3     y [B, H, W, Cout] = (SiLU(GroupNorm(x + pre_bias)) (*) w) + bias (+ res) in ONE kernel: x [B, H, W, Cin]
  *                        fp32 is normalised, activated, scaled and split on its way into LDS.  stats_in [B, groups_in, 2] as
  *                        gn_stats_f32 / the statistics outputs of this library; stats_out (optional): GroupNorm statistics of
- *                        y, [B, groups_out, 2] fp64 (4 | Cout / groups_out | 128).  H % 8 == 0, W % 32 == 0, Cin % 32 == 0,
+ *                        y, [B, groups_out] statistics records (4 | Cout / groups_out | 128).  H % 8 == 0, W % 32 == 0, Cin % 32 == 0,
  *                        Cin <= 512.  `scale`: a power of two with |activation| * scale <= 32768; mscale = 1 / (scale * u_scale).
  *                        Wf [Cin/16, 9, Cout/32, 2, 64, 8] fp16: operand-order weights -- chunk, tap ky*3+kx, column tile,
  *                        plane (h, l of w * u_scale), lane (n = 32 tile + lane%32, k-half lane/32), 8 input channels
@@ -235,14 +259,14 @@ int wino_gemm_f16x2(const void *V2, const void *Wf, float *M, int64_t P, int64_t
  *                        x * scale) or Cin % 32 != 0: Xs [B, Cin/16, H, W, 2, 16] fp16 = (h, l) of the activated, scaled
  *                        tensor; H*W % 16 == 0, Cin % 16 == 0. */
 int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                     const double *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
-                     const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B,
+                     const gqhip_gnstat_t *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
+                     const float *bias_or_null, const float *res_or_null, float *y, gqhip_gnstat_t *stats_out_or_null, int64_t B,
                      int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, float mscale, void *stream);
 int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *beta_or_null, const float *pre_bias_or_null,
-                       const double *stats_or_null, void *Xs, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                       const gqhip_gnstat_t *stats_or_null, void *Xs, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                        double eps, int apply_silu, float scale, void *stream);
 int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
-                  double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
+                  gqhip_gnstat_t *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
                   float mscale, void *stream);
 /* 1x1 convolution Cin -> Cout (128, 256, 512 or 1536 = the attention block's q | k | v) of a channels_last tensor = a GEMM over its B * HW pixels, fp16 x 3 as above
  * with the split of x done inside the kernel: the ResnetBlocks' nin_shortcut (reference pit/modules/unet.py:151-152) and the
@@ -252,7 +276,7 @@ int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, con
  * `scale` / `mscale` arguments.  Wf [Cin/16, 1, Cout/32, 2, 64, 8] as for conv3x3_f16x3; y = x W * mscale + bias (+ res);
  * stats_out optional.  HW % 256 == 0, Cin % 32 == 0. */
 int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf, const float *scales_dev_or_null, float scale,
-                  float mscale, const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t HW,
+                  float mscale, const float *bias_or_null, const float *res_or_null, float *y, gqhip_gnstat_t *stats_out_or_null, int64_t B, int64_t HW,
                   int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
 /* 3x3 convolution with stride 2 over x padded by one zero row / column at the bottom / right -- the reference's Downsample
  * (pit/modules/unet.py:76-97: F.pad(x, (0,1,0,1)) + conv stride 2) -- Cin -> Cout (128, 256 or 512), fp16 x 3 on the four
@@ -261,7 +285,7 @@ int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf,
  * Cin % 16 == 0.  Wf [9 Cin/16, Cout/32, 2, 64, 8]: operand-order weights, k-steps in the order (phase (a, b) = (0,0), (0,1),
  * (1,0), (1,1); chunk; tap (dy, dx) of the phase, ky = 2 dy + a, kx = 2 dx + b). */
 int conv3x3s2_f16x3(const float *x, const void *Wf, const float *scales_dev_or_null, float scale, float mscale,
-                    const float *bias_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t Hin, int64_t Win,
+                    const float *bias_or_null, float *y, gqhip_gnstat_t *stats_out_or_null, int64_t B, int64_t Hin, int64_t Win,
                     int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
 /* The reference's Upsample (pit/modules/unet.py:60-73: nearest x2, then conv 3x3) Cin -> Cout (128, 256 or 512) as its sub-pixel
  * form computed directly: output phase (a, b) = a 2x2 convolution of the low-resolution input with the phase weights (sums of
@@ -270,23 +294,23 @@ int conv3x3s2_f16x3(const float *x, const void *Wf, const float *scales_dev_or_n
  * optional (GroupNorm statistics of y).  H % 8 == 0, W % 32 == 0, Cin % 16 == 0.  Wf [4, 4 Cin/16, Cout/32, 2, 64, 8]:
  * operand-order phase weights, [phase 2a + b][chunk][tap 2u + v], tap (u, v) reading x[i - 1 + a + u][j - 1 + b + v]. */
 int upconv2x_f16x3(const float *x, const void *Wf, const float *scales_dev_or_null, float scale, float mscale,
-                   const float *bias_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t H, int64_t W,
+                   const float *bias_or_null, float *y, gqhip_gnstat_t *stats_out_or_null, int64_t B, int64_t H, int64_t W,
                    int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
 /* 3x3 convolution (stride 1, zero padding 1) into 1..4 channels with GroupNorm (+ SiLU) of the input fused in, fp32 FMAs:
  * the decoder's conv_out(swish(norm_out(h))) (reference pit/modules/unet.py:585-587).  x [B, H, W, Cin] fp32, w_ohwi
  * [Cout, 3, 3, Cin] fp32, y [B, H, W, Cout].  H % 16 == 0, W % 16 == 0, Cin % 32 == 0, Cin <= 512. */
 int conv3x3_gn_small_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                         const double *stats_in, int64_t groups_in, double eps, int apply_silu, const float *w_ohwi,
+                         const gqhip_gnstat_t *stats_in, int64_t groups_in, double eps, int apply_silu, const float *w_ohwi,
                          const float *bias_or_null, float *y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                          void *stream);
 /* ... with the producer fused in (as wino_in_gn_nhwc_f32 / wino4_in_gn_nhwc_f32): the convolution's input is
  * SiLU(GroupNorm(x + pre_bias)), never written. */
 int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                          const double *stats, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                          const gqhip_gnstat_t *stats, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                           double eps, int apply_silu, int tile, float scale, void *stream);
 /* ... writing the [h | l] operand of wino_gemm_c128_f16x2. */
 int wino_in_gn_nhwc_f16x2(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                          const double *stats, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
+                          const gqhip_gnstat_t *stats, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                           double eps, int apply_silu, int tile, float scale, void *stream);
 
 /* Winograd F(4x4, 3x3): V [36, tiles, C] of the 6x6 input tiles (tiles = B * H/4 * W/4, H and W multiples of 4) and
@@ -298,24 +322,24 @@ int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W
 /* Output transform (tile = 2: F(2x2,3x3), M [16, tiles, C]; tile = 4: F(4x4,3x3), M [36, tiles, C]) with the ResnetBlock's
  * tail fused in (pit/modules/unet.py:149-153): y = A^T M A + bias[c] (+ res, may be NULL), plus the GroupNorm statistics of y
  * (stats_out as add_bias_stats_f32) for the block that follows.  Needs (C/groups) % 4 == 0, 256 % (C/4) == 0. */
-int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or_null, float *y, double *stats_out,
+int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or_null, float *y, gqhip_gnstat_t *stats_out,
                           int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups, int tile, float mscale,
                           void *stream);
 
 /* NHWC only.  GroupNorm statistics alone (the first pass of gn_silu_f32): stats_out[2*(b*groups+g)] = sum, [+1] = sum of
- * squares of x (+ pre_bias[c]) over the group, fp64, zeroed here. */
+ * squares of x (+ pre_bias[c]) over the group (gqhip_gnstat_t records), zeroed here. */
 int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64_t C, int64_t HW, int64_t groups,
-                 double *stats_out, void *stream);
+                 gqhip_gnstat_t *stats_out, void *stream);
 
 /* wino_in_nhwc_f32 with the producer fused in: the convolution's input is SiLU(GroupNorm(x + pre_bias)) (the
  * `Normalize` -> `nonlinearity` -> conv chains of pit/modules/unet.py:140-142, :146-149); the normalised tensor is
  * never written.  `stats` as produced by gn_stats_f32 / add_bias_stats_f32. */
 int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                        const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C,
+                        const gqhip_gnstat_t *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C,
                         int64_t groups, double eps, int apply_silu, void *stream);
 /* the same for F(4x4,3x3) (V [36, tiles, C], H and W multiples of 4) */
 int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                         const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C,
+                         const gqhip_gnstat_t *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C,
                          int64_t groups, double eps, int apply_silu, void *stream);
 
 /* Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (pit/modules/unet.py:69-73): src [B, H+1, W+1, 4*C] is the
@@ -348,7 +372,7 @@ int upconv_im2col_nhwc_f16x3(const float *x, void *A3, int64_t B, int64_t H, int
 int attn_split_qkv_f16x3(const float *qkv, void *Q3, void *K3, void *V3, int64_t B, int64_t L, int64_t C, float sq, float sv,
                          void *stream);
 int attn_softmax_split_f16x3(const float *S, void *P3, int64_t rows, int64_t L, float factor, void *stream);
-int f16_scales_from_gn_stats(const double *stats, int64_t n_bg, double amp, double u_scale, float *scales_out,
+int f16_scales_from_gn_stats(const gqhip_gnstat_t *stats, int64_t n_bg, double amp, double u_scale, float *scales_out,
                              void *stream);
 
 /* ---- index wire format / usage histogram ----------------------------------- */
@@ -378,6 +402,14 @@ int gqhip_profile_collect(int *launches_host, double *total_ms_host);
 int gqhip_debug_enable(int on);
 int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
                          int64_t *reranked_halftiles_host);
+/* The tail kernel's grid barriers (cascade path of an ill-conditioned call) are allowed to fail: a block whose
+ * wait runs out, or that learns of another block's, finishes the undecided rows through the barrier-free exhaustive
+ * path, so a failed barrier costs time and never an index (the reference's plain launch, gq_cuda.cu:114-116, cannot
+ * mis-answer either).  gqhip_debug_barrier: blocks that timed out / whether the call aborted its barriers, for the
+ * last call on `workspace` (synchronous copy).  gqhip_debug_tail: TEST HOOK -- multiply the tail grid beyond what is
+ * co-resident (1 = normal) and set the barrier wait in polls of ~0.25 us (default 2^21), to force that path. */
+int gqhip_debug_barrier(const void *workspace, int64_t *timeouts_host, int64_t *aborted_host);
+int gqhip_debug_tail(int grid_mult, int spin_limit);
 
 #ifdef __cplusplus
 }

@@ -212,8 +212,8 @@ def test_engine_end_to_end_full_config():
         assert float((rec.cpu() - ref).abs().max()) <= 5e-3    # the golden is stored in fp16 (ulp 4.9e-4 at |x| ~ 1)
     mse = float(((rec.cpu() - ref) ** 2).mean())
     assert 10 * np.log10(4.0 / max(mse, 1e-20)) >= 60.0
-    # two separate forward passes: the conv libraries' split-K kernels are not bitwise reproducible, so the second pass
-    # may differ at rounding level (and an index only at a near-tie)
+    # two separate forward passes of the NCHW module (ATen / MIOpen convolutions, whose picks we do not control): the
+    # second pass may differ at rounding level and an index only at a near-tie
     assert float((z2 - z).abs().max()) <= 1e-4 or int((log["indices"] != ind).sum()) <= 2
     assert int((log["indices"] != ind).sum()) <= 2
     assert torch.allclose(rec, rec2, atol=1e-3)
@@ -222,6 +222,9 @@ def test_engine_end_to_end_full_config():
     with torch.no_grad():
         z_cl, ind_cl = vae_cl.quant(x.contiguous(memory_format=torch.channels_last))
         rec_cl = vae_cl.dequant(ind_cl)
+        # the product path (every kernel ours or a pinned library GEMM): a second pass gives the SAME bits
+        z_cl2, ind_cl2 = vae_cl.quant(x.contiguous(memory_format=torch.channels_last))
+        assert torch.equal(z_cl2, z_cl) and torch.equal(ind_cl2, ind_cl) and torch.equal(vae_cl.dequant(ind_cl2), rec_cl)
     diff_cl = _rows_from_bchw(ind_cl.cpu().numpy()) != _rows_from_bchw(want)
     print(f"e2e 256 channels_last: {int(diff_cl.sum())} of 1024 indices differ")
     assert diff_cl.sum() <= 2 and np.all(d["gap"][diff_cl] < 1e-3), (diff_cl.sum(), d["gap"][diff_cl])
@@ -271,7 +274,7 @@ def test_eval_loop_single_rank_on_gpu():
     assert out["indices"].shape == (8, 64) and out["psnr"].shape == (8,)
     with torch.no_grad():
         _, ind = vae.quant(images_for([0, 1, 2, 3]).to(DEV))
-    # (a second forward pass of the conv stack: equal up to the conv libraries' non-reproducibility at near-ties)
+    # (a second forward pass of the NCHW conv stack -- ATen / MIOpen kernels: equal up to their non-reproducibility at near-ties)
     assert int((out["indices"][:4].cpu() != ind.reshape(4, -1).cpu()).sum()) <= 2
 
 
@@ -686,7 +689,7 @@ def test_winograd_fused_tail_matches_unfused():
                 y, stats = _lib.wino_conv3x3(x, Uw, residual=res, bias=bias, stats_groups=32)
                 y0, stats0 = _lib.add_bias_stats(res, _lib.wino_conv3x3(x, Uw), bias, 32)
                 assert torch.allclose(y, y0, atol=1e-5, rtol=1e-5), float((y - y0).abs().max())
-                assert torch.allclose(stats, stats0, rtol=1e-6, atol=1e-4)
+                assert torch.allclose(_lib.gn_stats_values(stats), _lib.gn_stats_values(stats0), rtol=1e-6, atol=1e-4)
 
 
 def test_unet_with_and_without_fused_winograd_tail_agree():

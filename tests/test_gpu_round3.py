@@ -1,0 +1,184 @@
+"""-m gpu, round 3: what VERDICT r2 asked to harden -- the tokenizer is bit-reproducible run to run (order-independent
+GroupNorm statistics, the encoder's conv_out / decoder's conv_in on libgqhip's fixed-order fp32 matrix-core convolution
+instead of MIOpen's split-K pick), and end-to-end index parity over eight images (8 192 rows) against a golden captured
+from the reference on CPU (tests/golden/make_golden_r3.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+FULL = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=256, in_channels=3, out_ch=3, ch=128,
+            ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[32], dropout=0.0)
+
+
+def _engine(reg_target="pit.quantization.gaussian.GaussianQuantRegularizer", reg_params=None, unet=FULL, seed=1234):
+    from pit_hip.models.autoencoder import AutoencodingEngine
+
+    torch.manual_seed(seed)
+    reg_params = reg_params or {"format": "bchw", "group": 16, "n_samples": 65536, "backend": "hip"}
+    return AutoencodingEngine(encoder_config={"target": "pit.modules.unet.Encoder", "params": unet},
+                              decoder_config={"target": "pit.modules.unet.Decoder", "params": unet},
+                              regularizer_config={"target": reg_target, "params": reg_params}).eval()
+
+
+def _rows(ind):   # [B, K, h, w] -> rows (b, l, k)
+    return np.asarray(ind).transpose(0, 2, 3, 1).reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------ fixed-order fp32 convolution
+@pytest.mark.parametrize("cin,cout,H,W,gn", [(512, 32, 32, 32, True), (512, 16, 32, 32, True), (128, 32, 8, 64, False),
+                                              (16, 512, 32, 32, False), (8, 40, 5, 32, False), (32, 64, 4, 96, False),
+                                              (512, 32, 8, 8, True), (16, 512, 8, 8, False), (64, 8, 3, 45, False)])
+def test_conv3x3_f32_matches_fp64_and_is_bit_reproducible(cin, cout, H, W, gn):
+    """conv3x3_f32 (gq_conv_f32.h) against an fp64 convolution: both tilings (K split over the waves for >= 64 input channels,
+    output channels split otherwise), fused GroupNorm + SiLU, a partial last channel tile (Cout 16 / 40), non-square images.
+    Error gate: fp32 accumulation over K = 9 Cin terms, charged against sum |x||w|.  Five runs: identical bits."""
+    from pit_hip import _lib
+
+    B = 3
+    g = torch.Generator().manual_seed(100 + cin + cout)
+    x = (torch.randn(B, cin, H, W, generator=g) * 1.5 + 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.05)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+    wk = _lib.conv_f32_weights(conv.weight)
+    gn_t, xin = None, x.double()
+    if gn:
+        norm = torch.nn.GroupNorm(32, cin, eps=1e-6).to(DEV)
+        with torch.no_grad():
+            norm.weight.copy_(torch.rand(cin, generator=g) + 0.5)
+            norm.bias.copy_(torch.randn(cin, generator=g) * 0.3)
+        pre = (torch.randn(cin, generator=g) * 0.1).to(DEV)
+        gn_t = (norm.weight, norm.bias, 32, 1e-6, True, _lib.gn_stats(x, 32, pre), pre)
+        xin = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double() + pre.double()[None, :, None, None], 32,
+                                                                      norm.weight.double(), norm.bias.double(), 1e-6))
+    with torch.no_grad():
+        ref = torch.nn.functional.conv2d(xin, conv.weight.double(), conv.bias.double(), 1, 1)
+        sc = torch.nn.functional.conv2d(xin.abs(), conv.weight.double().abs(), None, 1, 1) + conv.bias.double().abs()[None, :, None, None]
+        y = _lib.conv3x3_f32(x, wk, cout, bias=conv.bias, gn=gn_t)
+        assert y.shape == (B, cout, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+        err = float(((y.double() - ref).abs() / sc).max())
+        print(f"conv3x3_f32 {cin}->{cout} {H}x{W} gn={gn}: max err {err:.2e} of sum|x||w|")
+        assert err <= (3e-6 if gn else 1e-6), err       # GN: the fp32 normalisation itself is ~1e-6 of |x|
+        for _ in range(5):
+            assert torch.equal(_lib.conv3x3_f32(x, wk, cout, bias=conv.bias, gn=gn_t), y)
+
+
+def test_groupnorm_statistics_are_order_independent_and_poison_loudly():
+    """gq_stats.h: integer-limb accumulation.  The same tensor through kernels with different thread -> element maps
+    (NHWC statistics kernel on x, the residual add's fused statistics on a + b = x): both must agree with the fp64 sums to
+    fp32-partial accuracy and, each on its own, give identical bits on every run; a non-finite input poisons the record
+    (NaN out) instead of producing a garbage integer."""
+    from pit_hip import _lib
+
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(4, 128, 64, 64, generator=g) * 3 + 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    a = (torch.randn(4, 128, 64, 64, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    b = x - a
+    xs = a + b                                   # what the fused add sees (fp32 a + b, not bitwise x)
+    st = _lib.gn_stats(xs, 32)
+    for _ in range(10):
+        assert torch.equal(_lib.gn_stats(xs, 32), st)
+    _, st2 = _lib.add_bias_stats(a, b, torch.zeros(128, device=DEV), 32)
+    for _ in range(10):
+        assert torch.equal(_lib.add_bias_stats(a, b, torch.zeros(128, device=DEV), 32)[1], st2)
+    xd = xs.double().permute(0, 2, 3, 1).reshape(4, 64 * 64, 32, 4)
+    want = torch.stack([xd.sum((1, 3)), (xd ** 2).sum((1, 3))], -1).flatten()
+    for s in (st, st2):
+        v = _lib.gn_stats_values(s)
+        assert torch.allclose(v, want, rtol=2e-6, atol=1e-3), float((v - want).abs().max())
+    # tiny activations keep their statistics (limb 0 reaches 2^-56)
+    tiny = (xs * 1e-6).contiguous(memory_format=torch.channels_last)
+    vt = _lib.gn_stats_values(_lib.gn_stats(tiny, 32))
+    td = tiny.double().permute(0, 2, 3, 1).reshape(4, 64 * 64, 32, 4)
+    wt = torch.stack([td.sum((1, 3)), (td ** 2).sum((1, 3))], -1).flatten()
+    assert torch.allclose(vt, wt, rtol=1e-5, atol=1e-14), float((vt - wt).abs().max())
+    bad = xs.clone()
+    bad[1, 5, 3, 3] = float("inf")
+    vb = _lib.gn_stats_values(_lib.gn_stats(bad.contiguous(memory_format=torch.channels_last), 32)).reshape(4, 32, 2)
+    assert torch.isnan(vb[1, 5 // 4]).all() and not torch.isnan(vb[0]).any() and not torch.isnan(vb[1, 3]).any()
+
+
+# ------------------------------------------------------------------------------------------ run-to-run reproducibility
+@pytest.mark.parametrize("size,batches", [(256, (1, 4, 16)), (512, (1, 4, 16))])
+def test_encoder_and_decoder_are_bit_reproducible(size, batches):
+    """VERDICT r2 next #1a: encoder(x) bit-identical across 20 calls at B = 1, 4, 16, at 256^2 and 512^2 (the reference's
+    CPU path is deterministic, pit/quantization/gaussian.py:136-150 sees ONE z per image); so are the tokens and the
+    decoder.  channels_last = the bench configuration."""
+    vae = _engine().to(DEV).to(memory_format=torch.channels_last)
+    for B in batches:
+        g = torch.Generator().manual_seed(9 + B + size)
+        x = (torch.rand(B, 3, size, size, generator=g) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            z0 = vae.encoder(x)
+            zq0, info0 = vae.regularization(z0)
+            r0 = vae.decode(zq0)
+            runs = 20 if B * size * size <= 16 * 256 * 256 else 8
+            for i in range(runs):
+                z = vae.encoder(x)
+                assert torch.equal(z, z0), f"encoder run {i} at B={B}, {size}^2 differs: max {float((z - z0).abs().max()):.2e}"
+            for i in range(4):
+                zq, info = vae.regularization(vae.encoder(x))
+                assert torch.equal(info["indices"], info0["indices"]) and torch.equal(zq, zq0)
+                assert torch.equal(vae.decode(zq0), r0), f"decoder run {i} at B={B}, {size}^2 differs"
+
+
+def test_nchw_encoder_is_bit_reproducible_too():
+    """The NCHW module (no channels_last conversion: ATen / MIOpen convolutions, libgqhip's NCHW GroupNorm): the statistics
+    are order-independent there as well; the conv libraries' picks are outside our control, so this asserts what we own --
+    the tokens of two passes agree exactly when the encoder's z does."""
+    vae = _engine().to(DEV)
+    g = torch.Generator().manual_seed(77)
+    x = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        z0 = vae.encoder(x)
+        z1 = vae.encoder(x)
+        i0 = vae.regularization(z0)[1]["indices"]
+        i1 = vae.regularization(z1)[1]["indices"]
+    if torch.equal(z0, z1):
+        assert torch.equal(i0, i1)
+    else:   # a library kernel of the NCHW route is not reproducible: report it, the channels_last route is the product path
+        print(f"NCHW route: z differs by {float((z0 - z1).abs().max()):.2e} between two passes (conv library)")
+        assert int((i0 != i1).sum()) <= 2
+
+
+# ------------------------------------------------------------------------------------------ 8-image end-to-end golden
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_g14_eight_images_end_to_end_vs_reference_golden(channels_last):
+    """8 images at 256^2 (eval.py:144-151 feeds batches) through GPU encoder -> GPU quantiser -> GPU
+    decoder against the reference's CPU path (golden g14: z, indices, top-2 gaps, reconstruction).  Gate per 1024 rows as
+    for g7: |dz| <= 5e-5, at most 2 indices differ and only where the reference's own top-2 gap is < 1e-3; the golden z
+    through the GPU quantiser: identical indices except where the gap is below the libm difference (< 1e-4)."""
+    d = np.load(os.path.join(G, "g14_e2e_8x256.npz"))
+    vae = _engine().to(DEV)
+    gx = torch.Generator().manual_seed(3256)
+    x = (torch.rand(8, 3, 256, 256, generator=gx) * 2 - 1).to(DEV)
+    if channels_last:
+        vae = vae.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        z_enc = vae.encode(x, unregularized=True)[0]
+        z, ind = vae.quant(x)
+        rec = vae.dequant(ind)
+    dz = float((z_enc.cpu() - torch.from_numpy(d["z_enc"])).abs().max())
+    assert dz <= 5e-5, dz
+    got, want, gap = _rows(ind.cpu().numpy()), _rows(d["indices"]), d["gap"]
+    diff = got != want
+    per_image = diff.reshape(8, 1024).sum(1)
+    print(f"g14 e2e 8 x 256^2 (channels_last={channels_last}): |dz| {dz:.2e}, {int(diff.sum())} of 8192 indices differ"
+          f"{' at gaps ' + str(gap[diff]) if diff.any() else ''}; rows with gap < 1e-3 in the golden: {int((gap < 1e-3).sum())}")
+    assert per_image.max() <= 2 and np.all(gap[diff] < 1e-3), (per_image, gap[diff])
+    ref = torch.from_numpy(d["x_rec"].astype(np.float32))
+    same = ~diff.reshape(8, 1024).any(1)
+    if same.any():    # images whose tokens all agree: the reconstruction is the reference's up to conv rounding (golden is fp16)
+        assert float((rec.cpu()[same] - ref[same]).abs().max()) <= 5e-3
+    mse = float(((rec.cpu() - ref) ** 2).mean())
+    assert 10 * np.log10(4.0 / max(mse, 1e-20)) >= 60.0
+    zhat, info = vae.regularization(torch.from_numpy(d["z_enc"]).to(DEV))
+    diff2 = _rows(info["indices"].cpu().numpy()) != want
+    assert diff2.sum() == 0 or np.all(gap[diff2] < 1e-4), (diff2.sum(), gap[diff2])

@@ -38,8 +38,21 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(dll, name), f"libgqhip.so does not export {name}"
     assert declared == set(L.EXPORTED_SYMBOLS), "python binding and header disagree"
-    assert L.lib().gqhip_abi_version() == L.ABI_VERSION == 4
+    assert L.lib().gqhip_abi_version() == L.ABI_VERSION == 5
     assert L.lib().gqhip_status_string(2) == b"workspace missing or too small"
+
+
+def test_groupnorm_statistics_arithmetic_on_the_host(tmp_path):
+    """csrc/gq_stats.h compiled for the host (tests/stats_host_test.cpp): the integer split of fp32 addends equals the fp64
+    split bit for bit over 300 000 addends (random bit patterns, edges, denormals, +-inf / NaN), sums are independent of the
+    order of the adds, the limbs hold the EXACT integer sum of the truncated addends, non-finite addends poison the record."""
+    import subprocess
+
+    exe = str(tmp_path / "stats_host_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "vq-vae-from-gaussian-vae_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "stats_host_test.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok:"), out.stdout + out.stderr
 
 
 def test_workspace_sizing_is_host_only_and_monotone():

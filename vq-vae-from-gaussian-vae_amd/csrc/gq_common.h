@@ -38,8 +38,10 @@ struct WsHeader {
   unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly
   float absmax;                       // max |cb|, reduced from absmax_part by the level-1 re-rank
   unsigned bar_count, bar_gen;        // grid barrier of the tail kernel (cascade path only)
-  int bar_timeout;                    // set if a barrier spin ever ran out (never expected; gqhip_debug_counters reports it)
-  int pad1[24];
+  int bar_timeout;                    // blocks whose barrier spin ran out (gqhip_debug_counters reports it)
+  int bar_abort;                      // set by the first such block: nobody waits at a barrier any more, every block
+                                      // finishes list A through the barrier-free exhaustive path (gq_tail.h)
+  int pad1[23];
   float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
   int pad2[128];

@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "gq_common.h"
+#include "gq_stats.h"
 #include "gq_wino_gemm.h"
 
 namespace gqhip {
@@ -55,7 +56,7 @@ struct Conv3Params {
   const float *bias;    // [cout] or null
   const float *res;     // [B][H][W][cout] or null
   float *y;             // [B][H][W][cout]
-  double *stats;        // [B][groups][2] (sum, sum of squares) or null
+  int64_t *stats;     // [B][groups] statistics records (gq_stats.h) or null
   int H, W, nch, cpg;   // cpg: channels per GroupNorm group of the output
   int cout, nnb;        // output channels (a multiple of 128), 128-channel blocks per tile (cout / 128)
   int tiles_x, tiles_y;
@@ -105,7 +106,7 @@ __device__ __forceinline__ void conv3_tap(const unsigned char *A, int dy, const 
 // COUT is a template parameter: with a run-time channel stride none of the 128 loads / 128 stores of a lane has a constant
 // offset and hipcc materialises their addresses (~300 bytes of scratch per lane).
 template <int COUT>
-__device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3Tile &t, const f32x16 (&acc)[4][2], double *red,
+__device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3Tile &t, const f32x16 (&acc)[4][2], int64_t *red,
                                                int tid, int wm, int wn, int c, int h) {
   float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
   const int W = p.W;
@@ -135,12 +136,11 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int g = ((2 * wn + j) * 32 + c) / p.cpg;      // group within this block's 128 channels
-      atomicAdd(&red[2 * g], (double)s[j]);
-      atomicAdd(&red[2 * g + 1], (double)ss[j]);
+      stat_add_f32(red + kStatWords * g, s[j], ss[j]);
     }
     __syncthreads();
     const int gpb = 128 / p.cpg, groups = cout / p.cpg;    // groups per block, per image
-    if (tid < 2 * gpb) atomicAdd(&p.stats[2 * (t.b * groups + t.nb * gpb) + tid], red[tid]);
+    if (tid < kStatWords * gpb) stat_flush_word(p.stats + kStatWords * (t.b * groups + t.nb * gpb) + tid, red[tid]);
   }
 }
 
@@ -152,13 +152,13 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3
 template <int COUT>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const Conv3Params p) {
   __shared__ __attribute__((aligned(16))) unsigned char sA[2][kC3Buf];
-  __shared__ double red[2 * 64];
+  __shared__ int64_t red[kStatWords * 32];   // statistics records of the block's <= 32 groups (gq_stats.h)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
   Conv3Tile t;
   if (!conv3_tile(p, t)) return;
   const int H = p.H, W = p.W;
-  if (tid < 128) red[tid] = 0.0;
+  red[tid] = 0;   // kStatWords * 32 = 256 words
 
   // loader bookkeeping: piece j = tid + 256 i -> (patch row, pixel, plane, half)
   int goff[kC3Loads], loff[kC3Loads];
@@ -237,7 +237,7 @@ struct Conv3GnParams {
   Conv3Params c;
   const float *x;          // [B][H][W][cin]
   const float *gamma, *beta, *pre_bias;
-  const double *stats_in;  // [B][groups_in][2]
+  const int64_t *stats_in;  // [B][groups_in] statistics records (gq_stats.h)
   int cin, cpg_in;
   double eps;
   float scale;
@@ -248,21 +248,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   const Conv3Params &p = pp.c;
   __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kC3Buf];
-  __shared__ double red[2 * 64];
+  __shared__ int64_t red[kStatWords * 32];   // statistics records of the block's <= 32 groups (gq_stats.h)
   __shared__ __attribute__((aligned(16))) float sAff[2][512];   // folded scale, shift per input channel (cin <= 512)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
   Conv3Tile t;
   if (!conv3_tile(p, t)) return;
   const int H = p.H, W = p.W, cin = pp.cin;
-  if (tid < 128) red[tid] = 0.0;
+  red[tid] = 0;   // kStatWords * 32 = 256 words
   {
     const int groups = cin / pp.cpg_in;
     const double n = (double)pp.cpg_in * (double)H * (double)W;
     for (int ch = tid; ch < cin; ch += 256) {
       const int g = ch / pp.cpg_in;
-      const double mean = pp.stats_in[2 * (t.b * groups + g)] / n;
-      double var = pp.stats_in[2 * (t.b * groups + g) + 1] / n - mean * mean;
+      double st_s, st_ss;
+      stat_load(pp.stats_in + kStatWords * (t.b * groups + g), st_s, st_ss);
+      const double mean = st_s / n;
+      double var = st_ss / n - mean * mean;
       var = var > 0.0 ? var : 0.0;
       const double rstd = 1.0 / sqrt(var + pp.eps);
       const double pbk = pp.pre_bias ? (double)pp.pre_bias[ch] : 0.0;
@@ -374,7 +376,7 @@ template <int SILU>
 __global__ __launch_bounds__(256) void conv3_split_gn_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta,
                                                              const float *__restrict__ pre_bias,
-                                                             const double *__restrict__ stats, _Float16 *__restrict__ Xs,
+                                                             const int64_t *__restrict__ stats, _Float16 *__restrict__ Xs,
                                                              long HW, int C, int cpg, double eps, float scale, long total) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   const int nch = C / 16, groups = C / cpg;
@@ -389,8 +391,10 @@ __global__ __launch_bounds__(256) void conv3_split_gn_kernel(const float *__rest
     if (stats) {
       const int g = c0 / cpg;
       const double n = (double)cpg * (double)HW;
-      const double mean = stats[2 * (b * groups + g)] / n;
-      double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+      double st_s, st_ss;
+      stat_load(stats + kStatWords * (b * groups + g), st_s, st_ss);
+      const double mean = st_s / n;
+      double var = st_ss / n - mean * mean;
       var = var > 0.0 ? var : 0.0;
       const double rstd = 1.0 / sqrt(var + eps);
       f32x4 a, sh;
@@ -437,12 +441,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const Conv1Params
   Conv3Params p = pp.c;
   constexpr int kPlane = 256 * 32, kChunk = 2 * kPlane, kStage = 2 * kChunk;   // bytes
   __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kStage];
-  __shared__ double red[2 * 64];
+  __shared__ int64_t red[kStatWords * 32];   // statistics records of the block's <= 32 groups (gq_stats.h)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
   Conv3Tile t;
   if (!conv3_tile(p, t)) return;
-  if (tid < 128) red[tid] = 0.0;
+  red[tid] = 0;   // kStatWords * 32 = 256 words
   const float scale = pp.scales_dev ? pp.scales_dev[0] : pp.scale;
   if (pp.scales_dev) p.mscale = pp.scales_dev[1];
   const int cin = pp.cin, nst = cin / 32;
@@ -544,12 +548,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(const Conv3S2Pa
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   Conv3Params p = pp.c;
   __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kC3Buf];
-  __shared__ double red[2 * 64];
+  __shared__ int64_t red[kStatWords * 32];   // statistics records of the block's <= 32 groups (gq_stats.h)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
   Conv3Tile t;
   if (!conv3_tile(p, t)) return;
-  if (tid < 128) red[tid] = 0.0;
+  red[tid] = 0;   // kStatWords * 32 = 256 words
   const float scale = pp.scales_dev ? pp.scales_dev[0] : pp.scale;
   if (pp.scales_dev) p.mscale = pp.scales_dev[1];
   const int cin = pp.cin, nch = p.nch, Hin = pp.Hin, Win = pp.Win;
@@ -673,13 +677,13 @@ __global__ __launch_bounds__(256, 2) void upconv2x_f16x3_kernel(const Upconv2Par
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   Conv3Params p = pp.c;
   __shared__ __attribute__((aligned(16))) unsigned char sA[2 * kC3Buf];
-  __shared__ double red[2 * 64];
+  __shared__ int64_t red[kStatWords * 32];   // statistics records of the block's <= 32 groups (gq_stats.h)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
   Conv3Tile t;
   if (!conv3_tile(p, t)) return;
   const int pa = (int)blockIdx.y >> 1, pb = (int)blockIdx.y & 1;
-  if (tid < 128) red[tid] = 0.0;
+  red[tid] = 0;   // kStatWords * 32 = 256 words
   const float scale = pp.scales_dev ? pp.scales_dev[0] : pp.scale;
   if (pp.scales_dev) p.mscale = pp.scales_dev[1];
   const int cin = pp.cin, nch = p.nch, H = p.H, W = p.W;
@@ -788,12 +792,11 @@ __global__ __launch_bounds__(256, 2) void upconv2x_f16x3_kernel(const Upconv2Par
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int g = ((2 * wn + j) * 32 + c) / p.cpg;      // group within this block's 128 channels
-      atomicAdd(&red[2 * g], (double)s[j]);
-      atomicAdd(&red[2 * g + 1], (double)ss[j]);
+      stat_add_f32(red + kStatWords * g, s[j], ss[j]);
     }
     __syncthreads();
     const int gpb = 128 / p.cpg, groups = cout / p.cpg;    // groups per block, per image
-    if (tid < 2 * gpb) atomicAdd(&p.stats[2 * (t.b * groups + t.nb * gpb) + tid], red[tid]);
+    if (tid < kStatWords * gpb) stat_flush_word(p.stats + kStatWords * (t.b * groups + t.nb * gpb) + tid, red[tid]);
   }
 }
 
@@ -808,7 +811,7 @@ template <int SILU, int COUT>
 __global__ __launch_bounds__(256) void conv3x3_gn_small_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                                const float *__restrict__ beta,
                                                                const float *__restrict__ pre_bias,
-                                                               const double *__restrict__ stats, const float *__restrict__ w,
+                                                               const int64_t *__restrict__ stats, const float *__restrict__ w,
                                                                const float *__restrict__ bias, float *__restrict__ y, int H,
                                                                int W, int C, int cpg, double eps) {
   constexpr int PW = 18, PS = 36;                       // patch width, floats per staged pixel
@@ -824,8 +827,10 @@ __global__ __launch_bounds__(256) void conv3x3_gn_small_kernel(const float *__re
     const double n = (double)cpg * (double)H * (double)W;
     for (int ch = tid; ch < C; ch += 256) {
       const int g = ch / cpg;
-      const double mean = stats[2 * (b * groups + g)] / n;
-      double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+      double st_s, st_ss;
+      stat_load(stats + kStatWords * (b * groups + g), st_s, st_ss);
+      const double mean = st_s / n;
+      double var = st_ss / n - mean * mean;
       var = var > 0.0 ? var : 0.0;
       const double rstd = 1.0 / sqrt(var + eps);
       const double pbk = pre_bias ? (double)pre_bias[ch] : 0.0;

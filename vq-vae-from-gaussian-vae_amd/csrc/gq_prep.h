@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     p.hdr->reranked = 0ull;
     p.hdr->bar_count = 0u;
     p.hdr->bar_timeout = 0;
+    p.hdr->bar_abort = 0;
   }
 
   if ((int)blockIdx.x >= p.row_blocks) {

@@ -90,6 +90,7 @@ struct RerankParams {
                       // every row undecided (cascade: fp32 filter, fp64 second stage)
   int all_rows;       // exhaustive kernel: process every row (no filter ran)
   int stats;          // count re-ranked half-pairs (debug)
+  int bar_spin_limit; // tail kernel: polls (~0.25 us each) a grid barrier waits before it gives up (gq_tail.h)
   OutMap omap;
 };
 
@@ -842,11 +843,18 @@ __device__ __forceinline__ void second_stage(const RerankParams &p) {
   }
 }
 
-// Grid barrier of the tail kernel (all blocks co-resident: the host sizes the grid with the occupancy API).
+// Grid barrier of the tail kernel.  The host sizes the grid so that every block is co-resident (occupancy API x CU
+// count), but nothing in HIP guarantees that: a CU mask, another stream holding CUs or a profiler can leave blocks
+// queued behind spinning ones.  So the barrier is allowed to FAIL: it returns false when this block's spin ran out or
+// any block has reported that (hdr->bar_abort).  From then on nobody waits at a barrier, and every block finishes
+// list A through exhaustive_rows() below, which depends on no other block (gq_tail.h) -- a failed barrier costs time,
+// never a wrong index.  A block only consumes other blocks' data behind a barrier that returned true, i.e. after
+// all `nblocks` arrivals, each made after the arriving block's own phase was complete and released.
 // Producer side: every wave drains its stores, the block meets, lane 0 releases at agent scope and arrives;
 // consumer side: relaxed agent-scope poll, ONE acquire, block barrier (MI355X_MICROARCH.md, inter-workgroup
 // visibility: per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores).
-__device__ __forceinline__ void grid_barrier(WsHeader *hdr, unsigned nblocks) {
+__device__ __forceinline__ bool grid_barrier(WsHeader *hdr, unsigned nblocks, int spin_limit) {
+  __shared__ int sh_ok;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -860,35 +868,38 @@ __device__ __forceinline__ void grid_barrier(WsHeader *hdr, unsigned nblocks) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(&hdr->bar_gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      // bounded (MI355X_MICROARCH.md: "bound every spin"): ~4 s, orders of magnitude beyond any real wait; if the
-      // grid were ever not co-resident the call ends with wrong rows flagged in the header instead of a hung GPU
-      long spins = 0;
-      while (__hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      // bounded (MI355X_MICROARCH.md: "bound every spin"): the default limit is ~0.5 s, orders of magnitude beyond
+      // any real wait of a co-resident grid
+      int spins = 0;
+      while (__hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen &&
+             __hip_atomic_load(&hdr->bar_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1L << 24)) {
-          hdr->bar_timeout = 1;
+        if (++spins > spin_limit) {
+          __hip_atomic_store(&hdr->bar_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(&hdr->bar_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sh_ok = __hip_atomic_load(&hdr->bar_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
   }
   __syncthreads();
+  return sh_ok != 0;
 }
 
-// Exhaustive exact arg-max: one block per listed row (grid-stride over the
-// list).  Used for rows the filter could not decide and for shapes the MFMA
-// filter does not cover (dim not in {4,8,16,32}).
+// Exhaustive exact arg-max of rows list[first], list[first + stride], ... (list == NULL: the rows themselves): one
+// block per row, every code scored in the reference's operation order.  Depends on nothing but the row operands and
+// the codebook, so it is also what the tail kernel falls back to when a grid barrier fails.
 template <int MODE>
-__global__ __launch_bounds__(256) void gq_exhaustive_kernel(const RerankParams p) {
+__device__ __forceinline__ void exhaustive_rows(const RerankParams &p, const int *list, int count, int first, int stride) {
   __shared__ double sh_s[256];
   __shared__ int sh_i[256];
   __shared__ RowOps rops;
   const int tid = threadIdx.x;
-  const int count = p.all_rows ? p.rows : p.hdr->fb_count;
-  for (int e = blockIdx.x; e < count; e += gridDim.x) {
-    const long row = p.all_rows ? e : p.fb_list[e];
+  for (int e = first; e < count; e += stride) {
+    const long row = list ? list[e] : e;
     if (tid < p.dim) load_row_ops(p, row, tid, rops);
     __syncthreads();
     double best_s = 0.0;
@@ -921,6 +932,14 @@ __global__ __launch_bounds__(256) void gq_exhaustive_kernel(const RerankParams p
     __syncthreads();
     write_result(p, row, best, tid);
   }
+}
+
+// Exhaustive exact arg-max as a kernel: rows the filter could not decide, and shapes the MFMA
+// filter does not cover (dim not in {4,8,16,32}).
+template <int MODE>
+__global__ __launch_bounds__(256) void gq_exhaustive_kernel(const RerankParams p) {
+  const int count = p.all_rows ? p.rows : p.hdr->fb_count;
+  exhaustive_rows<MODE>(p, p.all_rows ? nullptr : p.fb_list, count, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace gqhip

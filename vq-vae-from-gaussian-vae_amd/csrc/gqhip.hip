@@ -1,4 +1,5 @@
-// gqhip.hip -- C-ABI entry points of libgqhip.so (see include/gqhip.h).
+// gqhip.hip -- C-ABI entry points of libgqhip.so (see include/gqhip.h): the quantiser path (fused arg-max, compat score
+// op, dequant, LFQ / FSQ, wire format) and the library-wide services.  The conv-stack entry points are in gqhip_unet.hip.
 // gfx950 only; built by `make -C vq-vae-from-gaussian-vae_amd/csrc`.
 #include "gqhip.h"
 
@@ -12,6 +13,7 @@
 #include <utility>
 #include <vector>
 
+#include "gqhip_internal.h"
 #include "gq_aux.h"
 #include "gq_common.h"
 #include "gq_filter.h"
@@ -20,16 +22,13 @@
 #include "gq_rerank.h"
 #include "gq_scores.h"
 #include "gq_tail.h"
-#include "gq_wino_gemm.h"
-#include "gq_conv3.h"
 
 using namespace gqhip;
 
-namespace {
-
+namespace gqhip {
 thread_local int g_last_hip_error = 0;
 
-inline int check_launch() {
+int check_launch() {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
@@ -37,6 +36,9 @@ inline int check_launch() {
   }
   return GQHIP_OK;
 }
+}  // namespace gqhip
+
+namespace {
 
 // ---- launch plan: identical on the sizing and the launching side -----------
 struct Plan {
@@ -306,8 +308,14 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
   return check_launch();
 }
 
-// Grid of the tail kernel: every block must be co-resident (it contains grid barriers on the cascade path), so it
-// is sized from the device: min(occupancy API, 2) blocks per CU x CU count, cached per (device, kernel).
+// Diagnostics of the tail kernel's barrier-failure path (gqhip_debug_tail): the grid multiplied beyond what is
+// co-resident, and a spin limit short enough that a test does not wait half a second per barrier.
+std::atomic<int> g_tail_grid_mult{1};
+std::atomic<int> g_tail_spin_limit{1 << 21};   // polls of ~0.25 us: ~0.5 s
+
+// Grid of the tail kernel: every block should be co-resident (it contains grid barriers on the cascade path), so it
+// is sized from the device: min(occupancy API, 2) blocks per CU x CU count, cached per (device, kernel).  Should the
+// blocks not be co-resident after all, the barriers time out and the kernel finishes barrier-free (gq_tail.h).
 int tail_grid(const void *kernel) {
   static std::mutex mu;
   static std::map<std::pair<int, const void *>, int> cache;
@@ -331,8 +339,9 @@ template <int MODE>
 int launch_tail(const RerankParams &rp, const FilterParams &f2, int dim, hipStream_t st) {
 #define GQ_TAIL(D)                                                                               \
   do {                                                                                           \
-    const int g = tail_grid(reinterpret_cast<const void *>(&gq_tail_kernel<MODE, D>));            \
+    int g = tail_grid(reinterpret_cast<const void *>(&gq_tail_kernel<MODE, D>));                  \
     if (g < 1) return GQHIP_ERR_LAUNCH;                                                          \
+    g *= g_tail_grid_mult.load(std::memory_order_relaxed);                                       \
     hipLaunchKernelGGL((gq_tail_kernel<MODE, D>), dim3((unsigned)g), dim3(256), 0, st, rp, f2);  \
   } while (0)
   switch (dim) {
@@ -415,6 +424,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   if (env_ef > 0.0) rp.ef_coeff = (float)env_ef;
   rp.beta = (float)beta; rp.nsplit = mixed ? 2 * pl.nsplit : pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
+  rp.bar_spin_limit = g_tail_spin_limit.load(std::memory_order_relaxed);
 
   if (!pl.mfma) {
     // dims outside {4, 8, 16, 32}: exact score of every code (gq_exhaustive_kernel)
@@ -673,640 +683,6 @@ int lfq_unpack_f32(const int64_t *idx, float *q, int64_t rows, int64_t nbits, vo
   return check_launch();
 }
 
-int gn_silu_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null, float *y,
-                int64_t B, int64_t C, int64_t HW, int64_t groups, double eps, int apply_silu, int layout,
-                double *stats_ws, void *stream) {
-  if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !gamma || !beta || !y || !stats_ws) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t bg = B * groups, cpg = C / groups, chunk = cpg * HW;
-  if (layout == GQHIP_LAYOUT_NHWC) {
-    // thread <-> channel-quad mapping needs cpg % 4 == 0, (C/4) | 256, <= 64 groups
-    if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
-    if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * bg, st) != hipSuccess) return check_launch();
-    const int lanes = (int)(256 / (C / 4));
-    int slabs = (int)((HW + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16));   // ~16 pixels per thread
-    if (slabs > 1024) slabs = 1024;
-    if (slabs < 1) slabs = 1;
-    hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, pre_bias_or_null,
-                       stats_ws, (int)C, (long)HW, (int)cpg, slabs);
-    int rc = check_launch();
-    if (rc != GQHIP_OK) return rc;
-    if (apply_silu)
-      hipLaunchKernelGGL((gn_apply_nhwc_kernel<1>), dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, gamma, beta, y,
-                         stats_ws, pre_bias_or_null, (int)C, (long)HW, (int)cpg, eps, slabs);
-    else
-      hipLaunchKernelGGL((gn_apply_nhwc_kernel<0>), dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, gamma, beta, y,
-                         stats_ws, pre_bias_or_null, (int)C, (long)HW, (int)cpg, eps, slabs);
-    return check_launch();
-  }
-  if (layout != GQHIP_LAYOUT_NCHW || HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;   // callers fall back to torch
-  if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * bg, st) != hipSuccess) return check_launch();
-  // ~16 KiB of input per block keeps >= 2k blocks in flight at the big resolutions
-  int slices = (int)((chunk + 4095) / 4096);
-  if (slices > 256) slices = 256;
-  if (slices < 1) slices = 1;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(bg * slices)), dim3(256), 0, st, x, pre_bias_or_null, stats_ws,
-                     (long)chunk, slices, (long)HW, (int)cpg, (int)groups);
-  int rc = check_launch();
-  if (rc != GQHIP_OK) return rc;
-  int segs = (int)((HW + 8191) / 8192);
-  if (segs < 1) segs = 1;
-  const dim3 grid((unsigned)(B * C * segs));
-  if (apply_silu)
-    hipLaunchKernelGGL((gn_apply_kernel<1>), grid, dim3(256), 0, st, x, gamma, beta, y, stats_ws, pre_bias_or_null,
-                       (int)C, (long)HW, (int)cpg, eps, segs);
-  else
-    hipLaunchKernelGGL((gn_apply_kernel<0>), grid, dim3(256), 0, st, x, gamma, beta, y, stats_ws, pre_bias_or_null,
-                       (int)C, (long)HW, (int)cpg, eps, segs);
-  return check_launch();
-}
-
-int add_bias_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B, int64_t C,
-                 int64_t HW, int layout, void *stream) {
-  if (B < 0 || C < 1 || HW < 1) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!a || !b || !y) return GQHIP_ERR_INVALID_ARG;
-  const long total4 = (long)(B * C * HW / 4);
-  long blocks = (total4 + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (layout == GQHIP_LAYOUT_NHWC) {
-    if (C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(add_bias_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, bias_or_null, y, (int)C,
-                       total4);
-  } else {
-    if (layout != GQHIP_LAYOUT_NCHW || HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(add_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, bias_or_null, y, (int)C,
-                       (long)HW, total4);
-  }
-  return check_launch();
-}
-
-// slabs of ~16 pixels per thread, as gn_silu_f32's NHWC path
-static int nhwc_slabs(int64_t C, int64_t HW) {
-  const int lanes = (int)(256 / (C / 4));
-  int slabs = (int)((HW + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16));
-  if (slabs > 1024) slabs = 1024;
-  return slabs < 1 ? 1 : slabs;
-}
-
-int add_bias_stats_f32(const float *a, const float *b, const float *bias_or_null, float *y, int64_t B, int64_t C,
-                       int64_t HW, int64_t groups, double *stats_out, void *stream) {
-  if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!a || !b || !y || !stats_out) return GQHIP_ERR_INVALID_ARG;
-  const int64_t cpg = C / groups;
-  if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(stats_out, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) return check_launch();
-  const int slabs = nhwc_slabs(C, HW);
-  hipLaunchKernelGGL(add_bias_stats_nhwc_kernel, dim3((unsigned)(B * slabs)), dim3(256), 0, st, a, b, bias_or_null, y,
-                     stats_out, (int)C, (long)HW, (int)cpg, slabs);
-  return check_launch();
-}
-
-int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B, int64_t C, int64_t HW,
-                 int64_t groups, double eps, int apply_silu, const double *stats, void *stream) {
-  if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !gamma || !beta || !y || !stats) return GQHIP_ERR_INVALID_ARG;
-  const int64_t cpg = C / groups;
-  if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int slabs = nhwc_slabs(C, HW);
-  if (apply_silu)
-    hipLaunchKernelGGL((gn_apply_nhwc_kernel<1>), dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, gamma, beta, y, stats,
-                       (const float *)nullptr, (int)C, (long)HW, (int)cpg, eps, slabs);
-  else
-    hipLaunchKernelGGL((gn_apply_nhwc_kernel<0>), dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, gamma, beta, y, stats,
-                       (const float *)nullptr, (int)C, (long)HW, (int)cpg, eps, slabs);
-  return check_launch();
-}
-
-int wino_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
-  if (B < 0 || H < 2 || W < 2 || H % 2 || W % 2 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !V) return GQHIP_ERR_INVALID_ARG;
-  const long tiles = (long)(B * (H / 2) * (W / 2)), total = tiles * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(wino_in_nhwc_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     (void *)V, (int)H, (int)W, (int)(C / 4), tiles, total, 1.0f);
-  return check_launch();
-}
-
-static int wino_in_f16_impl(int vm, const float *x, void *V, int64_t B, int64_t H, int64_t W, int64_t C, int tile,
-                            float scale, void *stream) {
-  if ((tile != 2 && tile != 4) || B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 ||
-      !(scale > 0.f))
-    return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !V) return GQHIP_ERR_INVALID_ARG;
-  const long tiles = (long)(B * (H / tile) * (W / tile)), total = tiles * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-#define GQ_WIN(K, VM) \
-  hipLaunchKernelGGL(K<VM>, dim3((unsigned)blocks), dim3(256), 0, st, x, V, (int)H, (int)W, (int)(C / 4), tiles, total, scale)
-  if (tile == 4) { if (vm == 2) GQ_WIN(wino4_in_nhwc_kernel, 2); else GQ_WIN(wino4_in_nhwc_kernel, 1); }
-  else { if (vm == 2) GQ_WIN(wino_in_nhwc_kernel, 2); else GQ_WIN(wino_in_nhwc_kernel, 1); }
-#undef GQ_WIN
-  return check_launch();
-}
-
-int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
-                       void *stream) {
-  return wino_in_f16_impl(1, x, V3, B, H, W, C, tile, scale, stream);
-}
-
-int wino_in_nhwc_f16x2(const float *x, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
-                       void *stream) {
-  return wino_in_f16_impl(2, x, V2, B, H, W, C, tile, scale, stream);
-}
-
-int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, int64_t tiles, void *stream) {
-  if (P < 1 || tiles < 0 || tiles > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
-  if (tiles == 0) return GQHIP_OK;
-  if (!V2 || !U2t || !M) return GQHIP_ERR_INVALID_ARG;
-  WinoGemmParams wp{};
-  wp.V2 = static_cast<const _Float16 *>(V2); wp.U2t = static_cast<const _Float16 *>(U2t); wp.M = M; wp.tiles = tiles;
-  // ONE round of co-resident blocks (2 per CU: 70 KiB of LDS, <= 256 VGPRs): the kernel is HBM-bound, so a partial last
-  // round would idle part of the chip for a whole block's duration (1152 blocks of 2048 rows = 2.25 rounds ran at 3.9 TB/s).
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
-  long bpp = (2L * cus) / P;
-  if (bpp < 1) bpp = 1;
-  long rpb = ((tiles + bpp - 1) / bpp + 127) / 128 * 128;
-  if (rpb < 128) rpb = 128;
-  wp.rows_per_block = (int)rpb;
-  wp.blocks_per_pos = (int)((tiles + rpb - 1) / rpb);
-  hipLaunchKernelGGL(wino_gemm_c128_f16x2_kernel, dim3((unsigned)(P * wp.blocks_per_pos)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), wp);
-  return check_launch();
-}
-
-int wino_gemm_f16x2(const void *V2, const void *Wf, float *M, int64_t P, int64_t tiles, int64_t Cin, int64_t Cout,
-                    void *stream) {
-  if (P < 1 || tiles < 0 || tiles > 0x3fffffff || tiles % 256 != 0 || Cin < 32 || Cin % 32 != 0 || Cin > 4096 || Cout < 128 ||
-      Cout % 128 != 0 || Cout > 4096)
-    return GQHIP_ERR_INVALID_ARG;
-  if (tiles == 0) return GQHIP_OK;
-  if (!V2 || !Wf || !M) return GQHIP_ERR_INVALID_ARG;
-  WinoGemm2Params wp{};
-  wp.V2 = static_cast<const _Float16 *>(V2); wp.Wf = static_cast<const _Float16 *>(Wf); wp.M = M; wp.tiles = tiles;
-  wp.cin = (int)Cin; wp.cout = (int)Cout; wp.nnb = (int)(Cout / 128);
-  wp.mtiles = tiles / 256; wp.ntile_total = P * wp.mtiles; wp.tiles_per_xcd = (wp.ntile_total + 7) / 8;
-  // 256 x 256 tiles (8 waves, one block per CU) where the shape allows: Cin % 64 == 0, Cout % 256 == 0; GQHIP_WGEMM=128 keeps
-  // the 256 x 128 form (A/B)
-  static const int env_w = getenv("GQHIP_WGEMM") ? atoi(getenv("GQHIP_WGEMM")) : 0;
-  const bool wide = Cin % 64 == 0 && Cout % 256 == 0 && env_w != 128;
-  if (wide) wp.nnb = (int)(Cout / 256);
-  const long blocks = 8 * wp.tiles_per_xcd * wp.nnb;
-  if (blocks > 0x7fffffffL) return GQHIP_ERR_INVALID_ARG;
-  if (wide)
-    hipLaunchKernelGGL(wino_gemm_f16x2_w8_kernel, dim3((unsigned)blocks), dim3(512), 0, static_cast<hipStream_t>(stream), wp);
-  else
-    hipLaunchKernelGGL(wino_gemm_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), wp);
-  return check_launch();
-}
-
-int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64_t C, int64_t HW, int64_t groups,
-                 double *stats_out, void *stream) {
-  if (B < 0 || C < 1 || HW < 1 || groups < 1 || C % groups != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !stats_out) return GQHIP_ERR_INVALID_ARG;
-  const int64_t cpg = C / groups;
-  if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(stats_out, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) return check_launch();
-  const int slabs = nhwc_slabs(C, HW);
-  hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, pre_bias_or_null, stats_out,
-                     (int)C, (long)HW, (int)cpg, slabs);
-  return check_launch();
-}
-
-static int wino_in_gn_impl(int tile, int f16, const float *x, const float *gamma, const float *beta,
-                           const float *pre_bias_or_null, const double *stats, void *V, int64_t B, int64_t H, int64_t W,
-                           int64_t C, int64_t groups, double eps, int apply_silu, float scale, void *stream) {
-  if (B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 || groups < 1 || C % groups != 0 ||
-      (C / groups) % 4 != 0 || !(scale > 0.f))
-    return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !gamma || !beta || !stats || !V) return GQHIP_ERR_INVALID_ARG;
-  // F(4x4,3x3) on an fp16 operand: two channels per thread (register pressure: see the kernel); 4 otherwise
-  const int vw = (tile == 4 && f16 != 0) ? 2 : 4;
-  const long tiles = (long)(B * (H / tile) * (W / tile)), total = tiles * (C / vw);
-  long blocks = (total + 255) / 256;
-  if (blocks > 32768) blocks = 32768;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-#define GQ_WGN(K, ...)                                                                                                  \
-  hipLaunchKernelGGL((K<__VA_ARGS__>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, pre_bias_or_null, stats, \
-                     V, (int)H, (int)W, (int)(C / vw), (int)(C / groups), eps, tiles, total, scale)
-  if (tile == 4) {
-    if (apply_silu) {
-      if (f16 == 2) GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 2, 2); else if (f16 == 1) GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 1, 2);
-      else GQ_WGN(wino4_in_gn_nhwc_kernel, 1, 0, 4);
-    } else {
-      if (f16 == 2) GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 2, 2); else if (f16 == 1) GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 1, 2);
-      else GQ_WGN(wino4_in_gn_nhwc_kernel, 0, 0, 4);
-    }
-  } else {
-    if (apply_silu) {
-      if (f16 == 2) GQ_WGN(wino_in_gn_nhwc_kernel, 1, 2); else if (f16 == 1) GQ_WGN(wino_in_gn_nhwc_kernel, 1, 1);
-      else GQ_WGN(wino_in_gn_nhwc_kernel, 1, 0);
-    } else {
-      if (f16 == 2) GQ_WGN(wino_in_gn_nhwc_kernel, 0, 2); else if (f16 == 1) GQ_WGN(wino_in_gn_nhwc_kernel, 0, 1);
-      else GQ_WGN(wino_in_gn_nhwc_kernel, 0, 0);
-    }
-  }
-#undef GQ_WGN
-  return check_launch();
-}
-
-int wino_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                        const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
-                        double eps, int apply_silu, void *stream) {
-  return wino_in_gn_impl(2, 0, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, 1.0f, stream);
-}
-
-int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                         const double *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
-                         double eps, int apply_silu, void *stream) {
-  return wino_in_gn_impl(4, 0, x, gamma, beta, pre_bias_or_null, stats, V, B, H, W, C, groups, eps, apply_silu, 1.0f, stream);
-}
-
-int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                          const double *stats, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
-                          double eps, int apply_silu, int tile, float scale, void *stream) {
-  if (tile != 2 && tile != 4) return GQHIP_ERR_INVALID_ARG;
-  return wino_in_gn_impl(tile, 1, x, gamma, beta, pre_bias_or_null, stats, V3, B, H, W, C, groups, eps, apply_silu, scale,
-                         stream);
-}
-
-int wino_in_gn_nhwc_f16x2(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                          const double *stats, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
-                          double eps, int apply_silu, int tile, float scale, void *stream) {
-  if (tile != 2 && tile != 4) return GQHIP_ERR_INVALID_ARG;
-  return wino_in_gn_impl(tile, 2, x, gamma, beta, pre_bias_or_null, stats, V2, B, H, W, C, groups, eps, apply_silu, scale,
-                         stream);
-}
-
-int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *beta_or_null, const float *pre_bias_or_null,
-                       const double *stats_or_null, void *Xs, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
-                       double eps, int apply_silu, float scale, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || (H * W) % 16 != 0 || !(scale > 0.f)) return GQHIP_ERR_INVALID_ARG;
-  if (stats_or_null && (groups < 1 || C % groups != 0 || (C / groups) % 4 != 0 || !gamma_or_null || !beta_or_null))
-    return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !Xs) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * H * W * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 32768) blocks = 32768;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int cpg = stats_or_null ? (int)(C / groups) : 4;
-  if (apply_silu)
-    hipLaunchKernelGGL(conv3_split_gn_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma_or_null, beta_or_null,
-                       pre_bias_or_null, stats_or_null, static_cast<_Float16 *>(Xs), (long)(H * W), (int)C, cpg, eps, scale, total);
-  else
-    hipLaunchKernelGGL(conv3_split_gn_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma_or_null, beta_or_null,
-                       pre_bias_or_null, stats_or_null, static_cast<_Float16 *>(Xs), (long)(H * W), (int)C, cpg, eps, scale, total);
-  return check_launch();
-}
-
-// GroupNorm statistics of the output: every group must lie inside one block's 128 channels, 4 | channels per group
-static bool conv3_groups_ok(int64_t Cout, int64_t groups_out) {
-  if (groups_out < 1 || Cout % groups_out != 0) return false;
-  const int64_t cpg = Cout / groups_out;
-  return cpg % 4 == 0 && 128 % cpg == 0;
-}
-
-static void conv3_fill(Conv3Params &cp, const void *Wf, const float *bias, const float *res, float *y, double *stats, int64_t B,
-                       int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, float mscale) {
-  cp.Wf = static_cast<const _Float16 *>(Wf);
-  cp.bias = bias; cp.res = res; cp.y = y; cp.stats = stats;
-  cp.H = (int)H; cp.W = (int)W; cp.nch = (int)(Cin / 16); cp.cpg = stats ? (int)(Cout / groups_out) : 4;
-  cp.cout = (int)Cout; cp.nnb = (int)(Cout / 128);
-  cp.tiles_x = (int)(W / kC3TW); cp.tiles_y = (int)(H / kC3TH);
-  cp.ntiles = (long)B * cp.tiles_x * cp.tiles_y;
-  cp.tiles_per_xcd = (cp.ntiles + 7) / 8;
-  cp.mscale = mscale;
-}
-
-int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
-                  double *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
-                  float mscale, void *stream) {
-  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 16 || Cin % 16 != 0 || (Cout != 128 && Cout != 256) ||
-      H * W > (1 << 22))
-    return GQHIP_ERR_INVALID_ARG;
-  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!Xs || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
-    return check_launch();
-  Conv3Params cp{};
-  cp.Xs = static_cast<const _Float16 *>(Xs);
-  conv3_fill(cp, Wf, bias_or_null, res_or_null, y, stats_out_or_null, B, H, W, Cin, Cout, groups_out, mscale);
-  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
-  if (Cout == 128) hipLaunchKernelGGL(conv3x3_f16x3_kernel<128>, grid, dim3(256), 0, st, cp);
-  else hipLaunchKernelGGL(conv3x3_f16x3_kernel<256>, grid, dim3(256), 0, st, cp);
-  return check_launch();
-}
-
-int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                     const double *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
-                     const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B,
-                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, float mscale, void *stream) {
-  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 32 || Cin % 32 != 0 || Cin > 512 || (Cout != 128 && Cout != 256) ||
-      H * W > (1 << 22) || groups_in < 1 || Cin % groups_in != 0 || !(scale > 0.f))
-    return GQHIP_ERR_INVALID_ARG;
-  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !gamma || !beta || !stats_in || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
-    return check_launch();
-  Conv3GnParams gp{};
-  Conv3Params &cp = gp.c;
-  cp.Xs = nullptr;
-  conv3_fill(cp, Wf, bias_or_null, res_or_null, y, stats_out_or_null, B, H, W, Cin, Cout, groups_out, mscale);
-  gp.x = x; gp.gamma = gamma; gp.beta = beta; gp.pre_bias = pre_bias_or_null; gp.stats_in = stats_in;
-  gp.cin = (int)Cin; gp.cpg_in = (int)(Cin / groups_in); gp.eps = eps; gp.scale = scale;
-  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
-  if (Cout == 128) {
-    if (apply_silu) hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<1, 128>), grid, dim3(256), 0, st, gp);
-    else hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<0, 128>), grid, dim3(256), 0, st, gp);
-  } else {
-    if (apply_silu) hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<1, 256>), grid, dim3(256), 0, st, gp);
-    else hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<0, 256>), grid, dim3(256), 0, st, gp);
-  }
-  return check_launch();
-}
-
-int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf, const float *scales_dev_or_null, float scale,
-                  float mscale, const float *bias_or_null, const float *res_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t HW,
-                  int64_t Cin, int64_t Cout, int64_t groups_out, void *stream) {
-  if (B < 0 || HW < 256 || HW % 256 != 0 || Cin < 32 || Cin % 32 != 0 || (Cout != 128 && Cout != 256 && Cout != 512 && Cout != 1536) ||
-      HW > (1 << 24) || (!scales_dev_or_null && !(scale > 0.f)))
-    return GQHIP_ERR_INVALID_ARG;
-  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
-    return check_launch();
-  Conv1Params gp{};
-  Conv3Params &cp = gp.c;
-  conv3_fill(cp, Wf, bias_or_null, res_or_null, y, stats_out_or_null, B, HW / 32, 32, Cin, Cout, groups_out, mscale);
-  cp.nch = (int)(Cin / 16);
-  gp.x = x; gp.pre_bias = pre_bias_or_null; gp.scales_dev = scales_dev_or_null; gp.scale = scale; gp.cin = (int)Cin;
-  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
-  if (Cout == 128) hipLaunchKernelGGL(conv1x1_f16x3_kernel<128>, grid, dim3(256), 0, st, gp);
-  else if (Cout == 256) hipLaunchKernelGGL(conv1x1_f16x3_kernel<256>, grid, dim3(256), 0, st, gp);
-  else if (Cout == 512) hipLaunchKernelGGL(conv1x1_f16x3_kernel<512>, grid, dim3(256), 0, st, gp);
-  else hipLaunchKernelGGL(conv1x1_f16x3_kernel<1536>, grid, dim3(256), 0, st, gp);
-  return check_launch();
-}
-
-int conv3x3s2_f16x3(const float *x, const void *Wf, const float *scales_dev_or_null, float scale, float mscale,
-                    const float *bias_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t Hin, int64_t Win,
-                    int64_t Cin, int64_t Cout, int64_t groups_out, void *stream) {
-  // output H = Hin / 2, W = Win / 2 (the reference pads one zero row / column at the bottom / right: unet.py:92-95)
-  if (B < 0 || Hin < 2 * kC3TH || Win < 2 * kC3TW || Hin % (2 * kC3TH) || Win % (2 * kC3TW) || Cin < 16 || Cin % 16 != 0 ||
-      (Cout != 128 && Cout != 256 && Cout != 512) || Hin * Win > (1 << 24) || (!scales_dev_or_null && !(scale > 0.f)))
-    return GQHIP_ERR_INVALID_ARG;
-  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
-    return check_launch();
-  Conv3S2Params gp{};
-  Conv3Params &cp = gp.c;
-  conv3_fill(cp, Wf, bias_or_null, nullptr, y, stats_out_or_null, B, Hin / 2, Win / 2, Cin, Cout, groups_out, mscale);
-  gp.x = x; gp.scales_dev = scales_dev_or_null; gp.scale = scale; gp.cin = (int)Cin; gp.Hin = (int)Hin; gp.Win = (int)Win;
-  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
-  if (Cout == 128) hipLaunchKernelGGL(conv3x3s2_f16x3_kernel<128>, grid, dim3(256), 0, st, gp);
-  else if (Cout == 256) hipLaunchKernelGGL(conv3x3s2_f16x3_kernel<256>, grid, dim3(256), 0, st, gp);
-  else hipLaunchKernelGGL(conv3x3s2_f16x3_kernel<512>, grid, dim3(256), 0, st, gp);
-  return check_launch();
-}
-
-int upconv2x_f16x3(const float *x, const void *Wf, const float *scales_dev_or_null, float scale, float mscale,
-                   const float *bias_or_null, float *y, double *stats_out_or_null, int64_t B, int64_t H, int64_t W,
-                   int64_t Cin, int64_t Cout, int64_t groups_out, void *stream) {
-  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 16 || Cin % 16 != 0 ||
-      (Cout != 128 && Cout != 256 && Cout != 512) || H * W > (1 << 22) || (!scales_dev_or_null && !(scale > 0.f)))
-    return GQHIP_ERR_INVALID_ARG;
-  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(double) * 2 * B * groups_out, st) != hipSuccess)
-    return check_launch();
-  Upconv2Params gp{};
-  Conv3Params &cp = gp.c;
-  conv3_fill(cp, Wf, bias_or_null, nullptr, y, stats_out_or_null, B, H, W, Cin, Cout, groups_out, mscale);
-  gp.x = x; gp.scales_dev = scales_dev_or_null; gp.scale = scale; gp.cin = (int)Cin;
-  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb), 4);
-  if (Cout == 128) hipLaunchKernelGGL(upconv2x_f16x3_kernel<128>, grid, dim3(256), 0, st, gp);
-  else if (Cout == 256) hipLaunchKernelGGL(upconv2x_f16x3_kernel<256>, grid, dim3(256), 0, st, gp);
-  else hipLaunchKernelGGL(upconv2x_f16x3_kernel<512>, grid, dim3(256), 0, st, gp);
-  return check_launch();
-}
-
-int conv3x3_gn_small_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
-                         const double *stats_in, int64_t groups_in, double eps, int apply_silu, const float *w_ohwi,
-                         const float *bias_or_null, float *y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
-                         void *stream) {
-  if (B < 0 || H < 16 || W < 16 || H % 16 || W % 16 || Cin < 32 || Cin % 32 != 0 || Cin > 512 || Cout < 1 || Cout > 4 ||
-      groups_in < 1 || Cin % groups_in != 0 || B * (H / 16) * (W / 16) > 0x7fffffffL)
-    return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !gamma || !beta || !stats_in || !w_ohwi || !y) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)(B * (H / 16) * (W / 16)));
-  const int cpg = (int)(Cin / groups_in);
-#define GQ_CS(S, CO)                                                                                                      \
-  hipLaunchKernelGGL((conv3x3_gn_small_kernel<S, CO>), grid, dim3(256), 0, st, x, gamma, beta, pre_bias_or_null, stats_in, \
-                     w_ohwi, bias_or_null, y, (int)H, (int)W, (int)Cin, cpg, eps)
-#define GQ_CS2(CO) do { if (apply_silu) GQ_CS(1, CO); else GQ_CS(0, CO); } while (0)
-  switch (Cout) {
-    case 1: GQ_CS2(1); break;
-    case 2: GQ_CS2(2); break;
-    case 3: GQ_CS2(3); break;
-    default: GQ_CS2(4); break;
-  }
-#undef GQ_CS2
-#undef GQ_CS
-  return check_launch();
-}
-
-int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream) {
-  if (B < 0 || H < 2 || W < 2 || H % 2 || W % 2 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!M || !y) return GQHIP_ERR_INVALID_ARG;
-  const long tiles = (long)(B * (H / 2) * (W / 2)), total = tiles * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(wino_out_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), M, y,
-                     (int)H, (int)W, (int)(C / 4), tiles, total, mscale);
-  return check_launch();
-}
-
-int wino4_in_nhwc_f32(const float *x, float *V, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
-  if (B < 0 || H < 4 || W < 4 || H % 4 || W % 4 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !V) return GQHIP_ERR_INVALID_ARG;
-  const long tiles = (long)(B * (H / 4) * (W / 4)), total = tiles * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(wino4_in_nhwc_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     (void *)V, (int)H, (int)W, (int)(C / 4), tiles, total, 1.0f);
-  return check_launch();
-}
-
-int wino4_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W, int64_t C, float mscale, void *stream) {
-  if (B < 0 || H < 4 || W < 4 || H % 4 || W % 4 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!M || !y) return GQHIP_ERR_INVALID_ARG;
-  const long tiles = (long)(B * (H / 4) * (W / 4)), total = tiles * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(wino4_out_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), M, y,
-                     (int)H, (int)W, (int)(C / 4), tiles, total, mscale);
-  return check_launch();
-}
-
-int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or_null, float *y, double *stats_out,
-                          int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups, int tile, float mscale,
-                          void *stream) {
-  if ((tile != 2 && tile != 4) || B < 0 || H < tile || W < tile || H % tile || W % tile || C < 4 || C % 4 != 0 ||
-      groups < 1 || C % groups != 0)
-    return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!M || !y || !stats_out) return GQHIP_ERR_INVALID_ARG;   // res may be NULL: bias + statistics only
-  const int64_t cpg = C / groups;
-  if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(stats_out, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) return check_launch();
-  const long tpi = (long)((H / tile) * (W / tile)), tiles = (long)B * tpi;
-  // F(4x4,3x3): two channels per thread (see the kernel) wherever a block still spans whole pixels
-  const int vw = (tile == 4 && 256 % (C / 2) == 0) ? 2 : 4;
-  const int lanes = (int)(256 / (C / vw));
-  long slabs = (tpi + (long)lanes * 4 - 1) / ((long)lanes * 4);    // ~4 tiles per thread
-  if (slabs > 1024) slabs = 1024;
-  if (slabs < 1) slabs = 1;
-  const dim3 grid((unsigned)(B * slabs));
-  if (tile == 4 && vw == 2)
-    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<4, 2>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
-                       (int)W, (int)(C / 2), (int)cpg, tiles, (int)slabs, mscale);
-  else if (tile == 4)
-    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<4, 4>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
-                       (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs, mscale);
-  else
-    hipLaunchKernelGGL((wino_out_res_nhwc_kernel<2, 4>), grid, dim3(256), 0, st, M, res, bias_or_null, y, stats_out, (int)H,
-                       (int)W, (int)(C / 4), (int)cpg, tiles, (int)slabs, mscale);
-  return check_launch();
-}
-
-int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !A) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * (H + 1) * (W + 1) * 4 * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(upconv_im2col_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     x, (void *)A, (int)H, (int)W, (int)(C / 4), total, (const float *)nullptr);
-  return check_launch();
-}
-
-int upconv_im2col_nhwc_f16x3(const float *x, void *A3, int64_t B, int64_t H, int64_t W, int64_t C,
-                             const float *scales_dev, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !A3 || !scales_dev) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * (H + 1) * (W + 1) * 4 * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(upconv_im2col_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     x, A3, (int)H, (int)W, (int)(C / 4), total, scales_dev);
-  return check_launch();
-}
-
-int attn_split_qkv_f16x3(const float *qkv, void *Q3, void *K3, void *V3, int64_t B, int64_t L, int64_t C, float sq, float sv,
-                         void *stream) {
-  if (B < 0 || L < 1 || C < 4 || C % 4 != 0 || !(sq > 0.f) || !(sv > 0.f)) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!qkv || !Q3 || !K3 || !V3) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * L * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(attn_split_qkv_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), qkv,
-                     static_cast<_Float16 *>(Q3), static_cast<_Float16 *>(K3), static_cast<_Float16 *>(V3), (long)L,
-                     (int)(C / 4), sq, sv, total);
-  return check_launch();
-}
-
-int attn_softmax_split_f16x3(const float *S, void *P3, int64_t rows, int64_t L, float factor, void *stream) {
-  if (rows < 0 || L < 64 || L % 64 != 0 || L > 4096 || !(factor > 0.f)) return GQHIP_ERR_INVALID_ARG;
-  if (rows == 0) return GQHIP_OK;
-  if (!S || !P3) return GQHIP_ERR_INVALID_ARG;
-  const dim3 grid((unsigned)((rows + 3) / 4));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  _Float16 *p = static_cast<_Float16 *>(P3);
-#define GQ_SM(N) hipLaunchKernelGGL(attn_softmax_split_kernel<N>, grid, dim3(256), 0, st, S, p, (long)rows, factor)
-  switch (L / 64) {
-    case 1: GQ_SM(1); break;
-    case 4: GQ_SM(4); break;
-    case 16: GQ_SM(16); break;
-    case 36: GQ_SM(36); break;
-    case 64: GQ_SM(64); break;
-    default: return GQHIP_ERR_INVALID_ARG;
-  }
-#undef GQ_SM
-  return check_launch();
-}
-
-int f16_scales_from_gn_stats(const double *stats, int64_t n_bg, double amp, double u_scale, float *scales_out,
-                             void *stream) {
-  if (!stats || !scales_out || n_bg < 1 || n_bg > 0x7fffffff || !(amp > 0.0) || !(u_scale > 0.0)) return GQHIP_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(f16_scales_from_stats_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), stats, (int)n_bg,
-                     (float)amp, (float)u_scale, scales_out);
-  return check_launch();
-}
-
-int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C,
-                            const float *mscale_dev_or_null, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!src || !y) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * 2 * H * 2 * W * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(upconv_shuffle_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     src, y, (int)H, (int)W, (int)(C / 4), total, mscale_dev_or_null);
-  return check_launch();
-}
-
-int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !y) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * H * W * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     y, (int)H, (int)W, (int)(C / 4), total);
-  return check_launch();
-}
-
 static int fsq_levels(const int32_t *levels_host, int64_t nlev, FsqLevels *L) {
   if (!levels_host || nlev < 1 || nlev > 16) return GQHIP_ERR_INVALID_ARG;
   L->n = (int)nlev;
@@ -1431,7 +807,23 @@ int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
   if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
   if (fallback_rows_host) *fallback_rows_host = h.fb_count;
   if (reranked_halftiles_host) *reranked_halftiles_host = (int64_t)h.reranked;
-  return h.bar_timeout ? GQHIP_ERR_LAUNCH : GQHIP_OK;   // a tail-kernel grid barrier gave up (never expected)
+  return GQHIP_OK;
+}
+
+int gqhip_debug_barrier(const void *workspace, int64_t *timeouts_host, int64_t *aborted_host) {
+  if (!workspace) return GQHIP_ERR_INVALID_ARG;
+  WsHeader h;
+  if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
+  if (timeouts_host) *timeouts_host = h.bar_timeout;
+  if (aborted_host) *aborted_host = h.bar_abort;
+  return GQHIP_OK;
+}
+
+int gqhip_debug_tail(int grid_mult, int spin_limit) {
+  if (grid_mult < 1 || grid_mult > 64 || spin_limit < 1) return GQHIP_ERR_INVALID_ARG;
+  g_tail_grid_mult.store(grid_mult, std::memory_order_relaxed);
+  g_tail_spin_limit.store(spin_limit, std::memory_order_relaxed);
+  return GQHIP_OK;
 }
 
 }  // extern "C"

@@ -18,7 +18,8 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
 LIB_PATH = os.environ.get("GQHIP_LIB", os.path.join(_CSRC, "libgqhip.so"))  # GQHIP_LIB: diagnostic builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+GNSTAT_WORDS = 8     # int64 words per (image, group) statistics record (gqhip.h: gqhip_gnstat_t)
 GQHIP_LAYOUT = {"bchw": 0, "blc": 1}
 GQHIP_GROUP_STRIDED = 0
 GQHIP_GROUP_CONTIGUOUS = 1
@@ -80,6 +81,8 @@ _SIGNATURES = {
                                         _i64, _vp]),
     "conv3x3_gn_small_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _i64, _i64,
                                              _i64, _i64, _i64, _vp]),
+    "conv3x3_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _i64, _i64, _i64,
+                                   _i64, _i64, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
@@ -100,6 +103,8 @@ _SIGNATURES = {
     "gqhip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "gqhip_debug_enable": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_debug_counters": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "gqhip_debug_barrier": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "gqhip_debug_tail": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -110,7 +115,7 @@ class GqHipError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile libgqhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    args = ["make", "-C", _CSRC, "-s"]
+    args = ["make", "-C", _CSRC, "-s", "-j4"]
     if force:
         args.append("-B")
     subprocess.check_call(args + ["libgqhip.so"])
@@ -367,7 +372,7 @@ def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True, pre_bias
     HW = x.shape[2] * x.shape[3]
     # statistics scratch: a fresh (stream-ordered, caching-allocator) tensor per call -- a process-global buffer would be
     # shared by concurrent streams / models and baked into captured graphs
-    ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+    ws = torch.empty(GNSTAT_WORDS * B * groups, dtype=torch.int64, device=x.device)
     y = torch.empty_like(x)  # preserves the memory format
     with torch.cuda.device(x.device):
         _check(lib().gn_silu_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), y.data_ptr(), B, C, HW,
@@ -396,7 +401,7 @@ def add_bias_stats(a, b, bias, groups: int):
     B, C = a.shape[0], a.shape[1]
     HW = a.shape[2] * a.shape[3]
     y = torch.empty_like(a)
-    stats = torch.empty(2 * B * groups, dtype=torch.float64, device=a.device)
+    stats = torch.empty(GNSTAT_WORDS * B * groups, dtype=torch.int64, device=a.device)
     with torch.cuda.device(a.device):
         _check(lib().add_bias_stats_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, groups,
                                         stats.data_ptr(), _stream()), "add_bias_stats_f32")
@@ -416,12 +421,24 @@ def gn_apply(x, gamma, beta, groups: int, eps: float, silu: bool, stats):
     return y
 
 
+def gn_stats_values(stats):
+    """[2 * n_bg] fp64 (sum, sum of squares per (image, group)) from the fixed-point statistics records the kernels
+    accumulate (gqhip.h: gqhip_gnstat_t; the readers' evaluation order).  For tests and diagnostics."""
+    r = stats.view(-1, GNSTAT_WORDS).double()
+    s = (r[:, 2] * 2.0 ** 24 + r[:, 1] * 2.0 ** -16) + r[:, 0] * 2.0 ** -56
+    ss = (r[:, 5] * 2.0 ** 24 + r[:, 4] * 2.0 ** -16) + r[:, 3] * 2.0 ** -56
+    bad = r[:, 6] != 0
+    s = torch.where(bad, torch.full_like(s, float("nan")), s)
+    ss = torch.where(bad, torch.full_like(ss, float("nan")), ss)
+    return torch.stack([s, ss], 1).flatten()
+
+
 def gn_stats(x, groups: int, pre_bias=None):
     """channels_last only: GroupNorm statistics of x (+ pre_bias[c]) as [2 * B * groups] fp64 (sum, sum of squares)."""
     if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or not gn_nhwc_ok(x.shape[1], groups):
         raise GqHipError("gn_stats needs a dense channels_last fp32 HIP tensor with a GroupNorm-compatible C")
     B, C = x.shape[0], x.shape[1]
-    stats = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+    stats = torch.empty(GNSTAT_WORDS * B * groups, dtype=torch.int64, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().gn_stats_f32(x.data_ptr(), _ptr(pre_bias), B, C, x.shape[2] * x.shape[3], groups, stats.data_ptr(),
                                   _stream()), "gn_stats_f32")
@@ -510,7 +527,7 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
             if (residual is not None and (image_layout(residual) != 1 or tuple(residual.shape) != tuple(y.shape))) \
                     or not gn_nhwc_ok(cout, stats_groups):
                 raise GqHipError("fused Winograd tail needs a channels_last residual of the output shape and a GroupNorm-compatible C")
-            stats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device)
+            stats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device)
             _check(L.wino_out_res_nhwc_f32(M.data_ptr(), _ptr(residual), _ptr(bias), y.data_ptr(), stats.data_ptr(),
                                            B, H, W, cout, stats_groups, t, float(mscale), _stream()), "wino_out_res_nhwc_f32")
             return y, stats
@@ -617,7 +634,7 @@ def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None
     L = lib()
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+        ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
         mscale = 1.0 / (v_scale * u_scale)
         if gn is not None and C <= 512 and C % 32 == 0 and DIRECT_CONV_FUSED_SPLIT:
             gamma, beta, groups, eps, silu, stats, pre_bias = gn
@@ -664,7 +681,7 @@ def conv1x1_direct(x, wf, u_scale: float, scale, residual=None, bias=None, stats
         sdev, mscale = None, float(post_scale) / (v_scale * u_scale)
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+        ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
         _check(lib().conv1x1_f16x3(x.data_ptr(), _ptr(pre_bias), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), _ptr(residual),
                                    y.data_ptr(), _ptr(ostats), B, H * W, C, cout, max(stats_groups, 1), _stream()),
                "conv1x1_f16x3")
@@ -712,7 +729,7 @@ def conv3x3s2_direct(x, wf, u_scale: float, scale, bias=None, stats_groups: int 
         sdev, mscale = None, 1.0 / (v_scale * u_scale)
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+        ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
         _check(lib().conv3x3s2_f16x3(x.data_ptr(), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), y.data_ptr(),
                                      _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1), _stream()), "conv3x3s2_f16x3")
     return (y, ostats) if stats_groups else y
@@ -752,7 +769,7 @@ def upconv2x_direct(x, wf, u_scale: float, scale, bias=None, stats_groups: int =
         sdev, mscale = None, 1.0 / (v_scale * u_scale)
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+        ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
         _check(lib().upconv2x_f16x3(x.data_ptr(), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), y.data_ptr(),
                                     _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1), _stream()), "upconv2x_f16x3")
     return (y, ostats) if stats_groups else y
@@ -776,6 +793,45 @@ def conv3x3_gn_small(x, w_ohwi, bias, gn):
     return y
 
 
+def conv_f32_ok(cin: int, cout: int, H: int, W: int, gn: bool) -> bool:
+    """Shapes conv3x3_f32 tiles (gqhip.h)."""
+    return cout % 4 == 0 and (cin % 64 == 0 and (not gn or cin <= 1024) or (not gn and cin in (8, 16, 32)))
+
+
+def conv_f32_weights(weight):
+    """[Cout, Cin, 3, 3] fp32 -> the operand order of conv3x3_f32: [ceil(Cout/32)][9][Cin/8][64][4], element
+    (t, tap, g, 32 h + j, m) = w[32 t + j][8 g + 4 h + m][tap // 3][tap % 3], zero rows beyond Cout."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cin % 8 or tuple(weight.shape[2:]) != (3, 3):
+        raise GqHipError("conv_f32_weights needs a [Cout, Cin % 8 == 0, 3, 3] weight")
+    nt = (cout + 31) // 32
+    w = weight.detach().float().reshape(cout, cin, 9)
+    if nt * 32 != cout:
+        w = torch.cat([w, w.new_zeros(nt * 32 - cout, cin, 9)], 0)
+    return w.reshape(nt, 32, cin // 8, 2, 4, 9).permute(0, 5, 2, 3, 1, 4).contiguous()
+
+
+def conv3x3_f32(x, wk, cout: int, bias=None, gn=None):
+    """3x3 convolution (stride 1, padding 1) of a channels_last fp32 HIP tensor on the fp32 matrix cores with a fixed summation
+    order (gqhip.h:conv3x3_f32: bit-reproducible).  ``wk`` from conv_f32_weights; ``gn`` = (gamma, beta, groups, eps, silu, stats,
+    pre_bias): the input is act(GroupNorm(x + pre_bias)), applied while the patch is staged."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32:
+        raise GqHipError("conv3x3_f32 needs a dense channels_last fp32 HIP tensor")
+    B, C, H, W = x.shape
+    if not conv_f32_ok(C, cout, H, W, gn is not None) or wk.numel() != ((cout + 31) // 32) * 9 * (C // 8) * 256:
+        raise GqHipError(f"conv3x3_f32: shape {tuple(x.shape)} -> {cout} channels is not tiled by the kernel")
+    y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    gamma = beta = stats = pre_bias = None
+    groups, eps, silu = 1, 0.0, False
+    if gn is not None:
+        gamma, beta, groups, eps, silu, stats, pre_bias = gn
+    with torch.cuda.device(x.device):
+        _check(lib().conv3x3_f32(x.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(pre_bias), _ptr(stats), groups, float(eps),
+                                 1 if silu else 0, wk.data_ptr(), _ptr(bias), y.data_ptr(), B, H, W, C, cout, _stream()),
+               "conv3x3_f32")
+    return y
+
+
 def upconv_im2col(x, scales=None):
     """2x2 patches (padding 1) of a channels_last fp32 HIP tensor [B, C, H, W] as GEMM rows [B*(H+1)*(W+1), 4C];
     ``scales`` (device float[2] from f16_scales): the fp16 x 3 operand [rows, 12C] = [h | h | l] of x * scales[0] instead."""
@@ -796,13 +852,13 @@ def upconv_im2col(x, scales=None):
 
 def f16_scales(stats, amp: float, u_scale: float):
     """Device float[2] = (v_scale, 1 / (v_scale * u_scale)) for an fp16 x 3 GEMM whose activation operand x has the
-    GroupNorm statistics ``stats`` ([2 * n_bg] fp64: sum, sum of squares): v_scale = the largest power of two with
+    GroupNorm statistics ``stats`` (n_bg records of GNSTAT_WORDS int64: gqhip_gnstat_t): v_scale = the largest power of two with
     amp * sqrt(max sum of squares) * v_scale <= 32768.  Computed on the device (no sync)."""
-    if not (stats.is_cuda and stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() % 2 == 0):
-        raise GqHipError("f16_scales needs the fp64 statistics tensor of add_bias_stats / wino_conv3x3")
+    if not (stats.is_cuda and stats.dtype == torch.int64 and stats.is_contiguous() and stats.numel() % GNSTAT_WORDS == 0):
+        raise GqHipError("f16_scales needs the statistics tensor of add_bias_stats / wino_conv3x3")
     out = torch.empty(2, dtype=torch.float32, device=stats.device)
     with torch.cuda.device(stats.device):
-        _check(lib().f16_scales_from_gn_stats(stats.data_ptr(), stats.numel() // 2, float(amp), float(u_scale),
+        _check(lib().f16_scales_from_gn_stats(stats.data_ptr(), stats.numel() // GNSTAT_WORDS, float(amp), float(u_scale),
                                               out.data_ptr(), _stream()), "f16_scales_from_gn_stats")
     return out
 
@@ -916,3 +972,16 @@ def debug_counters(ws: Workspace) -> Tuple[int, int]:
     fb, rr = _i64(0), _i64(0)
     _check(lib().gqhip_debug_counters(ws.buf.data_ptr(), ctypes.byref(fb), ctypes.byref(rr)), "gqhip_debug_counters")
     return fb.value, rr.value
+
+
+def debug_barrier(ws: Workspace) -> Tuple[int, int]:
+    """(blocks of the tail kernel whose grid-barrier wait ran out, 1 if the call finished barrier-free) for the last
+    call on ``ws``."""
+    to, ab = _i64(0), _i64(0)
+    _check(lib().gqhip_debug_barrier(ws.buf.data_ptr(), ctypes.byref(to), ctypes.byref(ab)), "gqhip_debug_barrier")
+    return to.value, ab.value
+
+
+def debug_tail(grid_mult: int = 1, spin_limit: int = 1 << 21) -> None:
+    """Test hook: oversubscribe the tail kernel's grid / shorten its barrier wait (gqhip.h)."""
+    _check(lib().gqhip_debug_tail(int(grid_mult), int(spin_limit)), "gqhip_debug_tail")

@@ -204,6 +204,52 @@ def _norm_act_conv_small(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, p
     return conv(_norm_act(norm, x, pre_bias=pre_bias))
 
 
+def _wkey(*params):
+    return tuple((p.data_ptr(), p._version, p.device) for p in params)
+
+
+def _cached(module: nn.Module, name: str, key, build):
+    """Weight-derived data of ``module`` (operand-order copies, fp16 splits, bounds): one dict per module, entries keyed on
+    the parameters' (data_ptr, _version, device), dropped together by ``invalidate_caches``."""
+    cache = module.__dict__.setdefault("_gq_cache", {})
+    ent = cache.get(name)
+    if ent is None or ent[0] != key:
+        ent = (key, build())
+        cache[name] = ent
+    return ent[1]
+
+
+def _conv_f32_ok(conv: nn.Conv2d, x: torch.Tensor, gn: bool) -> bool:
+    """The narrow ends of the stack (encoder conv_out, decoder conv_in) on libgqhip's fp32 matrix-core convolution: a fixed
+    summation order, hence bit-reproducible -- MIOpen's pick for 512 -> 32 channels is a split-K kernel with atomics."""
+    if not (CONV_F32 and FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.dim() == 4
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and x.is_contiguous(memory_format=torch.channels_last)
+            and not x.is_contiguous()):
+        return False
+    from .. import _lib
+
+    return _lib.conv_f32_ok(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3], gn)
+
+
+def _conv_f32(conv: nn.Conv2d, x: torch.Tensor, gn=None) -> torch.Tensor:
+    from .. import _lib
+
+    wk = _cached(conv, "f32_wk", _wkey(conv.weight), lambda: _lib.conv_f32_weights(conv.weight))
+    return _lib.conv3x3_f32(x, wk, conv.out_channels, bias=conv.bias, gn=gn)
+
+
+def _norm_act_conv_f32(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
+    """conv(swish(norm(x + pre_bias))) for the encoder's conv_out (unet.py:432-436): GroupNorm + swish applied while the
+    patch is staged, fp32 matrix cores, fixed summation order."""
+    if _conv_f32_ok(conv, x, True) and _use_fused(x, norm):
+        from .. import _lib
+
+        if _lib.image_layout(x) == 1:
+            return _conv_f32(conv, x, gn=_gn_tuple(norm, x, pre_bias))
+    return conv(_norm_act(norm, x, pre_bias=pre_bias))
+
+
 def _norm_act_conv(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None, want_stats: bool = False):
     """conv(swish(norm(x + pre_bias))) -> (y, pending_bias).  The GroupNorm(+SiLU) is applied inside the Winograd input
     transform, so the normalised tensor is never written (FUSED_WINO_GN / FUSED_WINO_GN_F4)."""
@@ -303,6 +349,7 @@ def invalidate_caches(module: nn.Module) -> None:
     typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
     .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
     for m in module.modules():
+        m.__dict__.pop("_gq_cache", None)
         for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkb_key", "_qkv_wf_key", "_s2_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_phase_direct_key", "_gb_key"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
@@ -365,6 +412,9 @@ DIRECT_CONV = True
 DIRECT_CONV_S2 = True      # Downsample (pad + 3x3 stride 2) as an fp16 x 3 convolution on the four phase images of x
 DIRECT_CONV_1X1 = True     # 1x1 shortcut / proj_out convolutions as an fp16 x 3 GEMM with the split of x inside the kernel
 FUSED_CONV_OUT = True      # decoder conv_out (128 -> 3) with norm_out + swish fused in: one VALU kernel
+# encoder conv_out (512 -> 2 z, norm_out + swish fused in) and decoder conv_in (z -> 512) on the fp32 matrix cores with a fixed
+# summation order (bit-reproducible; MIOpen's pick for the former combines split-K partial sums with atomics)
+CONV_F32 = True
 DIRECT_CONV_OVER_F4 = False   # ... also where the alternative is F(4x4,3x3) (decoder, 256 channels at 128 x 128): A/B switch
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
 # written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
@@ -794,7 +844,7 @@ class Encoder(nn.Module):
             if lvl != self.num_resolutions - 1:
                 h, pb = level.downsample(h)
         h = self.mid(h, pb)
-        return self.conv_out(_norm_act(self.norm_out, h))
+        return _norm_act_conv_f32(self.norm_out, self.conv_out, h)
 
 
 class Decoder(nn.Module):
@@ -843,7 +893,10 @@ class Decoder(nn.Module):
     def forward(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
         self.last_z_shape = z.shape
         z = _match_layout(z, self.conv_in)
-        h, pb = _conv(self.conv_in, z)
+        if _conv_f32_ok(self.conv_in, z, False):
+            h, pb = _conv_f32(self.conv_in, z), None
+        else:
+            h, pb = _conv(self.conv_in, z)
         h, pb = self.mid(h, pb), None
         for lvl in reversed(range(self.num_resolutions)):
             h, pb = self.up[lvl].run(h, pb), None
