@@ -225,13 +225,30 @@ def pmc_traffic(kernel):
     return None, None
 
 
+# End-to-end parity gates (GPU encoder -> GPU quantiser -> GPU decoder against the reference's CPU path on the same input).
+# ONE definition: tests/test_gpu_modules.py, tests/test_gpu_round2.py and tests/test_gpu_round3.py gate on these numbers,
+# bench.py prints them beside what it measured, BASELINE.md / DESIGN.md quote them.
+GATES = {
+    "z_enc_max_abs": 5e-5,               # |z_gpu - z_cpu| at 256^2 (measured 3-5e-6)
+    "z_enc_max_abs_512": 2e-4,           # ... at 512^2
+    "indices_differing_per_1024": 2,     # end to end, and only where the reference's own top-2 gap is below `near_tie_gap`
+    "near_tie_gap": 1e-3,
+    "same_z_gap": 1e-4,                  # reference z through the GPU quantiser: equal, or gap below the libm difference of exp / log
+    "recon_max_abs_if_indices_equal": 5e-3,     # (goldens store x_rec in fp16: ulp 4.9e-4 at |x| ~ 1)
+    "recon_psnr_db_if_indices_equal": 60.0,
+    "recon_psnr_db": 40.0,               # when an allowed near-tie index differs, one 8 x 8 patch of the image changes
+}
+
+
 # ----------------------------------------------------------------------------- CPU baseline + in-run parity
 def cpu_baseline_and_parity(vae, x, cfg, channels_last):
     """Rank 0, N = 1, after the timed region.  ONE image (x[:1]) through the CPU path, timed on the host cores:
     torch-CPU encoder -> quantiser -> torch-CPU decoder with this model's weights.  The quantiser runs twice:
     leg "torch-restatement" = the reference's own backend="torch" arithmetic (oracle/gq_torch_ref.py,
     gaussian.py:136-150) and leg "c-oracle" = oracle/gq_oracle.c (OpenMP).  The same image then goes through the GPU
-    path and the two are compared (north_star: indices bit-identical, reconstruction within a stated tolerance)."""
+    path and the two are compared (north_star: indices bit-identical, reconstruction within a stated tolerance).
+    The quantiser alone is then checked on EVERY row of the step: the GPU encoder's z of the whole batch through the C oracle
+    (the checker, ~0.07 s per image) against the GPU quantiser's indices and zhat on that same z."""
     import numpy as np
 
     from oracle import gq_oracle as O
@@ -289,24 +306,54 @@ def cpu_baseline_and_parity(vae, x, cfg, channels_last):
         rec_gpu = vae.decode(zhat_g)
         # the GPU quantiser on the CPU encoder's z: the bit-exact gate (no conv rounding in between)
         zhat_s, info_s = vae.regularization(z_cpu.to(dev))
+        # every row of the step: the GPU encoder's z of the WHOLE batch, GPU quantiser vs the C oracle on that same z
+        z_all = vae.encoder(x)
+        zhat_all, info_all = vae.regularization(z_all)
     torch.cuda.synchronize()
+    z_all_c = z_all.float().to("cpu", memory_format=torch.contiguous_format)
+    t5 = time.perf_counter()
+    zhat_o, ind_o = O.gq1_forward(z_all_c.numpy(), cb.numpy(), dim, threads=cores)
+    t6 = time.perf_counter()
+    ind_all = info_all["indices"].cpu().numpy()
+    zhat_all_c = zhat_all.float().to("cpu", memory_format=torch.contiguous_format).numpy()
     ind_g = info_g["indices"].cpu()
     ind_s = info_s["indices"].cpu()
     rec_g = rec_gpu.float().cpu().contiguous()
     mse = float(((rec_g - rec_cpu) ** 2).mean())
+    n_diff = int((ind_g != ind_t).sum())
+    psnr = round(10.0 * float(np.log10(4.0 / max(mse, 1e-30))), 2)
+    max_abs = float((rec_g - rec_cpu).abs().max())
+    dz = float((z_gpu.float().cpu() - z_cpu).abs().max())
+    size = int(x.shape[-1])
+    gate_dz = GATES["z_enc_max_abs"] if size <= 256 else GATES["z_enc_max_abs_512"]
+    ok = (dz <= gate_dz and n_diff <= GATES["indices_differing_per_1024"] * max(1, ind_t.numel() // 1024)
+          and psnr >= (GATES["recon_psnr_db_if_indices_equal"] if n_diff == 0 else GATES["recon_psnr_db"])
+          and (n_diff > 0 or max_abs <= GATES["recon_max_abs_if_indices_equal"]))
     parity = {
-        "sample": "image 0 of the batch, GPU path vs the CPU path timed above (same weights, same input)",
+        "sample": "image 0 of the batch, GPU path vs the CPU path timed above (same weights, same input); quantiser_all_rows: "
+                  "the whole batch",
         "quantiser_same_z": {"indices_equal_frac": float((ind_s == ind_t).float().mean()),
                              "zhat_bit_equal": bool(torch.equal(zhat_s.cpu(), zhat_t)),
                              "note": "GPU quantiser fed the CPU encoder's z: must be 1.0 / true (bit-exact contract)"},
+        "quantiser_all_rows": {"rows": int(ind_o.size), "images": int(x.shape[0]),
+                               "indices_equal_frac": float((ind_all == ind_o).mean()),
+                               "indices_differing": int((ind_all != ind_o).sum()),
+                               "zhat_bit_equal": bool(np.array_equal(zhat_all_c, zhat_o)),
+                               "oracle_s": round(t6 - t5, 3),
+                               "note": "every row of the step: the GPU encoder's z of the whole batch, GPU quantiser vs the C oracle "
+                                       "(oracle/gq_oracle.c) on that same z: must be 1.0 / 0 / true"},
         "indices_equal_frac": float((ind_g == ind_t).float().mean()),
-        "indices_differing": int((ind_g != ind_t).sum()),
-        "z_enc_max_abs_err": float((z_gpu.float().cpu() - z_cpu).abs().max()),
-        "recon_max_abs_err": float((rec_g - rec_cpu).abs().max()),
-        "recon_psnr_db": round(10.0 * float(np.log10(4.0 / max(mse, 1e-30))), 2),
-        "tolerance": "end to end the GPU encoder's fp32 rounding differs from the CPU's (|dz| ~ 4e-6), so an index may "
-                     "differ only at a near-tie of the reference's own score; reconstruction: max-abs <= 5e-2, PSNR >= 40 dB "
-                     "(tests/test_gpu_modules.py::test_engine_end_to_end_full_config)",
+        "indices_differing": n_diff,
+        "z_enc_max_abs_err": dz,
+        "recon_max_abs_err": max_abs,
+        "recon_psnr_db": psnr,
+        "gates": dict(GATES), "within_gates": bool(ok),
+        "tolerance": f"end to end the GPU encoder's fp32 rounding differs from the CPU's (|dz| <= {gate_dz:g}), so an index may "
+                     f"differ only at a near-tie of the reference's own score (<= {GATES['indices_differing_per_1024']} per 1024 rows, "
+                     f"top-2 gap < {GATES['near_tie_gap']:g}); reconstruction with all indices equal: max-abs <= "
+                     f"{GATES['recon_max_abs_if_indices_equal']:g}, PSNR >= {GATES['recon_psnr_db_if_indices_equal']:g} dB; with an "
+                     f"allowed near-tie difference: PSNR >= {GATES['recon_psnr_db']:g} dB (bench.GATES; the -m gpu tests "
+                     "test_engine_end_to_end_full_config, test_g14_*, test_gq_512_* gate on the same numbers)",
     }
     return baseline, parity
 
@@ -498,9 +545,11 @@ def main():
                 traffic, prov = pmc_traffic(kname)
                 # executed work per algorithmic fp32 MAC, in bf16-rate MACs: split-bf16 = 3 bf16 MACs (A_h s_h + A_h s_l +
                 # A_l s_h); fp16 + fp8 = 1 fp16 MAC + 2 fp8 MACs on the block-scaled instruction (twice the bf16 rate) = 2
-                ex = 3 if kind == 1 else 2
-                what = ("split-bf16 MFMA filter" if kind == 1 else
-                        "fp16 + fp8 MFMA filter: v_mfma_f32_32x32x16_f16 main product + v_mfma_scale_f32_32x32x64_f8f6f4 corrections")
+                ex = {1: 3, 2: 2, 3: 1}[kind]
+                what = {1: "split-bf16 MFMA filter",
+                        2: "fp16 + fp8 MFMA filter: v_mfma_f32_32x32x16_f16 main product + v_mfma_scale_f32_32x32x64_f8f6f4 corrections",
+                        3: "fp16 main-product MFMA filter: v_mfma_f32_32x32x16_f16, no correction terms; the re-rank's data-dependent "
+                           "bound covers the fp16 rounding"}[kind]
                 roofline = {"kernel": f"{kname} ({what} of the fused quantiser; plan {plan})",
                             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
@@ -508,8 +557,8 @@ def main():
                             "vs_fp32_mfma_peak": round(achieved / PEAK_F32_TFLOPS, 3),
                             "note": "achieved = algorithmic fp32-equivalent flops (SURVEY 8d: 4*dim*N per row; VQ 2*dim*N) / "
                                     "launch time against the dense bf16/fp16 MFMA peak; executed = the MFMA work the kernel issues per "
-                                    "algorithmic MAC in bf16-rate MACs (split-bf16: three bf16 products of two-term splits; fp16 + fp8: "
-                                    "one fp16 product + two fp8 correction products at twice the rate = 2) -- the exact re-rank keeps "
+                                    "algorithmic MAC in bf16-rate MACs (fp16 main product: 1; split-bf16: three bf16 products of two-term splits; "
+                                    "fp16 + fp8: one fp16 product + two fp8 correction products at twice the rate = 2) -- the exact re-rank keeps "
                                     "the indices bit-identical either way",
                             "traffic": traffic, "traffic_source": prov,
                             "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate rocprofv3 --pmc passes of "
@@ -546,7 +595,7 @@ def main():
                         "note": "whole quantiser stage (module glue + one launch) by torch events; launch-latency bound at this size",
                         "algorithmic_bytes_per_launch": nbytes}
         line = {
-            "metric": "images/sec encode+quantize+decode, 256x256, codebook 2^16",
+            "metric": f"images/sec encode+quantize+decode, {args.size}x{args.size}, codebook 2^16",
             "value": round(args.batch * world * args.steps / elapsed, 3),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -64,16 +64,18 @@ const char *gqhip_status_string(int status);
 /* last hipError_t observed by a failing call on this thread (0 if none). */
 int gqhip_last_hip_error(void);
 
-/* Filter kernel of the fused arg-max (gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32).  AUTO: at dim 16 with the
- * Gaussian score the fp16 + fp8 MFMA filter (one fp16 product + block-scaled fp8 corrections per fp32 product), at the other
- * MFMA dims (4/8/32) and for VQ the split-bf16 filter (three bf16 products per fp32 product); rows a filter cannot decide
- * cascade through the fp32 MFMA filter, then an fp64 stage.  FP32: always the fp32 MFMA filter.  BF16: the split-bf16
- * filter wherever it applies (no fp16 + fp8).  All feed the same exact re-rank: the indices are identical.
- * Process-wide; initial value from the environment (GQHIP_FILTER=fp32|bf16).  The workspace size depends on it:
+/* Filter kernel of the fused arg-max (gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32).  AUTO: the fp16 main-product
+ * filter (ONE fp16 MFMA product per fp32 product, no correction terms; its rounding error is covered by a bound the re-rank
+ * derives from the row's own data) at every MFMA dim (4/8/16/32), Gaussian score and VQ; rows a filter cannot decide cascade
+ * through the fp32 MFMA filter, then an fp64 stage.  FP32: always the fp32 MFMA filter.  BF16: the split-bf16 filter (three
+ * bf16 products per fp32 product).  MIXED: round 2's fp16 + fp8 filter (one fp16 product + block-scaled fp8 corrections) at
+ * dim 16 with the Gaussian score, split-bf16 elsewhere.  All feed the same exact re-rank: the indices are identical.
+ * Process-wide; initial value from the environment (GQHIP_FILTER=fp32|bf16|mixed).  The workspace size depends on it:
  * query gqhip_workspace_bytes after changing it.  (No reference counterpart.) */
 #define GQHIP_FILTER_AUTO 0
 #define GQHIP_FILTER_FP32 1
 #define GQHIP_FILTER_BF16 2
+#define GQHIP_FILTER_MIXED 3
 int gqhip_set_filter(int kind);
 int gqhip_get_filter(void);
 
@@ -191,6 +193,12 @@ int add_bias_stats_f32(const float *a, const float *b, const float *bias_or_null
 /* NHWC only.  The apply pass of gn_silu_f32 with statistics computed earlier (by add_bias_stats_f32). */
 int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y, int64_t B, int64_t C,
                  int64_t HW, int64_t groups, double eps, int apply_silu, const gqhip_gnstat_t *stats, void *stream);
+
+/* Content checksums of `count` device tensors in ONE launch: table_dev = count entries {const void *ptr; int64_t words}
+ * (32-bit words; 16-byte aligned pointers), sums_dev[t] = a 64-bit position-salted hash sum of tensor t (zeroed here; integer
+ * atomics: independent of the order of the adds).  The conv-stack modules use it to notice parameter writes that bump no
+ * version counter (`param.data`): their weight-derived caches are rebuilt when a sum differs (pit_hip/modules/unet.py). */
+int gqhip_checksum_tensors(const void *table_dev, int64_t count, uint64_t *sums_dev, void *stream);
 
 /* 3x3 convolution, stride 1, zero padding 1, NHWC fp32, on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: an exact fp32 FMA
  * chain) with a FIXED summation order, so the result is bit-identical from run to run -- for the narrow ends of the conv

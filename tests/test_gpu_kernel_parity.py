@@ -11,9 +11,10 @@ from oracle import gq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "bf16", "fp32"])
+@pytest.fixture(autouse=True, params=["auto", "bf16", "fp32", "mixed"])
 def filter_kind(request):
-    """Every test of this module runs with all three filter selections ("auto": fp16 + fp8 at dim 16, split-bf16 at the other
+    """Every test of this module runs with all four filter selections ("auto": the fp16 main-product filter + data-dependent bound;
+    "mixed": round 2's fp16 + fp8 at dim 16, split-bf16 at the other
     MFMA dims; "bf16": split-bf16 everywhere; "fp32": the fp32 MFMA filter); same indices."""
     from pit_hip import _lib
 
@@ -235,7 +236,7 @@ def test_filter_value_error_within_the_bound_the_rerank_assumes(dim, rows, n, fi
     _lib.gq_argmax(mu.to(dev), sd.to(dev), torch.from_numpy(cb).to(dev), 1.0, ws=ws)
     torch.cuda.synchronize()
     pl = _lib.debug_plan(rows, n, dim)
-    assert pl["bf16"] == {"auto": 2 if dim == 16 else 1, "bf16": 1, "fp32": 0}[filter_kind]
+    assert pl["bf16"] == {"auto": 3 if dim != 4 else 1, "mixed": 2 if dim == 16 else 1, "bf16": 1, "fp32": 0}[filter_kind]
     m, ids = _lib.debug_records(ws, rows, n, dim)
     m1 = m[..., 0].cpu().numpy().astype(np.float64)            # [nsplit, rows]
     id1 = ids[..., 0].cpu().numpy()
@@ -247,8 +248,19 @@ def test_filter_value_error_within_the_bound_the_rerank_assumes(dim, rows, n, fi
     T = ((0.5 + 0.5 * inv) * N1 * N1 + np.abs(mu64) * inv * N1).sum(axis=1)   # the bound's T (gq_rerank.h)
     gt = pl["gt"]
     r = np.arange(16 * gt)
-    worst = 0.0
+    worst = worst_dd = 0.0
     sel = np.arange(0, rows, 7)
+    # the data-dependent bound of the fp16 main-product filter (gq_rerank.h:f16_bound), evaluated with the TRUE f of the code:
+    # E(j) <= k u min(T_old, T_norm, Cr - 3 f(j)) + E_abs
+    a_, b_ = np.abs(A), np.abs(B)
+    well = (A < 0) & (b_ <= 12.0 * a_)
+    Mw = np.where(well, B * B / np.maximum(4.0 * a_, 1e-300), 0.0).sum(1)
+    Uwc = np.where(~well, np.maximum(A, 0) * N1 * N1 + b_ * N1, 0.0).sum(1)
+    Twc = np.where(~well, a_ * N1 * N1 + b_ * N1, 0.0).sum(1)
+    Cr = 8 * Mw + 3 * Uwc + Twc
+    R2 = (cb64 ** 2).sum(1).max()
+    Tn = a_.max(1) * R2 + np.sqrt((B * B).sum(1) * R2)
+    Eabs = 2 * dim * (2.0 ** -25 * max(N1 * N1, N1) + 2.0 ** -11) * np.maximum(a_.max(1), b_.max(1)) * 2.0 ** -13
     for s in range(pl["nsplit"]):
         gid = id1[s, sel]
         tile = (gid >> 1)[:, None] * gt + (r >> 4)[None, :]
@@ -259,5 +271,12 @@ def test_filter_value_error_within_the_bound_the_rerank_assumes(dim, rows, n, fi
         f = np.where(ok, f, -np.inf).max(axis=1)
         err = np.abs(m1[s, sel] - f) / (2.0 ** -24 * T[sel])
         worst = max(worst, float(err.max()))
+        if pl["bf16"] == 3:
+            Tdd = np.minimum(np.minimum(T[sel], Tn[sel]), np.maximum(Cr[sel] - 3.0 * f, 0.0))
+            bound = pl["ef_coeff"] * 2.0 ** -24 * Tdd + Eabs[sel]
+            worst_dd = max(worst_dd, float((np.abs(m1[s, sel] - f) / bound).max()))
     print(f"filter={filter_kind} dim={dim}: max |f_filter - f| = {worst:.1f} x 2^-24 T (bound coefficient {pl['ef_coeff']})")
     assert worst <= pl["ef_coeff"] / 4.0
+    if pl["bf16"] == 3:
+        print(f"   ... and against the data-dependent bound of the group's best code: {worst_dd:.3f} of it")
+        assert worst_dd <= 0.5

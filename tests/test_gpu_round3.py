@@ -165,20 +165,77 @@ def test_g14_eight_images_end_to_end_vs_reference_golden(channels_last):
         z_enc = vae.encode(x, unregularized=True)[0]
         z, ind = vae.quant(x)
         rec = vae.dequant(ind)
+    from bench import GATES     # the ONE definition of the end-to-end gates
+
     dz = float((z_enc.cpu() - torch.from_numpy(d["z_enc"])).abs().max())
-    assert dz <= 5e-5, dz
+    assert dz <= GATES["z_enc_max_abs"], dz
     got, want, gap = _rows(ind.cpu().numpy()), _rows(d["indices"]), d["gap"]
     diff = got != want
     per_image = diff.reshape(8, 1024).sum(1)
     print(f"g14 e2e 8 x 256^2 (channels_last={channels_last}): |dz| {dz:.2e}, {int(diff.sum())} of 8192 indices differ"
           f"{' at gaps ' + str(gap[diff]) if diff.any() else ''}; rows with gap < 1e-3 in the golden: {int((gap < 1e-3).sum())}")
-    assert per_image.max() <= 2 and np.all(gap[diff] < 1e-3), (per_image, gap[diff])
+    assert per_image.max() <= GATES["indices_differing_per_1024"] and np.all(gap[diff] < GATES["near_tie_gap"]), (per_image, gap[diff])
     ref = torch.from_numpy(d["x_rec"].astype(np.float32))
     same = ~diff.reshape(8, 1024).any(1)
     if same.any():    # images whose tokens all agree: the reconstruction is the reference's up to conv rounding (golden is fp16)
-        assert float((rec.cpu()[same] - ref[same]).abs().max()) <= 5e-3
+        assert float((rec.cpu()[same] - ref[same]).abs().max()) <= GATES["recon_max_abs_if_indices_equal"]
     mse = float(((rec.cpu() - ref) ** 2).mean())
-    assert 10 * np.log10(4.0 / max(mse, 1e-20)) >= 60.0
+    assert 10 * np.log10(4.0 / max(mse, 1e-20)) >= (GATES["recon_psnr_db"] if diff.any() else GATES["recon_psnr_db_if_indices_equal"])
     zhat, info = vae.regularization(torch.from_numpy(d["z_enc"]).to(DEV))
     diff2 = _rows(info["indices"].cpu().numpy()) != want
-    assert diff2.sum() == 0 or np.all(gap[diff2] < 1e-4), (diff2.sum(), gap[diff2])
+    assert diff2.sum() == 0 or np.all(gap[diff2] < GATES["same_z_gap"]), (diff2.sum(), gap[diff2])
+
+
+# ------------------------------------------------------------------------------------------ self-invalidating weight caches
+@pytest.mark.parametrize("which", ["decoder", "encoder"])
+def test_weight_caches_notice_data_writes_without_any_call(which):
+    """VERDICT r2 next #6 / ADVICE: `conv.weight.data.mul_()` bumps no version counter, and nobody calls
+    `invalidate_caches()` here.  The forward's content-hash guard (unet._WeightGuard, gqhip_checksum_tensors) must notice
+    the new bytes -- conv weights, GroupNorm gamma / beta (the fp16 operand bounds depend on them), biases -- rebuild every
+    weight-derived cache and return the answer of the NEW weights: compared with the direct NCHW path (no caches).  A
+    third forward with unchanged weights is bit-identical to the second (no spurious rebuild changes anything)."""
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(3)
+    if which == "decoder":
+        mod = U.Decoder(**FULL).eval().to(DEV).to(memory_format=torch.channels_last)
+        x = torch.randn(2, 16, 32, 32, device=DEV)
+    else:
+        mod = U.Encoder(**FULL).eval().to(DEV).to(memory_format=torch.channels_last)
+        x = (torch.rand(2, 3, 256, 256, device=DEV) * 2 - 1)
+    assert U.WEIGHT_GUARD
+    with torch.no_grad():
+        y0 = mod(x).float().contiguous()
+        for p in mod.parameters():                      # an "EMA swap": every parameter rewritten through .data
+            p.data.mul_(1.0 + 0.2 * torch.rand_like(p))
+        y1 = mod(x).float().contiguous()                # NO invalidate_caches()
+        y2 = mod(x).float().contiguous()
+        mod.conv_in.weight.data[0, 0, 0, 0] += 0.5     # ... and a single element of a single tensor
+        y3 = mod(x).float().contiguous()
+        ref3 = mod.to(memory_format=torch.contiguous_format)(x).float().contiguous()   # direct convolutions, nothing cached
+    assert float((y1 - y0).abs().max()) > 1e-3          # the weights did change the output
+    assert torch.equal(y1, y2)
+    assert float((y3 - y2).abs().max()) > 1e-4
+    scale = max(float(ref3.abs().max()), 1.0)
+    assert float((y3 - ref3).abs().max()) <= 2e-4 * scale, (float((y3 - ref3).abs().max()), scale)
+
+
+def test_checksum_tensors_sees_every_word():
+    from pit_hip import _lib
+
+    g = torch.Generator().manual_seed(1)
+    ts = [torch.randn(n, generator=g).to(DEV) for n in (1, 3, 4, 5, 1024, 100003, 2359296)]
+    table = _lib.checksum_table(ts)
+    out = torch.empty(len(ts), dtype=torch.int64, device=DEV)
+    base = _lib.checksum_tensors(table, out).clone()
+    assert torch.equal(_lib.checksum_tensors(table, out), base)          # deterministic
+    for k, t in enumerate(ts):
+        for pos in {0, t.numel() // 2, t.numel() - 1}:
+            old = t[pos].clone()
+            t[pos] = old + 1.0
+            cur = _lib.checksum_tensors(table, out).clone()
+            assert cur[k] != base[k] and all(cur[j] == base[j] for j in range(len(ts)) if j != k), (k, pos)
+            t[pos] = old
+    a, b = ts[4][10].clone(), ts[4][11].clone()                            # a swap of two elements is seen too (position salt)
+    ts[4][10], ts[4][11] = b, a
+    assert _lib.checksum_tensors(table, out)[4] != base[4]

@@ -12,9 +12,10 @@ from oracle import gq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "bf16", "fp32"])
+@pytest.fixture(autouse=True, params=["auto", "bf16", "fp32", "mixed"])
 def filter_kind(request):
-    """Every test of this module runs with all three filter selections ("auto": fp16 + fp8 at dim 16, split-bf16 at the other
+    """Every test of this module runs with all four filter selections ("auto": the fp16 main-product filter + data-dependent bound;
+    "mixed": round 2's fp16 + fp8 at dim 16, split-bf16 at the other
     MFMA dims; "bf16": split-bf16 everywhere; "fp32": the fp32 MFMA filter); same indices."""
     from pit_hip import _lib
 

@@ -361,7 +361,7 @@ def test_operand_order_weight_layouts_and_gemm_policy():
     # the step's Winograd GEMM shapes (positions, tiles, Cout, Cin): only the 32 x 32 levels' 36 x 1024-tile GEMMs stay on the library
     assert _lib.own_gemm_fits(36, 16384, 256, 256) and _lib.own_gemm_fits(36, 4096, 512, 512) and _lib.own_gemm_fits(16, 4096, 512, 512)
     assert _lib.own_gemm_fits(16, 16384, 512, 256) and not _lib.own_gemm_fits(36, 1024, 512, 512) and not _lib.own_gemm_fits(16, 256, 512, 512)
-    assert set(_lib.FILTER_KINDS) == {"auto", "fp32", "bf16"}
+    assert set(_lib.FILTER_KINDS) == {"auto", "fp32", "bf16", "mixed"}
 
 
 def test_fp16_fp8_filter_representation_error_is_inside_the_charged_bound():

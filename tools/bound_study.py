@@ -92,10 +92,14 @@ def study(name, mu, sd, cb, beta=1.0):
         margin = 2.5 * (Ef + Er)
         within = gmax >= (fmax - margin)[:, None]
         cand = within.sum(1)
-        sets = within.reshape(rows, -1, 32).sum(2)          # record sets of 2048 codes = 32 groups
-        listed = (sets >= 4).any(1)
+        listed = np.zeros(rows, bool)
+        ls = []
+        for per in (32, 64, 128):                            # record sets of 2048 / 4096 / 8192 codes
+            sets = within.reshape(rows, -1, per).sum(2)
+            ls.append(int((sets >= 4).any(1).sum()))
+        listed = (within.reshape(rows, -1, 64).sum(2) >= 4).any(1)
         print(f"   {label:58s} margin/old {np.median(margin) / np.median(2.5 * (2450 * U * T_old + Er)):6.2f}   candidates/row {cand.mean():6.3f}   "
-              f"p99 {np.percentile(cand, 99):5.0f}   undecided rows {listed.sum():5d} ({listed.mean() * 100:.3f} %)")
+              f"p99 {np.percentile(cand, 99):5.0f}   undecided rows (sets of 32/64/128 groups) {ls}")
         out[label] = (cand.mean(), listed.mean())
 
     report("today: fp16 + fp8, 2450 u T_old", 2450 * U * T_old)

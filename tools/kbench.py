@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--filter", default=None, choices=["auto", "fp32", "bf16"], help="filter kernel (default: library default)")
+    ap.add_argument("--vq", action="store_true", help="time vq_argmin (A = -1, B = 2 z) instead of the Gaussian score")
+    ap.add_argument("--filter", default=None, choices=["auto", "fp32", "bf16", "mixed"], help="filter kernel (default: library default)")
     a = ap.parse_args()
     if a.filter:
         _lib.set_filter(a.filter)
@@ -29,6 +30,9 @@ def main():
     sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(a.rows, a.dim, generator=g))).to(dev)
     cb = torch.randn(a.n, a.dim, generator=g).clamp(-4.6, 4.6).to(dev)
     ws = _lib.Workspace()
+    if a.vq:
+        real = _lib.gq_argmax
+        _lib.gq_argmax = lambda mu_, sd_, cb_, beta_, ws=None: _lib.vq_argmin(mu_, cb_, ws=ws)
     for _ in range(5):
         _lib.gq_argmax(mu, sd, cb, 1.0, ws=ws)
     torch.cuda.synchronize()
@@ -50,10 +54,10 @@ def main():
     kind = _lib.debug_plan(a.rows, a.n, a.dim)["bf16"]     # 0 fp32 MFMA, 1 split-bf16, 2 fp16 + fp8
     bf16 = kind >= 1
     tf = flops / kms / 1e9
-    ex = 3 if kind == 1 else 2       # bf16-rate MACs executed per algorithmic MAC (fp16 + fp8: 1 fp16 + 2 fp8 at twice the rate)
+    ex = {1: 3, 2: 2, 3: 1}.get(kind, 1)   # bf16-rate MACs executed per algorithmic MAC (fp16 + fp8: 1 fp16 + 2 fp8 at twice the rate)
     rate = (f"{tf:.1f} algorithmic TFLOP/s = {tf/157.3:.2f}x the fp32 MFMA peak; executed {ex}x = {ex*tf:.0f} TFLOP/s bf16-equivalent "
             f"({ex*tf/2500*100:.1f}% of 2500)") if bf16 else f"{tf:.1f} TFLOP/s ({tf/157.3*100:.1f}% of 157.3)"
-    print(f"rows={a.rows} dim={a.dim} n={a.n}: {('fp32', 'split-bf16', 'fp16+fp8')[kind]} filter kernel {kms*1e3:.1f} us avg over "
+    print(f"rows={a.rows} dim={a.dim} n={a.n}: {('fp32', 'split-bf16', 'fp16+fp8', 'fp16 main product')[kind]} filter kernel {kms*1e3:.1f} us avg over "
           f"{launches} launches -> {rate}; "
           f"whole call wall {wall*1e6:.1f} us; fallback rows {fb}, re-ranked half-tiles/row {rr/a.rows:.3f}")
 

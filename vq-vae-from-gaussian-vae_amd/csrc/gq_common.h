@@ -28,7 +28,7 @@ struct __attribute__((aligned(32))) Rec {
   int pad;
 };
 
-// Workspace header (first 2 KiB of the caller's workspace).  Everything in it is (re)written by the kernels of ONE
+// Workspace header (first 4 KiB of the caller's workspace).  Everything in it is (re)written by the kernels of ONE
 // call: gq_prep_kernel resets the counters and writes the max|cb| partials, the level-1 re-rank reduces them to
 // `absmax` for the tail kernel.  Nothing here is read across calls.
 constexpr int kAbsmaxParts = 256;
@@ -41,12 +41,15 @@ struct WsHeader {
   int bar_timeout;                    // blocks whose barrier spin ran out (gqhip_debug_counters reports it)
   int bar_abort;                      // set by the first such block: nobody waits at a barrier any more, every block
                                       // finishes list A through the barrier-free exhaustive path (gq_tail.h)
-  int pad1[23];
+  float r2;                           // max_j |cb_j|^2 (fp32, as summed by gq_prep_kernel), reduced from r2_part likewise
+  int pad1[22];
   float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
   int pad2[128];
+  float r2_part[kAbsmaxParts];        // max squared code norm per code block (fp16 filter's norm bound, gq_rerank.h)
+  int pad3[256];
 };
-static_assert(sizeof(WsHeader) == 2048, "header is 2 KiB");
+static_assert(sizeof(WsHeader) == 4096, "header is 4 KiB");
 
 // Insert (t, id) into a descending top-4 (ids kept for the top 3 only).
 __device__ __forceinline__ void top4_insert(float t, int id, float &m1, float &m2, float &m3, float &m4,

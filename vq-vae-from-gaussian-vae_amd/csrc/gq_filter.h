@@ -92,6 +92,20 @@ __device__ __forceinline__ float max_chain(float t0, const f32x16 &d) {
   return __builtin_fmaxf(__builtin_fmaxf(t, d[14]), d[15]);
 }
 
+// The same maximum as a tree: 8 v_max3 in 3 dependent levels instead of 8 (max is exact and associative, so the value
+// is the same; a lane's 8-deep dependent chain was ~60 cycles of latency per tile once the MFMA work per tile shrank to
+// one or two instructions).
+__device__ __forceinline__ float max_tree(float t0, const f32x16 &d) {
+  const float a = __builtin_fmaxf(__builtin_fmaxf(d[0], d[1]), d[2]);
+  const float b = __builtin_fmaxf(__builtin_fmaxf(d[3], d[4]), d[5]);
+  const float c = __builtin_fmaxf(__builtin_fmaxf(d[6], d[7]), d[8]);
+  const float e = __builtin_fmaxf(__builtin_fmaxf(d[9], d[10]), d[11]);
+  const float f = __builtin_fmaxf(__builtin_fmaxf(d[12], d[13]), d[14]);
+  const float g = __builtin_fmaxf(__builtin_fmaxf(a, b), c);
+  const float h = __builtin_fmaxf(__builtin_fmaxf(e, f), d[15]);
+  return __builtin_fmaxf(__builtin_fmaxf(g, h), t0);
+}
+
 // MFMA k-steps [S0, S1) of one 32-code tile against the wave's RT row tiles
 // (k-step s < HD multiplies the squares by A, s >= HD the values by B).  The RT
 // chains alternate in program order (A1 B1 A2 B2 ...) so a chain's next MFMA is

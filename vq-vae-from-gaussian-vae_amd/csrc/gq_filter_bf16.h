@@ -141,20 +141,45 @@ __device__ __forceinline__ void tile_mfma_mixed(const u32x4 (&cv)[4], const u32x
   }
 }
 
+// ---- F16 (round 3): the main product alone.  A s ~ A_h s_h on v_mfma_f32_32x32x16_f16, NO correction terms: the value is
+// off by the two fp16 roundings, (2^-10 + 2^-22) |A s| per product -- 8x the fp16 + fp8 form's representation error -- and
+// the re-rank pays for it with a bound that follows the DATA instead of the worst case (gq_rerank.h:f16_bound: the error of
+// a high-scoring code is bounded through its own score, and through the codebook's largest norm), which more than makes up
+// the difference: 1.24 candidates per row at config 2 against 1.40 behind the fp16 + fp8 filter (tools/bound_study.py).
+// MFMA passes per tile and row tile: dim 16: 16 (32 / 48 before), dim 32: 32 (96), dims 8 and 4: 8 (24 / 16).  One operand
+// vector per MFMA and lane: half the LDS reads and half the image of the fp16 + fp8 form.  Applies to VQ as well (A = -1,
+// B = 2 z): nothing in it depends on the sign structure of the Gaussian score.
+template <int NCV, int RT, int S0, int S1>
+__device__ __forceinline__ void tile_mfma_f16(const u32x4 (&cv)[NCV], const u32x4 (&rv)[RT][NCV], f32x16 (&d)[RT]) {
+  if constexpr (S0 == 0) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      d[rt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int s = S0; s < S1; ++s)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      d[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8m, cv[s]), __builtin_bit_cast(f16x8m, rv[rt][s]), d[rt],
+                                                     0, 0, 0);
+}
+
 // WAVES = 8: one 512-thread block per CU, so the two waves that share a SIMD belong to the SAME block and meet at
 // every chunk barrier.  With two independent 4-wave blocks per CU the SIMD's arbiter favours one of them: it
 // finishes at ~70 % of the kernel time and the other runs the rest alone, without a partner to hide its LDS
 // waits and epilogues behind (measured per block with GQHIP_CLOCK_STAMPS: 104 / 149 us).  One block per CU also
 // halves the L2 -> LDS staging traffic (one chunk copy serves 8 waves).
-template <int NV, int RT, int CT, int GT, int WAVES, bool MIXED = false>
+// FK: 0 = split-bf16, 1 = fp16 + fp8 (MIXED), 2 = fp16 main product only (F16).
+template <int NV, int RT, int CT, int GT, int WAVES, int FK = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
+  constexpr bool MIXED = FK == 1, F16 = FK == 2;
   static_assert(!MIXED || NV == 2, "fp16 + fp8 filter: dim 16");
-  constexpr int NCV = BfLayout<NV>::NCV;      // code (and row) vectors per tile
+  constexpr int NCV = F16 ? (NV ? NV : 1) : BfLayout<NV>::NCV;      // code (and row) vectors per tile
   constexpr int TILE_Q = NCV * 64;            // 16-byte slots per tile
   constexpr int CHUNK_Q = CT * TILE_Q;
   constexpr int NT = 64 * WAVES;              // threads per block
   constexpr int R4 = CHUNK_Q / NT;            // 16-byte loads per thread per chunk
-  constexpr int NM = MIXED ? 3 : BfLayout<NV>::NM;   // MFMAs per tile and row tile
+  constexpr int NM = F16 ? NCV : (MIXED ? 3 : BfLayout<NV>::NM);   // MFMAs per tile and row tile
   // candidate tracker depth: top-4 (ids of three), except in the packed dim-4 kernel, which is bound by its
   // epilogue's VALU work (top-3 there: +18 % filter time otherwise, measured)
   constexpr bool TOP4 = NV > 0;
@@ -187,7 +212,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   const int sa = lane < 32 ? 127 - 11 : 127, sb = lane < 32 ? 127 + 6 : 127 - 6;
   auto tile_mfma = [&](auto s0_tag, auto s1_tag, const u32x4 (&cvx)[NCV], f32x16 (&dx)[RT]) {
     constexpr int A0 = decltype(s0_tag)::value, A1 = decltype(s1_tag)::value;
-    if constexpr (MIXED) tile_mfma_mixed<RT, A0, A1>(cvx, rv, dx, sa, sb);
+    if constexpr (F16) tile_mfma_f16<NCV, RT, A0, A1>(cvx, rv, dx);
+    else if constexpr (MIXED) tile_mfma_mixed<RT, A0, A1>(cvx, rv, dx, sa, sb);
     else tile_mfma_bf16<NV, RT, A0, A1>(cvx, rv, dx);
   };
   using IC0 = std::integral_constant<int, 0>;
@@ -228,7 +254,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   };
   auto fold = [&](f32x16 (&d)[RT], int tile, bool closes) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) tpend[rt] = max_chain(tpend[rt], d[rt]);
+    for (int rt = 0; rt < RT; ++rt) tpend[rt] = F16 ? max_tree(tpend[rt], d[rt]) : max_chain(tpend[rt], d[rt]);
     if (closes) close_group(tile);
   };
 
@@ -311,7 +337,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         // the first SKIP MFMAs carry no VALU (the previous tile's last accumulators are not readable yet: hipcc pads with
         // s_nop otherwise), the next EXTRA carry PER+1 slots, the rest PER
         constexpr int SKIP = K > 4 ? 2 : 0, SLOTS = K - SKIP;
-        constexpr int PER = BUDGET / SLOTS, EXTRA = BUDGET % SLOTS;
+        constexpr int SLOTS1 = SLOTS > 0 ? SLOTS : 1;       // (one MFMA per step: no slot between MFMAs, nothing to divide)
+        constexpr int PER = SLOTS > 0 ? BUDGET / SLOTS1 : 0, EXTRA = SLOTS > 0 ? BUDGET % SLOTS1 : 0;
 #pragma unroll
         for (int k = 0; k < SKIP; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
@@ -381,8 +408,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   for (int rt = 0; rt < RT; ++rt) {
     float a1 = m1[rt], a2v = m2[rt], a3 = m3[rt], a4 = m4[rt];
     int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h, j3 = i3[rt] * 2 + h;   // half-group ids
-    if constexpr (MIXED) {
-      // One record per LANE HALF (the re-rank sees 2 nsplit "splits"): the wider margin of this filter makes "a fourth
+    if constexpr (MIXED || F16) {
+      // One record per LANE HALF (the re-rank sees 2 nsplit "splits"): the wider margin of these filters makes "a fourth
       // group of one record within the margin" -- an undecided row: ~12 us of fp64 second stage for a lone row -- about
       // as likely as not per call with merged records (1 row in 16 384 at config 2); half the codes per record makes it
       // ~8x rarer, and the merge below is not needed.

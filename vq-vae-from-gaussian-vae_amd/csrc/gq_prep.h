@@ -36,7 +36,9 @@ struct PrepParams {
   double *rowsum;            // [rows, 4]
   float *coef;               // [rows, 2, dim]: the fp32 filter coefficients A | B (the re-rank's pre-filter reads them)
   u32x4 *rowimg;             // [rows][NVEC][2] or NULL (fp32 filter: no images)
-  float *rowscale;           // [rows] (MIXED images only): 2^e_r, the power of two the row's coefficients were divided by
+  float *rowscale;           // [rows] (fp16 images only): 2^e_r, the power of two the row's coefficients were divided by
+  float *rowaux;             // [rows, 8] (fp16 main-product filter only): the sums of its data-dependent bound (gq_rerank.h:
+                             // M_well, P, Q, Rb, |B|^2, max|A|, max(|A|, |B|), 0), each rounded UP to fp32
   const float *cb;           // [n, dim]
   u32x4 *cbimg;              // [tiles_total + CT][NVEC][2][32] or NULL
   WsHeader *hdr;
@@ -69,14 +71,19 @@ __device__ __forceinline__ float mixed_row_scale(const float *coef, int n) {
   return ldexpf(1.0f, 14 - ex);       // amax * s in [2^13, 2^14)
 }
 
-// MIXED (DIM 16, GQ only): the operand images of the fp16 + fp8 filter (gq_filter_bf16.h) instead of the split-bf16 ones.
-template <int MODE, int DIM, bool FROM_Z, bool MIXED = false>
+// fp64 -> fp32, never below the argument (bound inputs are rounded up)
+__device__ __forceinline__ float f32_up(double v) { return (float)(v * 1.0000002384185791); }   // (1 + 2^-22): covers the RNE error
+
+// FK (filter kind): 0 = the split-bf16 images; 1 = MIXED (DIM 16, GQ only): the operand images of the fp16 + fp8 filter;
+// 2 = F16: the fp16 images of the main-product-only filter (gq_filter_bf16.h), every MFMA dim, GQ and VQ.
+template <int MODE, int DIM, bool FROM_Z, int FK = 0>
 __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   static_assert(DIM == 4 || DIM == 8 || DIM == 16 || DIM == 32, "MFMA filter dims");
+  constexpr bool MIXED = FK == 1, F16 = FK == 2;
   static_assert(!MIXED || (DIM == 16 && MODE == kModeGQ), "fp16 + fp8 images: dim 16, Gaussian score");
   constexpr bool PACKED = DIM == 4;
   constexpr int NV = PACKED ? 1 : DIM / 8;     // 8-slot groups per operand half
-  constexpr int NVEC = PACKED ? 2 : 2 * NV;    // 16-byte vectors per (code | row, half) in an image
+  constexpr int NVEC = F16 ? NV : (PACKED ? 2 : 2 * NV);    // 16-byte vectors per (code | row, half) in an image
   constexpr int RB = 256 / DIM;                // rows per block
   const int tid = threadIdx.x;
 
@@ -92,13 +99,43 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   if ((int)blockIdx.x >= p.row_blocks) {
     // ------------------------------------------------------------------ codebook image + max |cb|
     const int cbk = blockIdx.x - p.row_blocks;
-    float amax = 0.0f;
+    float amax = 0.0f, r2max = 0.0f;
     if (p.cbimg) {
       const long items = (long)p.tiles_total * 64;   // (tile, half, code)
       for (long t = (long)cbk * 256 + tid; t < items; t += (long)kPrepCodeBlocks * 256) {
         const int tile = (int)(t >> 6), c = (int)t & 31, h = (int)(t >> 5) & 1;
         const long code = (long)tile * 32 + c;
         u32x4 *dst = p.cbimg + (long)tile * (NVEC * 64) + h * 32 + c;
+        if constexpr (F16) {
+          // slots [ squares of the dims | values of the dims ] as fp16; vector m, half h = slots 16 m + 8 h .. + 7 (the operand
+          // of MFMA m; DIM 4: its 8 slots in half 0, zeros in half 1).  Every lane reads the whole code row: max |n| and
+          // the squared norm |n|^2 (the norm bound of the re-rank) come from it.
+          float nv[DIM];
+          float r2 = 0.0f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            nv[k] = code < p.n ? p.cb[code * DIM + k] : 0.0f;
+            const float a = fabsf(nv[k]);
+            amax = (a != a) ? __builtin_inff() : __builtin_fmaxf(amax, a);
+            r2 = __builtin_fmaf(nv[k], nv[k], r2);
+          }
+          r2max = (r2 != r2) ? __builtin_inff() : __builtin_fmaxf(r2max, r2);
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+          for (int m = 0; m < NV; ++m) {
+            h8 v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int g = PACKED ? k : 16 * m + 8 * h + k;
+              const float x = nv[g < DIM ? g : g - DIM];
+              float t = g < DIM ? x * x : x;
+              asm volatile("" : "+v"(t));          // the fp32 square is the feature (no fused multiply-convert)
+              v[k] = (PACKED && h == 1) ? (_Float16)0.0f : (_Float16)t;
+            }
+            dst[(long)m * 64] = __builtin_bit_cast(u32x4, v);
+          }
+          continue;
+        }
         if constexpr (MIXED) {
           // slots: [0, 16) squares of the dims, [16, 32) their values.  Vector 0 / 1: fp16 h parts of slots 8h.. / 16 + 8h..
           // (the operands of the two K = 16 steps of the main product); vector 2: fp8 of the fp16 residuals * 2^11 of
@@ -185,13 +222,18 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
         amax = (a != a) ? __builtin_inff() : __builtin_fmaxf(amax, a);
       }
     }
-    __shared__ float s_amax[4];
+    __shared__ float s_amax[4], s_r2[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, o));
-    if ((tid & 63) == 0) s_amax[tid >> 6] = amax;
+    for (int o = 32; o > 0; o >>= 1) {
+      amax = __builtin_fmaxf(amax, __shfl_xor(amax, o));
+      r2max = __builtin_fmaxf(r2max, __shfl_xor(r2max, o));
+    }
+    if ((tid & 63) == 0) { s_amax[tid >> 6] = amax; s_r2[tid >> 6] = r2max; }
     __syncthreads();
-    if (tid == 0)
+    if (tid == 0) {
       p.hdr->absmax_part[cbk] = __builtin_fmaxf(__builtin_fmaxf(s_amax[0], s_amax[1]), __builtin_fmaxf(s_amax[2], s_amax[3]));
+      p.hdr->r2_part[cbk] = __builtin_fmaxf(__builtin_fmaxf(s_r2[0], s_r2[1]), __builtin_fmaxf(s_r2[2], s_r2[3]));
+    }
     return;
   }
 
@@ -301,11 +343,51 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; ++i) acc += s_sum[r * DIM + i][q];
-    if constexpr (MIXED) {
+    if constexpr (MIXED || F16) {
       const float sc = mixed_row_scale(&s_coef[r][0], 2 * DIM);
       if (sc != sc) acc = __builtin_nan("");     // no usable normalisation: the row's bound is NaN -> undecided
     }
     p.rowsum[(row0 + r) * 4 + q] = acc;
+  }
+  if constexpr (F16) {
+    // The sums of the data-dependent bound (gq_rerank.h:f16_bound), from the fp32 coefficients the filter multiplies.  A
+    // coordinate is a "well" when A < 0 and the vertex mu' = B / (2 |A|) of its parabola lies within |mu'| <= 6 (any
+    // classification is valid; this one keeps M_well small); everything else is charged at its worst case over |n| <= N1.
+    if (tid < RB && row0 + tid < p.rows) {
+      double Mw = 0.0, P = 0.0, Q = 0.0, Rb = 0.0, B2 = 0.0, Amax = 0.0, cmax = 0.0;
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        const double A = (double)s_coef[tid][i], B = (double)s_coef[tid][DIM + i];
+        const double a = fabs(A), b = fabs(B);
+        const bool well = A < 0.0 && b <= 12.0 * a;
+        if (well) Mw += B * B / (4.0 * a);
+        else { P += A > 0.0 ? A : 0.0; Q += a; Rb += b; }
+        B2 += B * B;
+        Amax = a > Amax ? a : Amax;
+        cmax = a > cmax ? a : cmax;
+        cmax = b > cmax ? b : cmax;
+      }
+      f32x4 o0 = {f32_up(Mw), f32_up(P), f32_up(Q), f32_up(Rb)}, o1 = {f32_up(B2), f32_up(Amax), f32_up(cmax), 0.0f};
+      f32x4 *dst = reinterpret_cast<f32x4 *>(p.rowaux + (row0 + tid) * 8);
+      dst[0] = o0;
+      dst[1] = o1;
+    }
+    if (p.rowimg && tid < RB * NVEC * 2) {
+      // row image: vector m, half h = fp16 of the normalised [A | B] slots 16 m + 8 h .. + 7 (DIM 4: half 0 holds all 8, half 1 zeros)
+      const int r = tid / (NVEC * 2), v = (tid / 2) % NVEC, h = tid % 2;
+      if (row0 + r < p.rows) {
+        float sc = mixed_row_scale(&s_coef[r][0], 2 * DIM);
+        if (v == 0 && h == 0) p.rowscale[row0 + r] = sc != sc ? sc : 1.0f / sc;     // 2^e_r (exact)
+        if (sc != sc) sc = 0.0f;
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          o[k] = (PACKED && h == 1) ? (_Float16)0.0f : (_Float16)(s_coef[r][(PACKED ? 0 : 16 * v + 8 * h) + k] * sc);
+        p.rowimg[(row0 + r) * (NVEC * 2) + v * 2 + h] = __builtin_bit_cast(u32x4, o);
+      }
+    }
+    return;
   }
   if constexpr (MIXED) {
     if (p.rowimg && tid < RB * 8) {

@@ -85,9 +85,12 @@ struct RerankParams {
   int gt;             // tiles per candidate group -- must match the filter's GT
   float ef_coeff;     // filter error bound E_f = ef_coeff * 2^-24 * T  (fp32 filter: 2 dim + 4; split-bf16: 220 + 24 dim;
                       // fp16 + fp8: 2450)
-  float n1_limit;     // > 0: the filter's operand formats assume 1 <= max|cb| <= n1_limit (fp16 + fp8 images: 16; below 1 the
-                      // absolute errors of fp8-subnormal operands are not covered by the bound); any other codebook makes
-                      // every row undecided (cascade: fp32 filter, fp64 second stage)
+  float n1_limit;     // > 0: the filter's operand formats assume n1_min <= max|cb| <= n1_limit (fp16 + fp8 images: 1 .. 16; below
+                      // 1 the absolute errors of fp8-subnormal operands are not covered by the bound; fp16 images: 0 .. 255, the
+                      // squares must stay below 65504); any other codebook makes every row undecided (cascade: fp32 filter,
+                      // fp64 second stage)
+  float n1_min;
+  const float *rowaux;   // [rows, 8] sums of the data-dependent bound (gq_prep_kernel, F16) or NULL: the classic bound k u T
   int all_rows;       // exhaustive kernel: process every row (no filter ran)
   int stats;          // count re-ranked half-pairs (debug)
   int bar_spin_limit; // tail kernel: polls (~0.25 us each) a grid barrier waits before it gives up (gq_tail.h)
@@ -187,8 +190,8 @@ __device__ __forceinline__ void write_result(const RerankParams &p, long row, in
 }
 
 // max |cb| from the per-block partials gq_prep_kernel left in the header (one 1-KiB coalesced load per wave).
-__device__ __forceinline__ float wave_absmax(const WsHeader *hdr, int lane) {
-  const f32x4 v = reinterpret_cast<const f32x4 *>(hdr->absmax_part)[lane];
+__device__ __forceinline__ float wave_absmax(const float *parts, int lane) {
+  const f32x4 v = reinterpret_cast<const f32x4 *>(parts)[lane];
   float m = __builtin_fmaxf(__builtin_fmaxf(v.x, v.y), __builtin_fmaxf(v.z, v.w));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
@@ -211,6 +214,46 @@ __device__ __forceinline__ void row_bound(const double *rs, double N1, int dim, 
     T = dim * N2 + 2.0 * rs[1] * N1;
     G = 0.0;
   }
+}
+
+// The error bound of the fp16 main-product filter (gq_filter_bf16.h, F16), level 1 only.  u = 2^-24, k = ef_coeff.
+// For every code j:  |f~(j) - f(j)| <= E(j) = k u T_j + E_abs,   T_j = sum_i |A_i| n_ji^2 + |B_i| |n_ji|,
+// (two fp16 roundings per product, 2^-10 + 2^-22 relative; fp32 accumulation; E_abs: operands in fp16's subnormal range).
+// Three bounds on T_j, all rigorous, the smallest wins:
+//   * worst case over |n| <= N1:                       T_j <= T_old                                    (row_bound)
+//   * Cauchy-Schwarz with R2 = max_j |n_j|^2:          T_j <= max|A| R2 + |B|_2 sqrt(R2) = T_norm
+//   * through the code's own score.  Coordinates are classed by gq_prep_kernel: a "well" (A < 0, vertex mu' = B / 2|A|
+//     with |mu'| <= 6) contributes  f_i = -a (n - mu')^2 + a mu'^2  and  |A| n^2 + |B||n| <= 3 a (n - mu')^2 + 5 a mu'^2
+//     (d = |n - mu'|, m = |mu'|: a (d + m)^2 + 2 a m (d + m) = a d^2 + 4 a d m + 3 a m^2 <= 3 a d^2 + 5 a m^2); any other
+//     coordinate contributes at most U_i = max(A, 0) N1^2 + |B| N1 to f and |A| N1^2 + |B| N1 to T.  Summing:
+//     sum_well a d^2 <= M_well + U_wc - f(j), hence   T_j <= 8 M_well + 3 U_wc + T_wc - 3 f(j) = Cr - 3 f(j):
+//     the better a code scores, the smaller its error.
+// With j^ = arg max f~, F = f~(j^) and the reference's arg-max j* (f(j*) >= f(j^) - 2 E_r):
+//     E(j^) <= Ea = min(E_unif, (k u (Cr - 3 F) + E_abs) / (1 - 3 k u)),        E_unif = k u min(T_old, T_norm) + E_abs,
+//     E(j*) <= Eb = min(E_unif, k u (Cr - 3 F + 3 Ea + 6 E_r) + E_abs),
+//     f~(j*) >= F - (Ea + Eb + 2 E_r).
+// Returns Ea + Eb (the caller adds 2 E_r and its safety factor).  aux = (M_well, P, Q, Rb, |B|^2, max|A|, max(|A|,|B|), 0).
+__device__ __forceinline__ double f16_bound(const float (&aux)[8], double T_old, double Er, double N1, double R2, double F,
+                                            int dim, double ku) {
+  const double N2 = N1 * N1;
+  const double U_wc = (double)aux[1] * N2 + (double)aux[3] * N1;
+  const double T_wc = (double)aux[2] * N2 + (double)aux[3] * N1;
+  const double Cr = 8.0 * (double)aux[0] + 3.0 * U_wc + T_wc;
+  const double T_norm = (double)aux[5] * R2 + sqrt((double)aux[4] * R2);
+  const double NN = N2 > N1 ? N2 : N1;
+  // subnormal operands (normalised units: the row's largest coefficient is in [2^13, 2^14), so 2^e_r <= cmax 2^-13):
+  // a coefficient below 2^-14 is off by <= 2^-25 absolute, times |s| <= max(N1^2, N1); an s below 2^-14 is off by <= 2^-25,
+  // times a coefficient < 2^14
+  const double E_abs = 2.0 * dim * (2.98023223876953125e-08 * NN + 4.8828125e-04) * (double)aux[6] * 1.220703125e-04;
+  const double Tu = T_old < T_norm ? T_old : T_norm;
+  const double E_unif = ku * Tu + E_abs;
+  double slack = Cr - 3.0 * F;
+  slack = slack > 0.0 ? slack : 0.0;
+  double Ea = (ku * slack + E_abs) / (1.0 - 3.0 * ku);
+  Ea = Ea < E_unif ? Ea : E_unif;
+  double Eb = ku * (slack + 3.0 * Ea + 6.0 * Er) + E_abs;
+  Eb = Eb < E_unif ? Eb : E_unif;
+  return Ea + Eb;       // NaN in, NaN out: the caller's `margin < 1e30` test sends the row to the next stage
 }
 
 // The reference score of a code row held in registers against row operands [mu | 2 sd^2 | log sd] in LDS (same
@@ -272,7 +315,8 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   auto group_bits = [&](bool c) { return (__ballot(c) >> gshift) & glow; };
 
   // ---- everything the row needs, issued together ---------------------------
-  const float N1f = p.level == 2 ? p.hdr->absmax : wave_absmax(p.hdr, lane);
+  const float N1f = p.level == 2 ? p.hdr->absmax : wave_absmax(p.hdr->absmax_part, lane);
+  const float R2f = (p.level == 1 && p.rowaux) ? wave_absmax(p.hdr->r2_part, lane) : 0.0f;   // max_j |cb_j|^2 (F16 bound)
   if (p.level == 1 && vblock == 0 && threadIdx.x == 0) p.hdr->absmax = N1f;   // for the tail kernel
   double rs[4];
   {
@@ -318,16 +362,26 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   double T, G;
   row_bound<MODE>(rs, N1, DIM, p.beta, T, G);
   const double Er = MODE == kModeGQ ? (DIM + 16.0) * u * G : 1e-12 * T;
-  const double margin = 2.5 * ((double)p.ef_coeff * u * T + Er) + 1e-30;      // around the filter's row maximum
   const float margin32 = (float)(2.5 * ((2.0 * DIM + 4.0) * u * T + Er) * 1.0000002 + 1e-30);   // around pass 1's F (rounded up)
-  bool bad = !(N1 == N1) || N1 > 1e18 || !(T < 1e30) || !(G < 1e30) || !(margin < 1e30);
-  if (p.level == 1 && p.n1_limit > 0.f && !(N1f <= p.n1_limit && N1f >= 1.0f)) bad = true;
 
   float fmax = NEG_INF;
 #pragma unroll
   for (int k = 0; k < NSI; ++k) fmax = __builtin_fmaxf(fmax, r[k].m1);
 #pragma unroll
   for (int o = GROUP / 2; o > 0; o >>= 1) fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, o));
+
+  double margin = 2.5 * ((double)p.ef_coeff * u * T + Er) + 1e-30;      // around the filter's row maximum
+  if (p.level == 1 && p.rowaux) {
+    // fp16 main-product filter: the data-dependent bound (f16_bound above); 1.25 (Ea + Eb + 2 E_r) keeps the same 25 % slack
+    float aux[8];
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(p.rowaux + row * 8);
+    const f32x4 q0 = q[0], q1 = q[1];
+    aux[0] = q0.x; aux[1] = q0.y; aux[2] = q0.z; aux[3] = q0.w; aux[4] = q1.x; aux[5] = q1.y; aux[6] = q1.z; aux[7] = q1.w;
+    const double R2 = (double)R2f * (1.0 + 64.0 * u);       // the fp32 sum of squares of up to 64 dims, rounded up
+    margin = 1.25 * (f16_bound(aux, T, Er, N1, R2, (double)fmax, DIM, (double)p.ef_coeff * u) + 2.0 * Er) + 1e-30;
+  }
+  bool bad = !(N1 == N1) || N1 > 1e18 || !(T < 1e30) || !(G < 1e30) || !(margin < 1e30);
+  if (p.level == 1 && p.n1_limit > 0.f && !(N1f <= p.n1_limit && N1f >= p.n1_min)) bad = true;
   bad = bad || !(fmax == fmax) || !(fmax > NEG_INF) || !(fmax < __builtin_inff());
 
   const double thr = (double)fmax - margin;

@@ -56,6 +56,7 @@ struct Plan {
   // second level of the cascade behind the split-bf16 filter: the fp32 MFMA filter (RT 1) on the undecided rows
   int nsplit2, tiles_per_split2, gt2;
   bool mixed;           // dim 16, Gaussian score: fp16 main product + fp8 corrections instead of three bf16 products
+  bool f16;             // fp16 main product only + the data-dependent bound of the re-rank (round 3: the default filter)
 };
 
 // gq_filter_bf16.h / DESIGN.md section 3: 2 x 1057 (the two fp8 correction types: (2^-3 + 2^-8) relative on a term of at most
@@ -64,17 +65,27 @@ struct Plan {
 // corrections) = 2417, rounded up
 constexpr float kMixedEfCoeff = 2450.0f;
 constexpr float kMixedN1Limit = 16.0f;   // ... and max|cb| >= 1 (gq_rerank.h)
+// fp16 main-product filter (gq_filter_bf16.h, F16): per product the two fp16 roundings, (1 + 2^-11)^2 - 1 = 16384 u + 4 u, the fp32
+// roundings of A / B, of n^2 and of the row normalisation's inputs (3 u), 4 u per accumulation step of up to 2 x 64 slots
+// ... charged for the widest layout (dim 32: 64 products): 16384 + 4 + 3 + 4 * 64 = 16647, rounded up.  Operands in fp16's
+// subnormal range are charged separately, as an absolute term (gq_rerank.h:f16_bound).
+constexpr float kF16EfCoeff = 16700.0f;
+constexpr float kF16N1Limit = 255.0f;    // n^2 must stay a finite fp16
 
-// Filter selection: 0 = auto (fp16 + fp8 at dim 16 / Gaussian score, split-bf16 at the other MFMA dims), 1 = always the
-// fp32 MFMA filter, 2 = split-bf16 wherever it applies (no fp16 + fp8).
+// Filter selection: 0 = auto (the fp16 main-product filter at every MFMA dim, GQ and VQ), 1 = always the fp32 MFMA filter,
+// 2 = split-bf16 wherever it applies, 3 = fp16 + fp8 (round 2's default: dim 16 / Gaussian score, split-bf16 elsewhere).
 // Initial value from GQHIP_FILTER=fp32|bf16, changed at run time by gqhip_set_filter().  Both filters feed the
 // same exact re-rank, so the choice never changes an index.
 std::atomic<int> g_filter_kind{[] {
   const char *e = getenv("GQHIP_FILTER");
-  return (e && (e[0] == 'f' || e[0] == 'F')) ? 1 : ((e && (e[0] == 'b' || e[0] == 'B')) ? 2 : 0);
+  if (e && (e[0] == 'f' || e[0] == 'F') && (e[1] == 'p' || e[1] == 'P') && e[2] == '3') return 1;   // fp32
+  if (e && (e[0] == 'b' || e[0] == 'B')) return 2;                                                   // bf16
+  if (e && (e[0] == 'm' || e[0] == 'M')) return 3;                                                   // mixed = fp16 + fp8
+  return 0;
 }()};
 bool want_bf16_filter() { return g_filter_kind.load(std::memory_order_relaxed) != 1; }
-bool want_mixed_filter() { return g_filter_kind.load(std::memory_order_relaxed) == 0; }
+bool want_mixed_filter() { return g_filter_kind.load(std::memory_order_relaxed) == 3; }
+bool want_f16_filter() { return g_filter_kind.load(std::memory_order_relaxed) == 0; }
 
 Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   Plan pl{};
@@ -119,7 +130,11 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   pl.mixed = pl.bf16 && want_mixed_filter() && dim == 16 && pl.waves == 8 && pl.ct == 16 && pl.gt == 4;
-  if (pl.mixed && pl.nsplit > kMaxSplit / 2) {
+  // dim 4 keeps the packed split-bf16 filter: 65 536 codes are dense in 4-d -- 3.5 candidate groups per row inside the fp16
+  // margin and a quarter of the rows undecided (measured, profiles/r03) -- and its kernel is not MFMA-bound in the first place
+  pl.f16 = pl.bf16 && want_f16_filter() && pl.waves == 8 && pl.gt == 4 && dim != 4;
+  if (pl.f16) pl.ct = dim == 32 ? 8 : 16;   // one 16-byte vector per MFMA, lane and tile: 16-tile chunks are 16 / 32 KiB
+  if ((pl.mixed || pl.f16) && pl.nsplit > kMaxSplit / 2) {
     // the fp16 + fp8 filter leaves one record per lane half: 2 nsplit record sets for the re-rank (<= kMaxSplit)
     const int s3 = kMaxSplit / 2;
     pl.tiles_per_split = ((pl.tiles_total + s3 - 1) / s3 + pl.gt - 1) / pl.gt * pl.gt;
@@ -135,7 +150,7 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WsLayout {
-  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, rowsum, coef, cbimg, rowimg, rowscale, total;
+  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, rowsum, coef, cbimg, rowimg, rowscale, rowaux, total;
 };
 
 WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
@@ -143,7 +158,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   WsLayout w{};
   int64_t off = 0;
   w.hdr = off; off += (int64_t)sizeof(WsHeader);
-  w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit * (pl.mixed ? 2 : 1) : 0));
+  w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit * ((pl.mixed || pl.f16) ? 2 : 1) : 0));
   w.fb = off;  off += align256(4 * rows);
   // cascade behind the split-bf16 filter: list B + the second-level fp32 filter's records (kCascadeSplit splits)
   w.fb2 = off;  off += pl.bf16 ? align256(4 * rows) : 0;
@@ -155,10 +170,11 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.rowsum = off; off += pl.mfma ? align256(8 * 4 * rows) : 0;
   w.coef = off; off += pl.mfma ? align256(4 * 2 * rows * dim) : 0;
   // split-bf16 operand images: 2*NV vectors of 16 B per (code, half) / (row, half), NV = dim / 8
-  const int64_t nvec = dim == 4 ? 2 : dim / 4;
+  const int64_t nvec = pl.f16 ? (dim == 4 ? 1 : dim / 8) : (dim == 4 ? 2 : dim / 4);
   w.cbimg = off;  off += pl.bf16 ? align256((int64_t)(pl.tiles_total + pl.ct) * nvec * 64 * 16) : 0;
   w.rowimg = off; off += pl.bf16 ? align256(rows * nvec * 2 * 16) : 0;
-  w.rowscale = off; off += pl.mixed ? align256(4 * rows) : 0;
+  w.rowscale = off; off += (pl.mixed || pl.f16) ? align256(4 * rows) : 0;
+  w.rowaux = off; off += pl.f16 ? align256(32 * rows) : 0;
   w.total = off;
   return w;
 }
@@ -254,6 +270,26 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
   const dim3 grid((unsigned)(pl.row_blocks * pl.nsplit));
   const dim3 fblock((unsigned)(64 * pl.waves));
   ProfScope prof;
+  if (pl.f16) {
+#define GQ_LAUNCH_F16(NV, R, C)                                                                                      \
+  do {                                                                                                             \
+    if (prof.on)                                                                                                   \
+      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2>), grid, fblock, 0, st, prof.a, prof.b, 0, fp); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2>), grid, fblock, 0, st, fp);                      \
+  } while (0)
+    switch (dim * 10 + pl.rt) {
+      case 81: GQ_LAUNCH_F16(1, 1, 16); break;
+      case 82: GQ_LAUNCH_F16(1, 2, 16); break;
+      case 161: GQ_LAUNCH_F16(2, 1, 16); break;
+      case 162: GQ_LAUNCH_F16(2, 2, 16); break;
+      case 321: GQ_LAUNCH_F16(4, 1, 8); break;
+      case 322: GQ_LAUNCH_F16(4, 2, 8); break;
+      default: return GQHIP_ERR_INVALID_ARG;
+    }
+#undef GQ_LAUNCH_F16
+    return check_launch();
+  }
 #define GQ_LAUNCH_BF1(NV, R, C, G, W)                                                                       \
   do {                                                                                                    \
     if (prof.on)                                                                                          \
@@ -275,9 +311,9 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
       case 16:
         if (mixed) {
           if (prof.on)
-            hipExtLaunchKernelGGL((gq_filter_bf16_kernel<2, 2, 16, 4, 8, true>), grid, fblock, 0, st, prof.a, prof.b, 0, fp);
+            hipExtLaunchKernelGGL((gq_filter_bf16_kernel<2, 2, 16, 4, 8, 1>), grid, fblock, 0, st, prof.a, prof.b, 0, fp);
           else
-            hipLaunchKernelGGL((gq_filter_bf16_kernel<2, 2, 16, 4, 8, true>), grid, fblock, 0, st, fp);
+            hipLaunchKernelGGL((gq_filter_bf16_kernel<2, 2, 16, 4, 8, 1>), grid, fblock, 0, st, fp);
         }
         else if (pl.ct == 16 && pl.gt == 2) GQ_LAUNCH_BF1(2, 2, 16, 2, 8);
         else if (pl.ct == 16 && pl.gt == 8) GQ_LAUNCH_BF1(2, 2, 16, 8, 8);
@@ -294,9 +330,9 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
       case 16:
         if (mixed) {
           if (prof.on)
-            hipExtLaunchKernelGGL((gq_filter_bf16_kernel<2, 1, 16, 4, 8, true>), grid, fblock, 0, st, prof.a, prof.b, 0, fp);
+            hipExtLaunchKernelGGL((gq_filter_bf16_kernel<2, 1, 16, 4, 8, 1>), grid, fblock, 0, st, prof.a, prof.b, 0, fp);
           else
-            hipLaunchKernelGGL((gq_filter_bf16_kernel<2, 1, 16, 4, 8, true>), grid, fblock, 0, st, fp);
+            hipLaunchKernelGGL((gq_filter_bf16_kernel<2, 1, 16, 4, 8, 1>), grid, fblock, 0, st, fp);
         }
         else GQ_LAUNCH_BF(2, 1, 8);
         break;
@@ -364,13 +400,22 @@ struct PrepInput {
 };
 
 template <int MODE, bool FROM_Z>
-int launch_prep(const PrepParams &pp, int dim, bool mixed, hipStream_t st) {
+int launch_prep(const PrepParams &pp, int dim, bool mixed, bool f16, hipStream_t st) {
   const dim3 grid((unsigned)(pp.row_blocks + kPrepCodeBlocks));
   if constexpr (MODE == kModeGQ) {
     if (mixed && dim == 16) {
-      hipLaunchKernelGGL((gq_prep_kernel<MODE, 16, FROM_Z, true>), grid, dim3(256), 0, st, pp);
+      hipLaunchKernelGGL((gq_prep_kernel<MODE, 16, FROM_Z, 1>), grid, dim3(256), 0, st, pp);
       return check_launch();
     }
+  }
+  if (f16) {
+    switch (dim) {
+      case 8: hipLaunchKernelGGL((gq_prep_kernel<MODE, 8, FROM_Z, 2>), grid, dim3(256), 0, st, pp); break;
+      case 16: hipLaunchKernelGGL((gq_prep_kernel<MODE, 16, FROM_Z, 2>), grid, dim3(256), 0, st, pp); break;
+      case 32: hipLaunchKernelGGL((gq_prep_kernel<MODE, 32, FROM_Z, 2>), grid, dim3(256), 0, st, pp); break;
+      default: return GQHIP_ERR_INVALID_ARG;
+    }
+    return check_launch();
   }
   switch (dim) {
     case 4: hipLaunchKernelGGL((gq_prep_kernel<MODE, 4, FROM_Z>), grid, dim3(256), 0, st, pp); break;
@@ -418,11 +463,16 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   rp.spread = reinterpret_cast<SpreadSlot *>(ws + w.spread);
   rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
   const bool mixed = pl.mixed && MODE == kModeGQ;
+  const bool f16 = pl.f16;
   rp.ef_coeff = pl.bf16 ? (float)(dim == 4 ? 332 : 220 + 24 * dim) : (float)(2 * dim + 4);
-  if (mixed) { rp.ef_coeff = kMixedEfCoeff; rp.n1_limit = kMixedN1Limit; }
+  if (mixed) { rp.ef_coeff = kMixedEfCoeff; rp.n1_limit = kMixedN1Limit; rp.n1_min = 1.0f; }
+  if (f16) {
+    rp.ef_coeff = kF16EfCoeff; rp.n1_limit = kF16N1Limit; rp.n1_min = 0.0f;
+    rp.rowaux = reinterpret_cast<const float *>(ws + w.rowaux);
+  }
   static const double env_ef = getenv("GQHIP_EF_COEFF") ? atof(getenv("GQHIP_EF_COEFF")) : 0.0;   // diagnostics
   if (env_ef > 0.0) rp.ef_coeff = (float)env_ef;
-  rp.beta = (float)beta; rp.nsplit = mixed ? 2 * pl.nsplit : pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
+  rp.beta = (float)beta; rp.nsplit = (mixed || f16) ? 2 * pl.nsplit : pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
   rp.bar_spin_limit = g_tail_spin_limit.load(std::memory_order_relaxed);
 
@@ -457,8 +507,9 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   pp.hdr = hdr; pp.rows = rows; pp.n = (int)n; pp.tiles_total = pl.tiles_total;
   pp.row_blocks = (int)((rows * dim + 255) / 256);
   pp.beta = (float)beta; pp.omap = omap;
-  pp.rowscale = mixed ? reinterpret_cast<float *>(ws + w.rowscale) : nullptr;
-  int rc = from_z ? launch_prep<MODE, true>(pp, (int)dim, mixed, st) : launch_prep<MODE, false>(pp, (int)dim, mixed, st);
+  pp.rowscale = (mixed || f16) ? reinterpret_cast<float *>(ws + w.rowscale) : nullptr;
+  pp.rowaux = f16 ? reinterpret_cast<float *>(ws + w.rowaux) : nullptr;
+  int rc = from_z ? launch_prep<MODE, true>(pp, (int)dim, mixed, f16, st) : launch_prep<MODE, false>(pp, (int)dim, mixed, f16, st);
   if (rc != GQHIP_OK) return rc;
 
   // ---- launch 2: the filter ---------------------------------------------------------------------------------
@@ -471,7 +522,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
     fp.hdr = hdr;
     fp.dbg = ws + w.rec2;   // diagnostic builds only (the cascade's records: unused until the tail kernel)
-    fp.rowscale = mixed ? reinterpret_cast<const float *>(ws + w.rowscale) : nullptr;
+    fp.rowscale = (mixed || f16) ? reinterpret_cast<const float *>(ws + w.rowscale) : nullptr;
     rc = launch_filter_bf16<MODE>(pl, fp, (int)dim, mixed, st);
     if (rc != GQHIP_OK) return rc;
     // Cascade: when more than kCascadeMin rows are undecided (ill-conditioned inputs: the split-bf16 margin is ~16x
@@ -502,7 +553,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   RerankParams r2 = rp;
   if (pl.bf16) {
     r2.rec = reinterpret_cast<const Rec *>(ws + w.rec2);
-    r2.nsplit = pl.nsplit2; r2.gt = pl.gt2; r2.ef_coeff = (float)(2 * dim + 4); r2.n1_limit = 0.f;
+    r2.nsplit = pl.nsplit2; r2.gt = pl.gt2; r2.ef_coeff = (float)(2 * dim + 4); r2.n1_limit = 0.f; r2.rowaux = nullptr;
   }
   r2.level = 2;
   return launch_tail<MODE>(r2, f2, (int)dim, st);
@@ -528,7 +579,8 @@ const char *gqhip_status_string(int s) {
 int gqhip_last_hip_error(void) { return g_last_hip_error; }
 
 int gqhip_set_filter(int kind) {
-  if (kind != GQHIP_FILTER_AUTO && kind != GQHIP_FILTER_FP32 && kind != GQHIP_FILTER_BF16) return GQHIP_ERR_INVALID_ARG;
+  if (kind != GQHIP_FILTER_AUTO && kind != GQHIP_FILTER_FP32 && kind != GQHIP_FILTER_BF16 && kind != GQHIP_FILTER_MIXED)
+    return GQHIP_ERR_INVALID_ARG;
   g_filter_kind.store(kind, std::memory_order_relaxed);
   return GQHIP_OK;
 }
@@ -539,10 +591,10 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
   if (!out8 || rows < 1 || n < 1 || dim < 1 || dim > kMaxDim) return GQHIP_ERR_INVALID_ARG;
   const Plan pl = make_plan(rows, n, dim);
   const WsLayout w = ws_layout(rows, n, dim);
-  out8[0] = w.rec; out8[1] = pl.mfma ? pl.nsplit * (pl.mixed ? 2 : 1) : 0;   // record sets per row (fp16 + fp8: one per lane half)
+  out8[0] = w.rec; out8[1] = pl.mfma ? pl.nsplit * ((pl.mixed || pl.f16) ? 2 : 1) : 0;   // record sets per row (fp16 + fp8: one per lane half)
   out8[2] = pl.gt; out8[3] = pl.tiles_per_split;
-  out8[4] = pl.mixed ? 2 : (pl.bf16 ? 1 : 0);   // 0 fp32 MFMA filter, 1 split-bf16, 2 fp16 + fp8 (Gaussian score)
-  out8[5] = pl.mixed ? (int)kMixedEfCoeff : (pl.bf16 ? (dim == 4 ? 332 : 220 + 24 * dim) : 2 * dim + 4);
+  out8[4] = pl.f16 ? 3 : (pl.mixed ? 2 : (pl.bf16 ? 1 : 0));   // 0 fp32 MFMA filter, 1 split-bf16, 2 fp16 + fp8 (Gaussian score), 3 fp16 main product
+  out8[5] = pl.f16 ? (int)kF16EfCoeff : (pl.mixed ? (int)kMixedEfCoeff : (pl.bf16 ? (dim == 4 ? 332 : 220 + 24 * dim) : 2 * dim + 4));
   out8[6] = pl.rt; out8[7] = pl.waves;
   return GQHIP_OK;
 }

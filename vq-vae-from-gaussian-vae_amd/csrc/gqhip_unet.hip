@@ -685,4 +685,15 @@ int upsample2x_nhwc_f32(const float *x, float *y, int64_t B, int64_t H, int64_t 
   return check_launch();
 }
 
+int gqhip_checksum_tensors(const void *table_dev, int64_t count, uint64_t *sums_dev, void *stream) {
+  if (count < 0 || count > 65535) return GQHIP_ERR_INVALID_ARG;
+  if (count == 0) return GQHIP_OK;
+  if (!table_dev || !sums_dev) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(sums_dev, 0, sizeof(uint64_t) * count, st) != hipSuccess) return check_launch();
+  hipLaunchKernelGGL(checksum_tensors_kernel, dim3((unsigned)count, kChecksumSlices), dim3(256), 0, st,
+                     static_cast<const ChecksumEntry *>(table_dev), reinterpret_cast<unsigned long long *>(sums_dev));
+  return check_launch();
+}
+
 }  // extern "C"

@@ -83,6 +83,7 @@ _SIGNATURES = {
                                              _i64, _i64, _i64, _vp]),
     "conv3x3_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _i64, _i64, _i64,
                                    _i64, _i64, _vp]),
+    "gqhip_checksum_tensors": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "gn_stats_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wino_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                             ctypes.c_int, _vp]),
@@ -793,6 +794,24 @@ def conv3x3_gn_small(x, w_ohwi, bias, gn):
     return y
 
 
+def checksum_table(tensors):
+    """Device table for checksum_tensors: one {pointer, 32-bit words} entry per tensor (dense fp32 / int32 HIP tensors)."""
+    dev = tensors[0].device
+    rows = []
+    for t in tensors:
+        if not (t.is_cuda and t.element_size() == 4 and t.data_ptr() % 16 == 0 and t.device == dev):
+            raise GqHipError("checksum_table needs 16-byte aligned 4-byte-element tensors on one HIP device")
+        rows += [t.data_ptr(), t.numel()]
+    return torch.tensor(rows, dtype=torch.int64).to(dev)
+
+
+def checksum_tensors(table, out):
+    """out[t] (int64, device) = content hash of tensor t of ``table`` (gqhip.h:gqhip_checksum_tensors); asynchronous."""
+    with torch.cuda.device(table.device):
+        _check(lib().gqhip_checksum_tensors(table.data_ptr(), table.numel() // 2, out.data_ptr(), _stream()), "gqhip_checksum_tensors")
+    return out
+
+
 def conv_f32_ok(cin: int, cout: int, H: int, W: int, gn: bool) -> bool:
     """Shapes conv3x3_f32 tiles (gqhip.h)."""
     return cout % 4 == 0 and (cin % 64 == 0 and (not gn or cin <= 1024) or (not gn and cin in (8, 16, 32)))
@@ -937,7 +956,7 @@ def debug_enable(on: bool) -> None:
     lib().gqhip_debug_enable(1 if on else 0)
 
 
-FILTER_KINDS = {"auto": 0, "fp32": 1, "bf16": 2}
+FILTER_KINDS = {"auto": 0, "fp32": 1, "bf16": 2, "mixed": 3}
 
 
 def set_filter(kind: str) -> None:

@@ -342,6 +342,66 @@ def _gn_act_bound(norm: nn.GroupNorm, x: torch.Tensor) -> float:
     return math.sqrt(max(n - 1, 1)) * norm._gb_max[0] + norm._gb_max[1]
 
 
+class _WeightGuard:
+    """Notices parameter writes that bump no version counter (``param.data.mul_()``, EMA swaps through ``.data``): the
+    weight-derived caches below are keyed on (data_ptr, _version), which such writes leave unchanged.  One libgqhip launch per
+    forward hashes the bytes of every parameter of the module (gqhip.h:gqhip_checksum_tensors, ~0.1-0.2 GB read); the forward
+    runs speculatively on the cached data while the sums travel to pinned host memory; before the result is returned they are
+    compared with the sums the caches were built from, and on a difference the caches are dropped and the forward runs again.
+    The wait is for a copy queued at the START of this forward, so the host stays at most one forward ahead of the device
+    and the device never idles."""
+
+    def __init__(self) -> None:
+        self.key = None
+
+    def begin(self, module: nn.Module) -> bool:
+        from .. import _lib
+
+        params = [p for p in module.parameters()]
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            return False
+        key = tuple(p.data_ptr() for p in params)
+        if key != self.key:
+            try:
+                self.table = _lib.checksum_table([p.detach() for p in params])
+            except _lib.GqHipError:
+                return False
+            self.sums = torch.empty(len(params), dtype=torch.int64, device=params[0].device)
+            self.host = torch.empty(len(params), dtype=torch.int64).pin_memory()
+            self.event = torch.cuda.Event()
+            self.baseline = None
+            self.key = key
+        _lib.checksum_tensors(self.table, self.sums)
+        self.host.copy_(self.sums, non_blocking=True)
+        self.event.record()
+        return True
+
+    def changed(self) -> bool:
+        self.event.synchronize()
+        cur = self.host.clone()
+        if self.baseline is not None and torch.equal(cur, self.baseline):
+            return False
+        first = self.baseline is None
+        self.baseline = cur
+        return not first
+
+
+def _guarded(module: nn.Module, run, x: torch.Tensor):
+    """run(x) with the module's weight caches verified against the parameters' bytes (see _WeightGuard)."""
+    if not (WEIGHT_GUARD and x.is_cuda and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
+        return run(x)
+    guard = module.__dict__.get("_gq_guard")
+    if guard is None:
+        guard = module.__dict__["_gq_guard"] = _WeightGuard()
+    if not guard.begin(module):
+        return run(x)
+    y = run(x)
+    if guard.changed():
+        invalidate_caches(module)
+        y = run(x)
+    return y
+
+
 def invalidate_caches(module: nn.Module) -> None:
     """Drop every weight-derived cache under ``module`` (Winograd U matrices, the sub-pixel phase matrices, the fused
     q/k/v matrix).  The caches are keyed on (data_ptr, _version, device), which follows ``load_state_dict``, optimizer
@@ -415,6 +475,9 @@ FUSED_CONV_OUT = True      # decoder conv_out (128 -> 3) with norm_out + swish f
 # encoder conv_out (512 -> 2 z, norm_out + swish fused in) and decoder conv_in (z -> 512) on the fp32 matrix cores with a fixed
 # summation order (bit-reproducible; MIOpen's pick for the former combines split-K partial sums with atomics)
 CONV_F32 = True
+# every inference forward of Encoder / Decoder on a HIP device checks its weight-derived caches against a content hash of the
+# parameters (catches ``param.data`` writes, which bump no version counter); see _WeightGuard
+WEIGHT_GUARD = True
 DIRECT_CONV_OVER_F4 = False   # ... also where the alternative is F(4x4,3x3) (decoder, 256 channels at 128 x 128): A/B switch
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
 # written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
@@ -837,6 +900,9 @@ class Encoder(nn.Module):
         invalidate_caches(self)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _guarded(self, self._forward, x)
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         x = _match_layout(x, self.conv_in)
         h, pb = _conv(self.conv_in, x)
         for lvl, level in enumerate(self.down):
@@ -892,6 +958,9 @@ class Decoder(nn.Module):
 
     def forward(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
         self.last_z_shape = z.shape
+        return _guarded(self, self._forward, z)
+
+    def _forward(self, z: torch.Tensor) -> torch.Tensor:
         z = _match_layout(z, self.conv_in)
         if _conv_f32_ok(self.conv_in, z, False):
             h, pb = _conv_f32(self.conv_in, z), None
