@@ -243,6 +243,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     for (int v = 0; v < NCV; ++v) cv[v] = tile[v * 64];
   };
   auto close_group = [&](int tile) {
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 4)      // diagnostic build: no candidate tracker (results are garbage, only the time is read)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { m1[rt] = __builtin_fmaxf(m1[rt], tpend[rt]); tpend[rt] = NEG_INF; }
+    return;
+#endif
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       if constexpr (TOP4)
@@ -253,6 +258,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     }
   };
   auto fold = [&](f32x16 (&d)[RT], int tile, bool closes) {
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 8)      // diagnostic build: no v_max3 fold
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) tpend[rt] = __builtin_fmaxf(tpend[rt], d[rt][0]);
+    if (closes) close_group(tile);
+    return;
+#endif
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) tpend[rt] = F16 ? max_tree(tpend[rt], d[rt]) : max_chain(tpend[rt], d[rt]);
     if (closes) close_group(tile);
@@ -300,7 +311,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
 
   for (int ch = 0; ch < nchunks; ++ch) {
     const int tile0 = t_begin + ch * CT;
+#if !(defined(GQHIP_ABL) && (GQHIP_ABL & 2))    // diagnostic build: no chunk staging (every chunk multiplies the first one)
     if (ch + 1 < nchunks) load_chunk(tile0 + CT);
+#endif
     const int nt = min(CT, t_full_end - tile0);
     const u32x4 *base = lds[ch & 1] + h * 32 + c;          // this lane's slot within a vector
     const u32x4 *nbase = lds[(ch + 1) & 1] + h * 32 + c;
@@ -315,8 +328,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         // this step's share of the next chunk's copy (stale registers after the last chunk: written, never read)
 #pragma unroll
         for (int r = 0; r < R4; ++r)
+#if !(defined(GQHIP_ABL) && (GQHIP_ABL & 2))
           if constexpr (TT < CT - 1)
             if (W0 + (r * WSTEPS) / R4 == TT) wdst[NT * r] = stage[r];
+#endif
         // hard fence: hipcc otherwise sinks these reads below the MFMAs of this step (seen in the ISA of the round-1 kernel:
         // every tile began with its own operand reads and lgkmcnt waits, the prefetch existed only in the source)
         __builtin_amdgcn_sched_barrier(0);
@@ -353,7 +368,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
+#if !(defined(GQHIP_ABL) && (GQHIP_ABL & 1))    // diagnostic build: no chunk barriers
         if constexpr (TT == CT - 2) __syncthreads();
+#endif
       };
       // one step per tile of the chunk, fully unrolled (the tags are compile-time constants)
       auto run_all = [&](auto... is) { (step(is), ...); };

@@ -14,6 +14,7 @@ this path (unet.py:342, :473) so the time-embedding projection is not created.
 from __future__ import annotations
 
 import math
+import os
 
 from typing import Sequence
 
@@ -477,7 +478,7 @@ FUSED_CONV_OUT = True      # decoder conv_out (128 -> 3) with norm_out + swish f
 CONV_F32 = True
 # every inference forward of Encoder / Decoder on a HIP device checks its weight-derived caches against a content hash of the
 # parameters (catches ``param.data`` writes, which bump no version counter); see _WeightGuard
-WEIGHT_GUARD = True
+WEIGHT_GUARD = os.environ.get("GQHIP_WEIGHT_GUARD", "1") != "0"   # (the env switch: A/B timing)
 DIRECT_CONV_OVER_F4 = False   # ... also where the alternative is F(4x4,3x3) (decoder, 256 channels at 128 x 128): A/B switch
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
 # written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
