@@ -67,7 +67,6 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) for real runs; gloo only to exercise the N>1 control flow on one GPU")
     ap.add_argument("--miopen-benchmark", type=int, default=int(os.environ.get("GQ_MIOPEN_BENCHMARK", "0")))
-    ap.add_argument("--miopen-db", type=int, default=0, help="1: use the shipped MIOpen find-db (implies find API, FAST mode)")
     ap.add_argument("--channels-last", type=int, default=int(os.environ.get("GQ_CHANNELS_LAST", "1")),
                     help="1: conv stack in torch channels_last (NHWC) -- MIOpen's fp32 igemm kernels run without the "
                          "NCHW<->NHWC transposes and the fused GroupNorm/bias kernels have NHWC variants (+8%)")
@@ -151,27 +150,6 @@ if __name__ == "__main__":
     if _early.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], _early.gpus))
 
-
-def _use_shipped_miopen_db():
-    """Point MIOpen at a private copy of the find-db/perf-db tuned for this workload on MI355X
-    (vq-vae-from-gaussian-vae_amd/miopen_db, produced by `bench.py --miopen-benchmark 1`): with
-    MIOPEN_FIND_MODE=FAST a hit returns the tuned solver at once and a miss falls back to the
-    immediate-mode heuristic, so there is no search at start-up.  Must run before torch loads MIOpen."""
-    import shutil
-    import tempfile
-
-    src = os.path.join(ROOT, "vq-vae-from-gaussian-vae_amd", "miopen_db")
-    if not os.path.isdir(src) or os.environ.get("MIOPEN_USER_DB_PATH"):
-        return
-    dst = tempfile.mkdtemp(prefix=f"gq_miopen_db_{os.environ.get('LOCAL_RANK', '0')}_")
-    for f in os.listdir(src):
-        shutil.copy(os.path.join(src, f), dst)
-    os.environ["MIOPEN_USER_DB_PATH"] = dst
-    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-
-
-if "--miopen-db" in sys.argv and sys.argv[sys.argv.index("--miopen-db") + 1] == "1":
-    _use_shipped_miopen_db()
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -383,7 +361,7 @@ def main():
     torch.cuda.set_device(device)
     # 0 = MIOpen immediate mode (measured: same steady-state img/s as find mode, 35 s vs 248 s of warm-up on a
     # fresh box); 1 = find mode like the reference's trainer.benchmark: True
-    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark) or bool(args.miopen_db)
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
 
     vae = build_model(device, cfg)
     g = torch.Generator().manual_seed(1000 + rank)

@@ -236,13 +236,10 @@ int wino_out_nhwc_f32(const float *M, float *y, int64_t B, int64_t H, int64_t W,
  * caller derives it from the GroupNorm that feeds the convolution: |SiLU(GN(x))| <= sqrt(n - 1) max|gamma| + max|beta|). */
 int wino_in_nhwc_f16x3(const float *x, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
                        void *stream);
-/* The 128-channel case (Cin = Cout = 128: the 256 x 256 level, where this GEMM is HBM-bound): V2 [16|36, tiles, 2C] fp16 =
- * [h | l] only (4 instead of 6 bytes per element) and wino_gemm_c128_f16x2 forms the three products itself on
- * v_mfma_f32_32x32x16_f16: M [P, tiles, 128] fp32 = V2 (x) U2t, U2t [P, 2, 128 n, 128 k] fp16 = (U_h^T, U_l^T) of U * u_scale.
- * Same splits, same products, same accumulation type as the K-concatenated library GEMM. */
+/* ... as V2 [16|36, tiles, 2C] fp16 = [h | l] only (4 instead of 6 bytes per element): the operand of wino_gemm_f16x2, which
+ * forms the three products itself. */
 int wino_in_nhwc_f16x2(const float *x, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int tile, float scale,
                        void *stream);
-int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, int64_t tiles, void *stream);
 /* The wider levels (Cin % 32 == 0, Cout % 128 == 0, tiles % 256 == 0; the SD3-UNet's 256- and 512-channel convolutions,
  * reference pit/modules/unet.py:142, :149): M [P, tiles, Cout] fp32 = V2 (x) U with Wf [P, Cin/16, Cout/32, 2, 64, 8] fp16 =
  * (U_h, U_l) of U * u_scale in MFMA operand order (lane (c, h) of column tile nt holds k = 16 chunk + 8 h .. + 7 of column
@@ -263,25 +260,17 @@ int wino_gemm_f16x2(const void *V2, const void *Wf, float *M, int64_t P, int64_t
  *                        Wf [Cin/16, 9, Cout/32, 2, 64, 8] fp16: operand-order weights -- chunk, tap ky*3+kx, column tile,
  *                        plane (h, l of w * u_scale), lane (n = 32 tile + lane%32, k-half lane/32), 8 input channels
  *                        16 chunk + 8 (lane/32) + e.
- *   conv3_split_gn_f16 + conv3x3_f16x3   the same in two steps, for inputs without a GroupNorm (stats NULL: plain split of
- *                        x * scale) or Cin % 32 != 0: Xs [B, Cin/16, H, W, 2, 16] fp16 = (h, l) of the activated, scaled
- *                        tensor; H*W % 16 == 0, Cin % 16 == 0. */
+ */
 int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                      const gqhip_gnstat_t *stats_in, int64_t groups_in, double eps, int apply_silu, float scale, const void *Wf,
                      const float *bias_or_null, const float *res_or_null, float *y, gqhip_gnstat_t *stats_out_or_null, int64_t B,
                      int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, float mscale, void *stream);
-int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *beta_or_null, const float *pre_bias_or_null,
-                       const gqhip_gnstat_t *stats_or_null, void *Xs, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
-                       double eps, int apply_silu, float scale, void *stream);
-int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
-                  gqhip_gnstat_t *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
-                  float mscale, void *stream);
 /* 1x1 convolution Cin -> Cout (128, 256, 512 or 1536 = the attention block's q | k | v) of a channels_last tensor = a GEMM over its B * HW pixels, fp16 x 3 as above
  * with the split of x done inside the kernel: the ResnetBlocks' nin_shortcut (reference pit/modules/unet.py:151-152) and the
  * attention block's proj_out (:203).  x [B * HW, Cin] fp32 (NOT normalised; + pre_bias[c], a bias still pending on it); the
  * power-of-two scale of x + pre_bias comes from
  * scales_dev = {scale, 1 / (scale * u_scale)} in device memory (f16_scales_from_gn_stats) or, when that is NULL, from the
- * `scale` / `mscale` arguments.  Wf [Cin/16, 1, Cout/32, 2, 64, 8] as for conv3x3_f16x3; y = x W * mscale + bias (+ res);
+ * `scale` / `mscale` arguments.  Wf [Cin/16, 1, Cout/32, 2, 64, 8] as for conv3x3_gn_f16x3; y = x W * mscale + bias (+ res);
  * stats_out optional.  HW % 256 == 0, Cin % 32 == 0. */
 int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf, const float *scales_dev_or_null, float scale,
                   float mscale, const float *bias_or_null, const float *res_or_null, float *y, gqhip_gnstat_t *stats_out_or_null, int64_t B, int64_t HW,
@@ -316,7 +305,7 @@ int conv3x3_gn_small_f32(const float *x, const float *gamma, const float *beta, 
 int wino_in_gn_nhwc_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                           const gqhip_gnstat_t *stats, void *V3, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                           double eps, int apply_silu, int tile, float scale, void *stream);
-/* ... writing the [h | l] operand of wino_gemm_c128_f16x2. */
+/* ... writing the [h | l] operand of wino_gemm_f16x2. */
 int wino_in_gn_nhwc_f16x2(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
                           const gqhip_gnstat_t *stats, void *V2, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
                           double eps, int apply_silu, int tile, float scale, void *stream);
@@ -350,25 +339,6 @@ int wino4_in_gn_nhwc_f32(const float *x, const float *gamma, const float *beta, 
                          const gqhip_gnstat_t *stats, float *V, int64_t B, int64_t H, int64_t W, int64_t C,
                          int64_t groups, double eps, int apply_silu, void *stream);
 
-/* Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (pit/modules/unet.py:69-73): src [B, H+1, W+1, 4*C] is the
- * padding-1 2x2 convolution of the LOW-resolution input with the four phase kernels stacked along the output channels
- * (phase (a, b) = sums of the 3x3 taps that fall on the same source pixel); y [B, 2H, 2W, C] NHWC,
- * y[b][2i+a][2j+b'][c] = src[b][i+a][j+b'][(2a+b')*C + c].  2.25x fewer conv flops than upsampling first. */
-int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C,
-                            const float *mscale_dev_or_null, void *stream);
-
-/* The 2x2 patches (padding 1) of an NHWC tensor x [B, H, W, C] as GEMM rows: A [B*(H+1)*(W+1), 4*C],
- * A[(b,p,q)][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c] (zero outside).  A x Wmat [4C, 4*Cout] is the `src` of
- * upconv_shuffle_nhwc_f32 (the phase convolution as one hipBLASLt GEMM). */
-int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64_t W, int64_t C, void *stream);
-
-/* The same patches as the operand of ONE fp16 GEMM whose K axis carries the three products of two-term fp16 splits (see
- * wino_in_nhwc_f16x3): A3 [B*(H+1)*(W+1), 3 * 4C] fp16 = [h | h | l] of x * scales_dev[0], times Wmat3 [3 * 4C, 4*Cout] =
- * [W_h; W_l; W_h] of Wmat * u_scale; upconv_shuffle_nhwc_f32 multiplies by mscale_dev = scales_dev + 1.  The scales are
- * DEVICE floats produced by f16_scales_from_gn_stats from the GroupNorm statistics [2 * n_bg] (sum, sum of squares per
- * (image, group)) that the producer of x left behind: bound = sqrt(max sum of squares) >= max|x| rigorously, no host sync. */
-int upconv_im2col_nhwc_f16x3(const float *x, void *A3, int64_t B, int64_t H, int64_t W, int64_t C,
-                             const float *scales_dev, void *stream);
 /* Single-head attention softmax(q k^T C^-1/2) v (reference pit/modules/unet.py:185-206: F.scaled_dot_product_attention on
  * [B, 1, L, C]) as two fp16 GEMMs with fp32 accumulation over K axes of two-term fp16 splits, fp32 results:
  *   attn_split_qkv_f16x3   qkv [B, L, 3C] fp32 (q | k | v per token) -> Q3 [B, L, 3C] = [q_h | q_h | q_l] of q * sq,

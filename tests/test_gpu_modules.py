@@ -580,9 +580,10 @@ def test_unet_with_and_without_fused_add_stats_agree():
     assert dz <= 1e-4 and dx <= 5e-4, (dz, dx)
 
 
-def test_subpixel_upsample_conv_matches_upsample_then_conv():
-    """Upsample (nearest x2 + conv3x3) as four 2x2 phase convolutions of the low-resolution input + pixel shuffle
-    == interpolate followed by the 3x3 conv (same math, different fp32 summation order)."""
+def test_upsample_fallback_route_matches_upsample_then_conv():
+    """Upsample at shapes the direct sub-pixel kernel does not tile (H % 8, W % 32, or no statistics on the input): libgqhip's
+    NHWC upsample copy + the ordinary convolution routes == interpolate followed by the 3x3 conv.  (The tiled shapes:
+    tests/test_gpu_round2.py::test_upconv2x_direct_matches_fp64.)"""
     import torch.nn.functional as F
     from pit_hip.modules import unet as U
 
@@ -591,17 +592,11 @@ def test_subpixel_upsample_conv_matches_upsample_then_conv():
         up = U.Upsample(ch).eval().to(DEV).to(memory_format=torch.channels_last)
         x = torch.randn(2, ch, H, W).to(DEV).contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
-            U.SUBPIXEL_UPCONV = True
             y, b = up(x)
-            U.SUBPIXEL_UPCONV = False
-            y0, b0 = up(x)
-            U.SUBPIXEL_UPCONV = True
             ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), up.conv.weight, up.conv.bias, 1, 1)
         assert y.shape == (2, ch, 2 * H, 2 * W) and y.is_contiguous(memory_format=torch.channels_last)
-        assert b is up.conv.bias and b0 is up.conv.bias
-        got = y + b[None, :, None, None]
-        assert torch.allclose(got, ref, atol=2e-5, rtol=1e-5), float((got - ref).abs().max())
-        assert torch.allclose(y, y0, atol=2e-5, rtol=1e-5)
+        got = y if b is None else y + b[None, :, None, None]
+        assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4), float((got - ref).abs().max())
 
 
 def test_winograd_conv3x3_matches_direct_conv():

@@ -239,3 +239,59 @@ def test_checksum_tensors_sees_every_word():
     a, b = ts[4][10].clone(), ts[4][11].clone()                            # a swap of two elements is seen too (position salt)
     ts[4][10], ts[4][11] = b, a
     assert _lib.checksum_tensors(table, out)[4] != base[4]
+
+
+# ------------------------------------------------------------------------------------------ checkpoint-shaped weights
+def _checkpoint_like_(module, seed):
+    """Re-draw the parameters of an Encoder / Decoder the way trained SD-VAE stacks look: GroupNorm
+    gamma in [0.05, 8] (log-uniform, a few at the ends), beta in +-3, conv weights with a 10^3 dynamic range across output
+    channels (per-channel log-uniform gains on the default init) and a few large biases."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.GroupNorm):
+                gam = torch.exp(torch.rand(m.weight.shape, generator=g) * (np.log(8.0) - np.log(0.05)) + np.log(0.05))
+                gam[0], gam[-1] = 8.0, 0.05
+                m.weight.copy_(gam.to(m.weight.device))
+                m.bias.copy_(((torch.rand(m.bias.shape, generator=g) * 2 - 1) * 3.0).to(m.bias.device))
+            elif isinstance(m, torch.nn.Conv2d):
+                gain = torch.exp((torch.rand(m.weight.shape[0], generator=g) * 2 - 1) * np.log(1000.0) / 2)   # 1e-1.5 .. 1e1.5
+                gain = gain / gain.mean()
+                # keep the layer's overall scale near the init's (a trained net is not exploding): normalise the RMS gain
+                gain = gain / float((gain ** 2).mean().sqrt())
+                m.weight.mul_(gain.to(m.weight.device)[:, None, None, None])
+                if m.bias is not None:
+                    m.bias.copy_((torch.randn(m.bias.shape, generator=g) * 0.3).to(m.bias.device))
+
+
+@pytest.mark.parametrize("which", ["encoder", "decoder"])
+def test_fp16x3_routes_hold_fp32_grade_accuracy_with_checkpoint_like_weights(which):
+    """The fp16 x 3 routes scale their operands by powers of two derived from RIGOROUS bounds (sqrt(n - 1) max|gamma| + max|beta|
+    for everything a GroupNorm feeds, row sums for the attention operands).  With seeded-random weights gamma = 1, beta = 0; a
+    checkpoint has gamma over two decades and beta of a few units, which makes those bounds ~10x looser and pushes the small
+    operands toward fp16's subnormal range.  Gate: the channels_last product path against the NCHW path of the same module
+    (ATen / MIOpen fp32 convolutions, no fp16 anywhere) and both against an fp64 run on the CPU -- the product path must be as
+    close to fp64 as the fp32 library path is (factor 2), at 1e-5 of the output scale."""
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(11)
+    if which == "encoder":
+        mod = U.Encoder(**FULL).eval()
+        x = torch.rand(1, 3, 256, 256) * 2 - 1
+    else:
+        mod = U.Decoder(**FULL).eval()
+        x = torch.randn(1, 16, 32, 32)
+    _checkpoint_like_(mod, 5)
+    with torch.no_grad():
+        ref = mod.double()(x.double())                    # fp64 on the CPU: the arbiter
+        mod = mod.float().to(DEV)
+        y_nchw = mod(x.to(DEV)).double().cpu()            # fp32 library route
+        mod = mod.to(memory_format=torch.channels_last)
+        y_cl = mod(x.to(DEV).contiguous(memory_format=torch.channels_last)).double().cpu()     # the product path
+    scale = float(ref.abs().max())
+    e_lib = float((y_nchw - ref).abs().max()) / scale
+    e_cl = float((y_cl - ref).abs().max()) / scale
+    print(f"{which}, checkpoint-like weights: |y| max {scale:.3g}; fp32 library route {e_lib:.2e}, fp16 x 3 product path {e_cl:.2e} of it")
+    assert torch.isfinite(y_cl).all()
+    assert e_cl <= max(2.0 * e_lib, 1e-5), (e_cl, e_lib)
+    assert e_cl <= 5e-5, e_cl

@@ -177,3 +177,19 @@ def test_torch_restatement_matches_reference_goldens():
     zt, it = T.gq1_forward(torch.from_numpy(z), torch.from_numpy(cb8), 8)
     zo, io = O.gq1_forward(z, cb8, 8)
     assert np.array_equal(it.numpy(), io) and np.array_equal(zt.numpy(), zo)
+
+
+def test_oracle_entry_points_under_asan_and_ubsan(tmp_path):
+    """`make -C oracle san` -- the C restatement + a driver over every entry point (120 shape
+    combinations: dims that are not multiples of 8, one row, one code, non-finite rows, ties) built with
+    -fsanitize=address,undefined and run on the CPU.  (The host half of libgqhip has the same kind of target:
+    `make -C vq-vae-from-gaussian-vae_amd/csrc san`, ~2 min, run on demand.)"""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("gq_oracle.c", "san_driver.c", "Makefile"):
+        shutil.copy(os.path.join(root, "oracle", f), tmp_path / f)
+    out = subprocess.run(["make", "-C", str(tmp_path), "san"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok: 120 shape combinations" in out.stdout, out.stdout + out.stderr

@@ -28,10 +28,6 @@ for cin in (128, 256):
         stats = _lib.gn_stats(x, 32)
         gn = (norm.weight, norm.bias, 32, 1e-6, True, stats, None)
         y, st = _lib.conv3x3_direct(x, wf, us, U._gn_act_bound(norm, x), gn=gn, residual=res, bias=conv.bias, stats_groups=32)
-        _lib.DIRECT_CONV_FUSED_SPLIT = False
-        y2, st2 = _lib.conv3x3_direct(x, wf, us, U._gn_act_bound(norm, x), gn=gn, residual=res, bias=conv.bias, stats_groups=32)
-        _lib.DIRECT_CONV_FUSED_SPLIT = True
-        print(f"Cin {cin}: fused-split kernel vs split + conv: bit-identical {bool(torch.equal(y, y2))}")
         xn = _lib.gn_apply(x, norm.weight, norm.bias, 32, 1e-6, True, stats)
         ref = torch.nn.functional.conv2d(xn.double(), conv.weight.double(), conv.bias.double(), 1, 1) + res.double()
         sc = torch.nn.functional.conv2d(xn.double().abs(), conv.weight.double().abs(), None, 1, 1)
@@ -53,27 +49,9 @@ for (cin, cout, H) in ((128, 128, 256), (256, 128, 256), (256, 256, 128), (128, 
         stats = _lib.gn_stats(x, 32)
         gn = (norm.weight, norm.bias, 32, 1e-6, True, stats, None)
         bound = U._gn_act_bound(norm, x)
-        _lib.DIRECT_CONV_FUSED_SPLIT = False
-        t_all = timed(lambda: _lib.conv3x3_direct(x, wf, us, bound, gn=gn, residual=res, bias=conv.bias, stats_groups=32))
-        L = _lib.lib(); S = torch.cuda.current_stream().cuda_stream
-        xs = torch.empty((16, cin // 16, H, H, 2, 16), dtype=torch.float16, device=dev)
-        t_split = timed(lambda: _lib._check(L.conv3_split_gn_f16(x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), None,
-                        stats.data_ptr(), xs.data_ptr(), 16, H, H, cin, 32, 1e-6, 1, 64.0, S), "split"))
         flops = 2.0 * 16 * H * H * 9 * cin * cout * 3
-        y = torch.empty_like(res); ost = torch.empty(2 * 16 * 32, dtype=torch.float64, device=dev)
-        def run_conv(r, st_):
-            _lib._check(L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), conv_b, r, y.data_ptr(), st_, 16, H, H, cin, cout, 32,
-                                             1.0, S), "conv")
-        cb = torch.zeros(cout, device=dev); conv_b = cb.data_ptr()
-        t_full = timed(lambda: run_conv(res.data_ptr(), ost.data_ptr()))
-        t_nores = timed(lambda: run_conv(None, ost.data_ptr()))
-        t_bare = timed(lambda: run_conv(None, None))
-        _lib.DIRECT_CONV_FUSED_SPLIT = True
         t_fused = timed(lambda: _lib.conv3x3_direct(x, wf, us, bound, gn=gn, residual=res, bias=conv.bias, stats_groups=32))
-        yf, _ = _lib.conv3x3_direct(x, wf, us, bound, gn=gn, residual=res, bias=conv.bias, stats_groups=32)
-        _lib.DIRECT_CONV_FUSED_SPLIT = False
-        y2, _ = _lib.conv3x3_direct(x, wf, us, bound, gn=gn, residual=res, bias=conv.bias, stats_groups=32)
-        print(f"{cin}->{cout} {H}^2: ONE kernel (GroupNorm + split fused) {t_fused:.0f} us = {flops/t_fused/1e6:.0f} TFLOP/s executed; "
-              f"max diff vs two kernels {float((yf - y2).abs().max()):.1e}")
-        print(f"{cin}->{cout} {H}^2: split {t_split:.0f} us; conv + residual + stats {t_full:.0f} us = {flops/t_full/1e6:.0f} TFLOP/s executed; "
-              f"without residual {t_nores:.0f}; without statistics too {t_bare:.0f}; split + conv {t_all:.0f} us", flush=True)
+        t_nores = timed(lambda: _lib.conv3x3_direct(x, wf, us, bound, gn=gn, bias=conv.bias, stats_groups=32))
+        t_bare = timed(lambda: _lib.conv3x3_direct(x, wf, us, bound, gn=gn))
+        print(f"{cin}->{cout} {H}^2: GroupNorm + split + conv + residual + stats {t_fused:.0f} us = {flops/t_fused/1e6:.0f} TFLOP/s executed; "
+              f"without residual {t_nores:.0f}; without statistics too {t_bare:.0f}", flush=True)

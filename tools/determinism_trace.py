@@ -91,7 +91,7 @@ def main():
         vae = bench.build_model(dev, bench.CONFIGS[args.config]).to(memory_format=torch.channels_last)
     for n in ("gn_silu", "add_bias", "add_bias_stats", "gn_apply", "gn_stats", "wino_conv3x3", "attention_f16x3",
               "conv3x3_direct", "conv1x1_direct", "conv3x3s2_direct", "upconv2x_direct", "conv3x3_gn_small", "conv3x3_f32",
-              "upconv_im2col", "f16_scales", "upconv_shuffle", "upsample2x_nhwc"):
+              "f16_scales", "upsample2x_nhwc"):
         wrap(_lib, n, "_lib." + n)
     wrap(F, "conv2d", "F.conv2d")
     for n in ("mm", "bmm", "matmul", "addmm", "softmax"):

@@ -32,7 +32,6 @@ def main():
     ap.add_argument("--defer-bias", type=int, default=1)
     ap.add_argument("--attn-math", type=int, default=1)
     ap.add_argument("--add-stats", type=int, default=1)
-    ap.add_argument("--subpixel", type=int, default=1)
     ap.add_argument("--winograd", type=int, default=1)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -41,7 +40,6 @@ def main():
     unet.DEFER_BIAS = bool(a.defer_bias)
     unet.ATTN_MATH = bool(a.attn_math)
     unet.FUSED_ADD_STATS = bool(a.add_stats)
-    unet.SUBPIXEL_UPCONV = bool(a.subpixel)
     unet.WINOGRAD = bool(a.winograd)
     torch.backends.cudnn.benchmark = False
     vae = bench.build_model(dev, bench.CONFIGS["gq_0.25"])
@@ -57,7 +55,7 @@ def main():
         te, z = timed(lambda: vae.encoder(x), a.iters)
         tq, (zh, info) = timed(lambda: vae.regularization(z), a.iters * 4)
         td, _ = timed(lambda: vae.decoder(zh), a.iters)
-    print(f"channels_last={a.channels_last} fused_gn={a.fused_gn} defer_bias={a.defer_bias} attn_math={a.attn_math} add_stats={a.add_stats} subpixel={a.subpixel} winograd={a.winograd} batch={a.batch}: encoder {te:.1f} ms, quantiser {tq:.3f} ms, "
+    print(f"channels_last={a.channels_last} fused_gn={a.fused_gn} defer_bias={a.defer_bias} attn_math={a.attn_math} add_stats={a.add_stats} winograd={a.winograd} batch={a.batch}: encoder {te:.1f} ms, quantiser {tq:.3f} ms, "
           f"decoder {td:.1f} ms -> {a.batch / (te + tq + td) * 1e3:.1f} img/s (stage sum)")
 
 

@@ -11,19 +11,15 @@
 // splits (h + l, 22 bits) of the scaled fp32 values, the three products h W_h + h W_l + l W_h accumulate in fp32 --
 // without Winograd's transform amplification.
 //
-// Two kernels:
-//   conv3_split_gn_kernel   x fp32 NHWC -> SiLU(GroupNorm(x + pre_bias)) * scale, split, as
-//                           Xs [B][Cin/16][H][W][2][16] fp16 (chunk-major: a block's 34-pixel patch row of one 16-channel
-//                           chunk is 2176 contiguous bytes);
-//   conv3x3_f16x3_kernel  block = 8 x 32 output pixels x 128 output channels, 4 waves (wave = 4 rows x 64 channels:
-//                           eight 32 x 32 accumulator tiles).  Per 16-channel chunk the 10 x 34-pixel patch (h and l
-//                           planes, 21.8 KB) is staged in LDS, double buffered, 32 bytes per pixel and plane with the two
-//                           16-byte halves swapped on odd groups of 8 pixels (any 16 consecutive pixels then hit 64
-//                           different banks with ds_read_b128); each of the 9 taps is one MFMA k-step whose A operand is
-//                           the patch shifted by (dy, dx) -- 8 LDS reads for 24 MFMAs per wave.  The weights, laid out in
-//                           operand order ([chunk][tap][column tile][plane][lane][8]), come straight from L2 into
-//                           registers, two k-steps ahead (three register sets): a wave's load is 1 KB contiguous.
-//                           Epilogue: * mscale + bias (+ residual), store, GroupNorm statistics of the result.
+// conv3x3_gn_f16x3_kernel: block = 8 x 32 output pixels x 128 output channels, 4 waves (wave = 4 rows x 64 channels: eight
+// 32 x 32 accumulator tiles).  Per 16-channel chunk the 10 x 34-pixel patch of the fp32 input is normalised (GroupNorm), activated
+// (SiLU), scaled and split on its way into LDS (h and l planes, 21.8 KB, double buffered, 32 bytes per pixel and plane with the
+// two 16-byte halves swapped on odd groups of 8 pixels: any 16 consecutive pixels then hit 64 different banks with ds_read_b128);
+// each of the 9 taps is one MFMA k-step whose A operand is the patch shifted by (dy, dx) -- 8 LDS reads for 24 MFMAs per wave.
+// The weights, laid out in operand order ([chunk][tap][column tile][plane][lane][8]), come straight from L2 into registers, two
+// k-steps ahead (three register sets): a wave's load is 1 KB contiguous.  Epilogue: * mscale + bias (+ residual), store,
+// GroupNorm statistics of the result.  (Round 2's two-kernel form -- a split pass + a convolution of the pre-split tensor --
+// was never selected at a BASELINE shape and is gone: profiles/r03/route_table.txt.)
 #pragma once
 #include <type_traits>
 
@@ -147,86 +143,6 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3Params &p, const Conv3
 #define GQ_C3_ZERO_ACC(acc)                                                                                         \
   _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[rr][j] =       \
       f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
-
-// ---- input = the pre-split tensor Xs (conv3_split_gn_kernel) ----
-template <int COUT>
-__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const Conv3Params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char sA[2][kC3Buf];
-  __shared__ int64_t red[kStatWords * 32];   // statistics records of the block's <= 32 groups (gq_stats.h)
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  Conv3Tile t;
-  if (!conv3_tile(p, t)) return;
-  const int H = p.H, W = p.W;
-  red[tid] = 0;   // kStatWords * 32 = 256 words
-
-  // loader bookkeeping: piece j = tid + 256 i -> (patch row, pixel, plane, half)
-  int goff[kC3Loads], loff[kC3Loads];
-  unsigned inb = 0;
-#pragma unroll
-  for (int i = 0; i < kC3Loads; ++i) {
-    int j = tid + 256 * i;
-    const bool live = j < kC3Pieces;
-    j = live ? j : kC3Pieces - 1;
-    const int R = j / (4 * kC3PW), rem = j % (4 * kC3PW), px = rem >> 2, part = rem & 3;
-    const int gy = t.y0 - 1 + R, gx = t.x0 - 1 + px;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-    goff[i] = (cy * W + cx) * 32 + part * 8;                    // halfs, within one (image, chunk) plane pair
-    loff[i] = live ? (part >> 1) * kC3Plane + conv3_lds_off(R, px, part & 1) : -1;
-    inb |= (unsigned)(in ? 1 : 0) << i;
-  }
-  int aoff[3];
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx) aoff[dx] = conv3_lds_off(4 * wm, c + dx, h);
-  const long chunk_stride = (long)H * W * 32;
-  const _Float16 *xb = p.Xs + t.b * p.nch * chunk_stride;
-  f16x8 st[kC3Loads];
-  auto issue = [&](int chunk) {
-    const _Float16 *src = xb + chunk * chunk_stride;
-#pragma unroll
-    for (int i = 0; i < kC3Loads; ++i) st[i] = *reinterpret_cast<const f16x8 *>(src + goff[i]);
-  };
-  auto commit = [&](int buf) {
-    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < kC3Loads; ++i)
-      if (loff[i] >= 0) *reinterpret_cast<f16x8 *>(&sA[buf][loff[i]]) = ((inb >> i) & 1) ? st[i] : zero;
-  };
-
-  f32x16 acc[4][2];
-  GQ_C3_ZERO_ACC(acc);
-  // weights of k-step ks = chunk * 9 + tap, column tiles 2 wn and 2 wn + 1, planes h / l: 4 operands of 1 KB per wave
-  const f16x8 *wsrc = reinterpret_cast<const f16x8 *>(p.Wf) + (4 * t.nb + 2 * wn) * 128 + lane;
-  f16x8 bq[4], bn[4];   // [2 j + plane]
-  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
-    const f16x8 *s = wsrc + (long)ks * (p.nnb * 512);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dst[k] = s[k * 64];
-  };
-  const int nks = p.nch * 9;
-  load_b(0, bq);
-  issue(0);
-  commit(0);
-  __syncthreads();
-
-  for (int chunk = 0; chunk < p.nch; ++chunk) {
-    if (chunk + 1 < p.nch) issue(chunk + 1);
-    const unsigned char *A = sA[chunk & 1];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ks = chunk * 9 + tap;
-      load_b(ks + 1 < nks ? ks + 1 : ks, bn);
-      conv3_tap(A + aoff[tap % 3], tap / 3, bq, acc);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) bq[k] = bn[k];
-      __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting the LDS reads of later taps (spills otherwise)
-    }
-    if (chunk + 1 < p.nch) commit((chunk + 1) & 1);
-    __syncthreads();
-  }
-  conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
-}
 
 // ---- input = the fp32 tensor itself: SiLU(GroupNorm(x + pre_bias)) * scale and the fp16 split happen on the way into
 //      LDS (no Xs: saves writing and re-reading 4 bytes per element and a launch).  A chunk is 16 channels = 64 bytes of
@@ -368,56 +284,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
 // epilogue that nothing overlaps in that design (the main loop itself ran at 1.7 PFLOP/s); loaders alone 737 us -- four
 // loader waves per CU are as slow as the multipliers; both together 1032 us.  Two combined-role blocks per CU overlap one
 // block's epilogue with the other's main loop for free, which is worth more here than the cleaner instruction streams.
-
-// SiLU(GroupNorm(x + pre_bias)) * scale as the chunk-major two-term fp16 split the convolution kernel stages.
-// thread -> (pixel, 4 channels): lanes = 4 channel quads of a chunk (fastest) x 16 pixels; a wave writes 2 x 512 bytes
-// interleaved into one contiguous KiB.  `stats` null: no normalisation (plain split of x * scale).
-template <int SILU>
-__global__ __launch_bounds__(256) void conv3_split_gn_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
-                                                             const float *__restrict__ beta,
-                                                             const float *__restrict__ pre_bias,
-                                                             const int64_t *__restrict__ stats, _Float16 *__restrict__ Xs,
-                                                             long HW, int C, int cpg, double eps, float scale, long total) {
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  const int nch = C / 16, groups = C / cpg;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const int within = (int)(t & 3), pl = (int)((t >> 2) & 15);
-    const long u = t >> 6;
-    const int chunk = (int)(u % nch);
-    const long pix = (u / nch) * 16 + pl;          // over B * HW
-    const long b = pix / HW, pi = pix % HW;
-    const int c0 = chunk * 16 + within * 4;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * C + c0);
-    if (stats) {
-      const int g = c0 / cpg;
-      const double n = (double)cpg * (double)HW;
-      double st_s, st_ss;
-      stat_load(stats + kStatWords * (b * groups + g), st_s, st_ss);
-      const double mean = st_s / n;
-      double var = st_ss / n - mean * mean;
-      var = var > 0.0 ? var : 0.0;
-      const double rstd = 1.0 / sqrt(var + eps);
-      f32x4 a, sh;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const double pbk = pre_bias ? (double)pre_bias[c0 + k] : 0.0;
-        a[k] = (float)(rstd * (double)gamma[c0 + k]);
-        sh[k] = (float)((double)beta[c0 + k] + (pbk - mean) * rstd * (double)gamma[c0 + k]);
-      }
-      v = gn_act<SILU>(v, a, sh);
-    }
-    v = v * scale;
-    f16x4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      hi[e] = (_Float16)v[e];
-      lo[e] = (_Float16)(v[e] - (float)hi[e]);
-    }
-    _Float16 *dst = Xs + (((b * nch + chunk) * HW + pi) * 2) * 16 + within * 4;
-    *reinterpret_cast<f16x4 *>(dst) = hi;
-    *reinterpret_cast<f16x4 *>(dst + 16) = lo;
-  }
-}
 
 // ---- 1x1 convolution Cin -> 128 / 256 channels (the ResnetBlocks' nin_shortcut, unet.py:151-152; the attention block's
 // proj_out, unet.py:203) = a GEMM over the pixels, same fp16 x 3 scheme, the split of x done on the way into LDS.  MIOpen

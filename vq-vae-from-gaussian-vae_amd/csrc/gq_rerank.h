@@ -533,8 +533,19 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   }
   // level 1: the block's RPB consecutive rows leave as contiguous runs (BCHW: along l per channel)
   if (sub == 0) s_best[slot] = decided ? best_i : -1;
-  if (p.zhat && decided)
-    for (int i = sub; i < DIM; i += GROUP) s_zhat[slot][i] = p.cb[(long)best_i * DIM + i];
+  if (p.zhat && decided) {
+    // the winner's code row is almost always still in a lane's registers (nb: the lane's best code of pass 1): no second
+    // round trip to the codebook for zhat.  Otherwise (the winner came out of the rare second scan) it is loaded.
+    const unsigned long long holders = group_bits(codeb == best_i && codeb >= 0);
+    if (holders != 0ull) {
+      if (sub == __builtin_ctzll(holders)) {
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) s_zhat[slot][i] = nb[i];
+      }
+    } else {
+      for (int i = sub; i < DIM; i += GROUP) s_zhat[slot][i] = p.cb[(long)best_i * DIM + i];
+    }
+  }
   __syncthreads();
   const long row0 = (long)vblock * RPB;
   if (threadIdx.x < RPB) {

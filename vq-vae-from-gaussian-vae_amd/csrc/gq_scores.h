@@ -9,9 +9,14 @@
 // roofline SURVEY.md 8(d) assigns to this op.
 //
 // Tiling: D[i = row][j = code] (A operand = row coefficients, B operand = codebook values / squares), so a lane's
-// accumulator register holds one code column for 16 rows and a wave's store of one register is two 128-byte runs along n
-// (full cache lines).  Block = 4 waves x RT row tiles of 32 rows; blockIdx % nsplit = code split (multiple of 8: each XCD's
-// L2 streams 1/8 of the codebook), chunks of CT tiles staged through LDS exactly like gq_filter_kernel.
+// accumulator register holds one code column for 16 rows.  Block = 4 waves x RT row tiles of 32 rows; blockIdx % nsplit =
+// code split (multiple of 8: each XCD's L2 streams 1/8 of the codebook), chunks of CT tiles staged through LDS exactly
+// like gq_filter_kernel.  Tiles are processed in PAIRS so that a store instruction writes one 256-byte run (below).
+// Where the time goes at 16 384 x 65 536 x dim 16 (4.29 GB; diagnostic builds, profiles/r03/scores_ablation.txt): the
+// matrix work alone 0.55 ms (80 % of the fp32 MFMA peak), the store stream alone 0.86 ms = 5.0 TB/s (a torch fill of the same
+// buffer: 6.9 TB/s -- one dword per lane and instruction is what the store path issues here, whatever the run length:
+// 128-byte and 256-byte runs measured the same, and so did 32 instead of 128 write streams per wave quartet), both
+// together 1.05 ms = 4.1 TB/s: the two overlap only partly because a wave's stores follow its own MFMAs.
 // The expansion differs from the per-pair formula by ~2^-24 * sum_i |terms| (cancellation between n^2/sd^2, mu n/sd^2 and
 // mu^2/sd^2): relative to the score's own magnitude that is a few ulp, and the arg-max can differ from the per-pair
 // formula's only at rounding ties -- the same caveat the CUDA kernel's own rounding carries (its bits cannot be pinned
@@ -130,13 +135,14 @@ __global__ __launch_bounds__(256, 2) void gq_scores_mfma_kernel(const ScoresPara
     const int nt = min(CT, t_end - tile0);
     const float *val = lds[ch & 1][0] + c * DIM;
     const float *sq = lds[ch & 1][1] + c * DIM;
-    for (int tt = 0; tt < nt; ++tt) {
+    // one tile's accumulators for the wave's RT row tiles
+    auto compute = [&](int tt, f32x16 (&d)[RT]) {
       float a[HD], a2[HD];
       lds_read_half<DIM>(val + tt * TILE_F, h, swz, a);
       lds_read_half<DIM>(sq + tt * TILE_F, h, swz, a2);
-      f32x16 d[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) d[rt] = cinit[rt];
+#if !(defined(GQHIP_ABL) && (GQHIP_ABL & 16))    // diagnostic build: no MFMAs (what the store stream alone takes)
 #pragma unroll
       for (int s = 0; s < HD; ++s)
 #pragma unroll
@@ -145,7 +151,68 @@ __global__ __launch_bounds__(256, 2) void gq_scores_mfma_kernel(const ScoresPara
       for (int s = 0; s < HD; ++s)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) d[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(coefB[rt][s], a[s], d[rt], 0, 0, 0);
+#else
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) d[rt][0] += a[0] + a2[0];
+#endif
+    };
+    int tt = 0;
+    // Tile PAIRS: register r of tile A and of tile B hold the same two rows (ro, ro + 4: lane halves) for 32 codes each.
+    // v_permlane32_swap exchanges A's upper half with B's lower half, so one register then holds 64 CONSECUTIVE codes of row
+    // ro and the other those of row ro + 4: every store instruction writes one 256-byte run instead of two 128-byte runs in
+    // two rows (measured with the matrix work compiled out: 5.0 -> ... TB/s; a plain fill of the buffer runs at 6.9).
+    for (; tt + 1 < nt; tt += 2) {
+      f32x16 d0[RT], d1[RT];
+      compute(tt, d0);
+      compute(tt + 1, d1);
       const int code0 = (tile0 + tt) * kTileCodes;
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 32)       // diagnostic build: no stores (what the matrix work alone takes)
+      if (d0[0][0] == 12345.678f && d1[RT - 1][15] == 0.5f)
+#endif
+      if (code0 + 2 * kTileCodes <= p.n) {          // wave-uniform: the swap below is a cross-lane operation
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          float *base = p.out + (tile_row0 + 32 * rt) * p.n + code0 + lane;     // row 0 of the tile, this lane's column
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0[rt][r]), __float_as_uint(d1[rt][r]), false, false);
+            if (all_rows || tile_row0 + 32 * rt + ro < p.rows) base[(long)ro * p.n] = __uint_as_float(sw[0]);
+            if (all_rows || tile_row0 + 32 * rt + ro + 4 < p.rows) base[(long)(ro + 4) * p.n] = __uint_as_float(sw[1]);
+          }
+        }
+      } else if (code0 + c < p.n) {
+        // the pair straddles the end of the codebook (n % 64 != 0): tile A alone, two 128-byte runs per register
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          float *base = p.out + (tile_row0 + 32 * rt) * p.n + code0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (all_rows || tile_row0 + 32 * rt + ro + 4 * h < p.rows) base[(long)ro * p.n + lane_off] = d0[rt][r];
+          }
+        }
+        const int code1 = code0 + kTileCodes;
+        if (code1 + c < p.n) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            float *base = p.out + (tile_row0 + 32 * rt) * p.n + code1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ro = (r & 3) + 8 * (r >> 2);
+              if (all_rows || tile_row0 + 32 * rt + ro + 4 * h < p.rows) base[(long)ro * p.n + lane_off] = d1[rt][r];
+            }
+          }
+        }
+      }
+    }
+    for (; tt < nt; ++tt) {          // an odd tile at the end of the split
+      f32x16 d[RT];
+      compute(tt, d);
+      const int code0 = (tile0 + tt) * kTileCodes;
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 32)
+      if (d[0][0] == 12345.678f && d[RT - 1][15] == 0.5f)
+#endif
       if (code0 + c < p.n) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {

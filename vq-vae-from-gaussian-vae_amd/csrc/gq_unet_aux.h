@@ -603,48 +603,6 @@ __global__ __launch_bounds__(256) void wino_out_res_nhwc_kernel(const float *__r
   for (int w = threadIdx.x; w < kStatWords * groups; w += 256) stat_flush_word(stats + kStatWords * (b * groups) + w, red[w]);
 }
 
-// im2col of the 2x2 phase convolution (padding 1) of an NHWC tensor: A[b][p][q][(2u+v)*C + c] = x[b][p+u-1][q+v-1][c]
-// (zero outside), p in [0, H], q in [0, W].  One thread per (patch position, tap, channel quad).
-// F16X3: the patches as the operand of ONE fp16 GEMM over a K axis carrying the three products of two-term fp16 splits
-// (see wino_store_v): A3 [rows][3 * 4C] fp16 = [h | h | l] of x * scales[0]; the scale lives in DEVICE memory
-// (f16_scales_from_stats_kernel derives it from the GroupNorm statistics the producer left behind: no host sync).
-template <bool F16X3>
-__global__ __launch_bounds__(256) void upconv_im2col_nhwc_kernel(const float *__restrict__ x, void *__restrict__ A,
-                                                                 int H, int W, int C4, long total,
-                                                                 const float *__restrict__ scales) {
-  const float scale = F16X3 ? scales[0] : 1.0f;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const int q4 = (int)(t % C4);
-    long r = t / C4;
-    const int tap = (int)(r & 3);
-    r >>= 2;
-    const int q = (int)(r % (W + 1));
-    r /= W + 1;
-    const int p = (int)(r % (H + 1));
-    const long b = r / (H + 1);
-    const int sy = p + (tap >> 1) - 1, sx = q + (tap & 1) - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = reinterpret_cast<const f32x4 *>(x)[((b * H + sy) * W + sx) * C4 + q4];
-    if constexpr (F16X3) {
-      v = v * scale;
-      f16x4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        h[e] = (_Float16)v[e];
-        l[e] = (_Float16)(v[e] - (float)h[e]);
-      }
-      const long row = t / (4L * C4);                 // patch position
-      const int col = (int)(t % (4L * C4));           // (tap, channel quad) within the 4C patch
-      f16x4 *o = reinterpret_cast<f16x4 *>(A) + row * (12L * C4) + col;
-      o[0] = h;
-      o[4 * C4] = h;
-      o[8 * C4] = l;
-    } else {
-      reinterpret_cast<f32x4 *>(A)[t] = v;
-    }
-  }
-}
-
 // scales[0] = v_scale = the largest power of two with amp * bound * v_scale <= 32768, bound = sqrt(max over (image,
 // group) of the sum of squares) >= max|x| (rigorous: the L2 norm of a group bounds its largest element), from the
 // GroupNorm statistics [2 * n_bg] (sum, sum of squares) the producer of x left behind; scales[1] = 1 / (v_scale * u_scale),
@@ -673,28 +631,6 @@ __global__ __launch_bounds__(64) void f16_scales_from_stats_kernel(const int64_t
     const float vs = (float)ldexp(1.0, e);
     scales[0] = vs;
     scales[1] = (float)(1.0 / ((double)vs * (double)u_scale));
-  }
-}
-
-// Pixel shuffle of the sub-pixel form of "nearest x2 upsample, then 3x3 conv" (unet.py:69-73): the four output phases
-// (a, b) = (oy & 1, ox & 1) are 2x2 convolutions of the LOW-resolution input (weights = sums of the 3x3 taps that fall
-// on the same source pixel); one conv computes all four as 4*C output channels on an (H+1) x (W+1) grid (padding 1),
-//   y[b][2i+a][2j+b'][c] = src[b][i+a][j+b'][(2a+b')*C + c].   NHWC, one thread per (output pixel, channel quad).
-// `mscale_dev` (device pointer or NULL): y = *mscale_dev * src (the f16x3 GEMM's result on scaled operands).
-__global__ __launch_bounds__(256) void upconv_shuffle_nhwc_kernel(const float *__restrict__ src, float *__restrict__ y,
-                                                                  int H, int W, int C4, long total,
-                                                                  const float *__restrict__ mscale_dev) {
-  const float mscale = mscale_dev ? *mscale_dev : 1.0f;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const int q = (int)(t % C4);
-    long p = t / C4;
-    const int ox = (int)(p % (2 * W));
-    p /= 2 * W;
-    const int oy = (int)(p % (2 * H));
-    const long b = p / (2 * H);
-    const int a = oy & 1, bb = ox & 1;
-    const long sp = (b * (H + 1) + (oy >> 1) + a) * (W + 1) + (ox >> 1) + bb;   // source pixel
-    reinterpret_cast<f32x4 *>(y)[t] = reinterpret_cast<const f32x4 *>(src)[sp * (4L * C4) + (2 * a + bb) * C4 + q] * mscale;
   }
 }
 

@@ -1,127 +1,13 @@
-// gq_wino_gemm.h -- the Winograd batched GEMM of the 128-channel convolutions (256 x 256 level of the SD3-UNet,
-// pit/modules/unet.py:142, :149): M[p] = V[p] x U[p] for the 16 / 36 tile positions p, [tiles, 128] x [128, 128].
-//
-// At K = N = 128 this GEMM is HBM-bound (2 * 128 flops per 8 bytes moved): the library route -- V3 = [h | h | l] fp16, one
-// hipBLASLt GEMM with K' = 384 -- moves 6 bytes per V element and reaches ~3.5 TB/s.  This kernel reads V2 = [h | l]
-// (4 bytes per element: the two-term fp16 split of V * scale, written by the input transforms in F16X2 mode) and forms
-// the three products  h U_h + h U_l + l U_h  itself on v_mfma_f32_32x32x16_f16 (fp32 accumulation): 18 instead of 22.5
-// bytes per element through the GEMM, 9 instead of 13.5 out of the input transform, same numerics as the K-concatenated
-// library GEMM (same splits, same products).
-//
-// Block = 4 waves, ONE tile position p and a contiguous range of rows.  U_h^T and U_l^T of the position (k contiguous per
-// output column: the MFMA's B operand is 8 consecutive k of one column) sit in LDS for the whole block (2 x 128 rows of
-// 272 bytes: the 16-byte pad makes every ds_read_b128 lane group hit 64 different banks); each wave walks 32-row tiles:
-// A operands (8 consecutive k of one row per lane) come straight from global memory -- every byte of V2 is used exactly
-// once, its 128-byte lines are consumed over four consecutive k-steps out of L1 --, double buffered in registers;
-// 96 MFMAs per tile (4 column tiles x 8 k-steps x 3 products) against 32 KiB of HBM traffic: a quarter of the time the
-// memory system needs for it, so nothing about the MFMA schedule matters here.  D layout: lane (c, h), register r holds
-// row (r & 3) + 8 (r >> 2) + 4 h of the tile, column c of the column tile: a store of one register is two 128-byte runs.
-// (Measured alternative: operands swapped so that a lane owns a row and leaves 16-byte stores, 32 row-scattered pieces
-// per instruction: 564 vs 501 us at 36 x 65 536 tiles -- the 4-byte stores in full 128-byte runs are the better pattern.)
-// Alone the kernel runs at 4.8-5.0 TB/s (tools/wino_gemm_bench.py); the grid is one co-resident round of blocks.
+// gq_wino_gemm.h -- the Winograd batched GEMMs of the 256- / 512-channel levels on the [h | l] operand (two-term fp16 split of
+// V * scale, written by the input transforms in F16X2 mode: 4 instead of 6 bytes per element of V): the three products
+// h U_h + h U_l + l U_h are formed in the kernel on v_mfma_f32_32x32x16_f16 (fp32 accumulation) -- the numerics of the
+// K-concatenated library GEMM over [h | h | l] (same splits, same products).
 #pragma once
 #include "gq_common.h"
 
 namespace gqhip {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-struct WinoGemmParams {
-  const _Float16 *V2;   // [P][tiles][256]  (h[0..128) | l[0..128)) of V * v_scale
-  const _Float16 *U2t;  // [P][2][128 n][128 k]  (U_h^T, U_l^T) of U * u_scale
-  float *M;             // [P][tiles][128]
-  long tiles;
-  int rows_per_block;   // multiple of 128
-  int blocks_per_pos;
-};
-
-constexpr int kWgPad = 136;   // halfs per LDS row (128 + 8): 272 bytes
-
-__global__ __launch_bounds__(256, 2) void wino_gemm_c128_f16x2_kernel(const WinoGemmParams p) {
-  __shared__ __attribute__((aligned(16))) _Float16 sB[2][128][kWgPad];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 31, h = lane >> 5;
-  const int pos = blockIdx.x / p.blocks_per_pos, chunk = blockIdx.x % p.blocks_per_pos;
-
-  // ---- U_h^T, U_l^T of this position -> LDS (2 x 128 x 128 halfs = 4096 16-byte pieces) ----
-  {
-    const f16x8 *src = reinterpret_cast<const f16x8 *>(p.U2t + (long)pos * 2 * 128 * 128);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = tid + 256 * r;              // piece index: plane (q >> 11), row n ((q >> 4) & 127), k-group (q & 15)
-      const f16x8 v = src[q];
-      *reinterpret_cast<f16x8 *>(&sB[q >> 11][(q >> 4) & 127][(q & 15) * 8]) = v;
-    }
-  }
-  __syncthreads();
-
-  const long row_begin = (long)chunk * p.rows_per_block;
-  const long row_end = row_begin + p.rows_per_block < p.tiles ? row_begin + p.rows_per_block : p.tiles;
-  const _Float16 *Vp = p.V2 + (long)pos * p.tiles * 256;
-  float *Mp = p.M + (long)pos * p.tiles * 128;
-
-  auto load_a = [&](long tile_row0, f16x8 (&ah)[8], f16x8 (&al)[8]) {
-    long row = tile_row0 + c;
-    row = row < p.tiles ? row : p.tiles - 1;
-    const f16x8 *src = reinterpret_cast<const f16x8 *>(Vp + row * 256);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      ah[ks] = src[2 * ks + h];                 // k = 16 ks + 8 h .. + 7 of the h part
-      al[ks] = src[16 + 2 * ks + h];            // ... of the l part
-    }
-  };
-
-  f16x8 ah[8], al[8];
-  long t0 = row_begin + (long)wave * 32;
-  if (t0 < row_end) load_a(t0, ah, al);
-  for (; t0 < row_end; t0 += 128) {
-    f16x8 nh[8], nl[8];
-    const long tn = t0 + 128;
-    if (tn < row_end) load_a(tn, nh, nl);       // next tile's operands in flight during this tile's MFMAs
-    const bool full = t0 + 32 <= p.tiles;
-    // two passes of 64 output columns: 32 accumulator registers and 4 B-operand reads per k-step live at a time (the
-    // A operands of the tile stay in registers for both passes); sched_barrier keeps hipcc from hoisting every LDS read
-    // of a pass to its top (that spilled 222 registers)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      f32x16 acc[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        f16x8 bh[2], bl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          bh[j] = *reinterpret_cast<const f16x8 *>(&sB[0][(2 * half + j) * 32 + c][ks * 16 + h * 8]);
-          bl[j] = *reinterpret_cast<const f16x8 *>(&sB[1][(2 * half + j) * 32 + c][ks * 16 + h * 8]);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[j], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[j], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[j], acc[j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- store: register r of lane (c, h) = row (r & 3) + 8 (r >> 2) + 4 h, column nt * 32 + c ----
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float *base = Mp + (t0 + 4 * h) * 128 + (2 * half + j) * 32 + c;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = (r & 3) + 8 * (r >> 2);
-          if (full || t0 + 4 * h + ro < p.tiles) base[(long)ro * 128] = acc[j][r];
-        }
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      ah[ks] = nh[ks];
-      al[ks] = nl[ks];
-    }
-  }
-}
 
 // ---- the Winograd batched GEMM of the wider levels (Cin, Cout in {256, 512}): M[p] = V[p] x U[p], [tiles, Cin] x [Cin, Cout].
 // The library route (ONE hipBLASLt fp16 GEMM over K' = 3 Cin of V3 = [h | h | l]) runs these at 0.6-0.95 PFLOP/s executed

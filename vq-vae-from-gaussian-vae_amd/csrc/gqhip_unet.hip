@@ -171,30 +171,6 @@ int wino_in_nhwc_f16x2(const float *x, void *V2, int64_t B, int64_t H, int64_t W
   return wino_in_f16_impl(2, x, V2, B, H, W, C, tile, scale, stream);
 }
 
-int wino_gemm_c128_f16x2(const void *V2, const void *U2t, float *M, int64_t P, int64_t tiles, void *stream) {
-  if (P < 1 || tiles < 0 || tiles > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
-  if (tiles == 0) return GQHIP_OK;
-  if (!V2 || !U2t || !M) return GQHIP_ERR_INVALID_ARG;
-  WinoGemmParams wp{};
-  wp.V2 = static_cast<const _Float16 *>(V2); wp.U2t = static_cast<const _Float16 *>(U2t); wp.M = M; wp.tiles = tiles;
-  // ONE round of co-resident blocks (2 per CU: 70 KiB of LDS, <= 256 VGPRs): the kernel is HBM-bound, so a partial last
-  // round would idle part of the chip for a whole block's duration (1152 blocks of 2048 rows = 2.25 rounds ran at 3.9 TB/s).
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
-  long bpp = (2L * cus) / P;
-  if (bpp < 1) bpp = 1;
-  long rpb = ((tiles + bpp - 1) / bpp + 127) / 128 * 128;
-  if (rpb < 128) rpb = 128;
-  wp.rows_per_block = (int)rpb;
-  wp.blocks_per_pos = (int)((tiles + rpb - 1) / rpb);
-  hipLaunchKernelGGL(wino_gemm_c128_f16x2_kernel, dim3((unsigned)(P * wp.blocks_per_pos)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), wp);
-  return check_launch();
-}
-
 int wino_gemm_f16x2(const void *V2, const void *Wf, float *M, int64_t P, int64_t tiles, int64_t Cin, int64_t Cout,
                     void *stream) {
   if (P < 1 || tiles < 0 || tiles > 0x3fffffff || tiles % 256 != 0 || Cin < 32 || Cin % 32 != 0 || Cin > 4096 || Cout < 128 ||
@@ -301,29 +277,6 @@ int wino_in_gn_nhwc_f16x2(const float *x, const float *gamma, const float *beta,
                          stream);
 }
 
-int conv3_split_gn_f16(const float *x, const float *gamma_or_null, const float *beta_or_null, const float *pre_bias_or_null,
-                       const int64_t *stats_or_null, void *Xs, int64_t B, int64_t H, int64_t W, int64_t C, int64_t groups,
-                       double eps, int apply_silu, float scale, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || (H * W) % 16 != 0 || !(scale > 0.f)) return GQHIP_ERR_INVALID_ARG;
-  if (stats_or_null && (groups < 1 || C % groups != 0 || (C / groups) % 4 != 0 || !gamma_or_null || !beta_or_null))
-    return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !Xs) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * H * W * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 32768) blocks = 32768;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int cpg = stats_or_null ? (int)(C / groups) : 4;
-  if (apply_silu)
-    hipLaunchKernelGGL(conv3_split_gn_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma_or_null, beta_or_null,
-                       pre_bias_or_null, stats_or_null, static_cast<_Float16 *>(Xs), (long)(H * W), (int)C, cpg, eps, scale, total);
-  else
-    hipLaunchKernelGGL(conv3_split_gn_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma_or_null, beta_or_null,
-                       pre_bias_or_null, stats_or_null, static_cast<_Float16 *>(Xs), (long)(H * W), (int)C, cpg, eps, scale, total);
-  return check_launch();
-}
-
-// GroupNorm statistics of the output: every group must lie inside one block's 128 channels, 4 | channels per group
 static bool conv3_groups_ok(int64_t Cout, int64_t groups_out) {
   if (groups_out < 1 || Cout % groups_out != 0) return false;
   const int64_t cpg = Cout / groups_out;
@@ -340,27 +293,6 @@ static void conv3_fill(Conv3Params &cp, const void *Wf, const float *bias, const
   cp.ntiles = (long)B * cp.tiles_x * cp.tiles_y;
   cp.tiles_per_xcd = (cp.ntiles + 7) / 8;
   cp.mscale = mscale;
-}
-
-int conv3x3_f16x3(const void *Xs, const void *Wf, const float *bias_or_null, const float *res_or_null, float *y,
-                  int64_t *stats_out_or_null, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out,
-                  float mscale, void *stream) {
-  if (B < 0 || H < kC3TH || W < kC3TW || H % kC3TH || W % kC3TW || Cin < 16 || Cin % 16 != 0 || (Cout != 128 && Cout != 256) ||
-      H * W > (1 << 22))
-    return GQHIP_ERR_INVALID_ARG;
-  if (stats_out_or_null && !conv3_groups_ok(Cout, groups_out)) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!Xs || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
-    return check_launch();
-  Conv3Params cp{};
-  cp.Xs = static_cast<const _Float16 *>(Xs);
-  conv3_fill(cp, Wf, bias_or_null, res_or_null, y, stats_out_or_null, B, H, W, Cin, Cout, groups_out, mscale);
-  const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
-  if (Cout == 128) hipLaunchKernelGGL(conv3x3_f16x3_kernel<128>, grid, dim3(256), 0, st, cp);
-  else hipLaunchKernelGGL(conv3x3_f16x3_kernel<256>, grid, dim3(256), 0, st, cp);
-  return check_launch();
 }
 
 int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null,
@@ -593,31 +525,6 @@ int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or
   return check_launch();
 }
 
-int upconv_im2col_nhwc_f32(const float *x, float *A, int64_t B, int64_t H, int64_t W, int64_t C, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !A) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * (H + 1) * (W + 1) * 4 * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(upconv_im2col_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     x, (void *)A, (int)H, (int)W, (int)(C / 4), total, (const float *)nullptr);
-  return check_launch();
-}
-
-int upconv_im2col_nhwc_f16x3(const float *x, void *A3, int64_t B, int64_t H, int64_t W, int64_t C,
-                             const float *scales_dev, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!x || !A3 || !scales_dev) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * (H + 1) * (W + 1) * 4 * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(upconv_im2col_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     x, A3, (int)H, (int)W, (int)(C / 4), total, scales_dev);
-  return check_launch();
-}
-
 int attn_split_qkv_f16x3(const float *qkv, void *Q3, void *K3, void *V3, int64_t B, int64_t L, int64_t C, float sq, float sv,
                          void *stream) {
   if (B < 0 || L < 1 || C < 4 || C % 4 != 0 || !(sq > 0.f) || !(sv > 0.f)) return GQHIP_ERR_INVALID_ARG;
@@ -657,19 +564,6 @@ int f16_scales_from_gn_stats(const int64_t *stats, int64_t n_bg, double amp, dou
   if (!stats || !scales_out || n_bg < 1 || n_bg > 0x7fffffff || !(amp > 0.0) || !(u_scale > 0.0)) return GQHIP_ERR_INVALID_ARG;
   hipLaunchKernelGGL(f16_scales_from_stats_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), stats, (int)n_bg,
                      (float)amp, (float)u_scale, scales_out);
-  return check_launch();
-}
-
-int upconv_shuffle_nhwc_f32(const float *src, float *y, int64_t B, int64_t H, int64_t W, int64_t C,
-                            const float *mscale_dev_or_null, void *stream) {
-  if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return GQHIP_ERR_INVALID_ARG;
-  if (B == 0) return GQHIP_OK;
-  if (!src || !y) return GQHIP_ERR_INVALID_ARG;
-  const long total = (long)(B * 2 * H * 2 * W * (C / 4));
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(upconv_shuffle_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     src, y, (int)H, (int)W, (int)(C / 4), total, mscale_dev_or_null);
   return check_launch();
 }
 

@@ -60,7 +60,6 @@ _SIGNATURES = {
                                               ctypes.c_float, _vp]),
     "wino_in_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
     "wino_in_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_float, _vp]),
-    "wino_gemm_c128_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "wino_gemm_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "upconv2x_f16x3": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
                                       _vp]),
@@ -70,9 +69,6 @@ _SIGNATURES = {
                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
     "wino_in_gn_nhwc_f16x2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
-    "conv3_split_gn_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
-                                           ctypes.c_int, ctypes.c_float, _vp]),
-    "conv3x3_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "conv3x3_gn_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp,
                                          _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "conv1x1_f16x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
@@ -90,9 +86,6 @@ _SIGNATURES = {
     "wino4_in_gn_nhwc_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_double,
                                              ctypes.c_int, _vp]),
     "wino_out_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
-    "upconv_im2col_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
-    "upconv_shuffle_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
-    "upconv_im2col_nhwc_f16x3": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "f16_scales_from_gn_stats": (ctypes.c_int, [_vp, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "upsample2x_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp]),
@@ -474,12 +467,10 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
             amp = 100.0 if f4 else 4.0
             v_scale = 2.0 ** math.floor(math.log2(32768.0 / (amp * max(float(x_bound), 1e-30))))
             v_scale = min(v_scale, 2.0 ** 14)
-            use_c128 = C == 128 and cout == 128 and len(f16) > 3 and f16[3] is not None
-            use_own = (not use_c128 and len(f16) > 4 and f16[4] is not None and tiles % 256 == 0
-                       and own_gemm_fits(U.shape[0], tiles, cout, C))
-            if use_c128 or use_own:
-                # [h | l] operand (4 bytes per element) + our own GEMM kernel forming the three products: the HBM-bound
-                # 128-channel case (wino_gemm_c128_f16x2) and the wider levels (wino_gemm_f16x2: weights in operand order)
+            use_own = len(f16) > 3 and f16[3] is not None and tiles % 256 == 0 and own_gemm_fits(U.shape[0], tiles, cout, C)
+            if use_own:
+                # [h | l] operand (4 bytes per element) + our own GEMM kernel forming the three products (wino_gemm_f16x2:
+                # weights in operand order)
                 V = torch.empty((U.shape[0], tiles, 2 * C), dtype=torch.float16, device=x.device)
                 if gn is not None:
                     gamma, beta, groups, eps, silu, stats, pre_bias = gn
@@ -490,12 +481,8 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
                     _check(L.wino_in_nhwc_f16x2(x.data_ptr(), V.data_ptr(), B, H, W, C, t, float(v_scale), _stream()),
                            "wino_in_nhwc_f16x2")
                 M = torch.empty((U.shape[0], tiles, cout), dtype=torch.float32, device=x.device)
-                if use_c128:
-                    _check(L.wino_gemm_c128_f16x2(V.data_ptr(), f16[3].data_ptr(), M.data_ptr(), U.shape[0], tiles, _stream()),
-                           "wino_gemm_c128_f16x2")
-                else:
-                    _check(L.wino_gemm_f16x2(V.data_ptr(), f16[4].data_ptr(), M.data_ptr(), U.shape[0], tiles, C, cout,
-                                             _stream()), "wino_gemm_f16x2")
+                _check(L.wino_gemm_f16x2(V.data_ptr(), f16[3].data_ptr(), M.data_ptr(), U.shape[0], tiles, C, cout,
+                                         _stream()), "wino_gemm_f16x2")
                 V = None
             else:
                 V = torch.empty((U.shape[0], tiles, 3 * C), dtype=torch.float16, device=x.device)
@@ -575,18 +562,12 @@ def own_gemm_fits(positions: int, tiles: int, cout: int, cin: int = 256) -> bool
     else 256 x 128) fills whole rounds of the chip reasonably (36 x 1024 tiles x 512 channels = 288 blocks = 1.125 rounds does
     not).  Alone the kernel is 1.05-1.21x the library at 256 input channels and at 16 x 4096 tiles, 0.91-0.95x at the two largest
     512-channel shapes (tools/wino_gemm2_bench.py) -- but its [h | l] operand also takes a third off what the input transform
-    writes, so the step as a whole is faster with it everywhere (33.9 -> 33.4 ms; OWN_GEMM_MAX_CH = 256 restores the old
-    policy)."""
-    if OWN_GEMM_MAX_CH and (cin > OWN_GEMM_MAX_CH or cout > OWN_GEMM_MAX_CH):
-        return False
+    writes, so the step as a whole is faster with it everywhere (33.9 -> 33.4 ms)."""
     if cout % 256 == 0 and cin % 64 == 0:
         rounds = positions * (tiles // 256) * (cout // 256) / 256.0      # 8-wave blocks, one per CU
     else:
         rounds = positions * (tiles // 256) * (cout // 128) / 512.0      # 4-wave blocks, two per CU
     return rounds >= 1.0 and rounds / math.ceil(rounds) >= 0.85
-
-
-OWN_GEMM_MAX_CH = 0     # 0: no channel limit; 256: only the 256-channel level (A/B switch)
 
 
 def wino_weights_operand_order(h, l):
@@ -595,9 +576,6 @@ def wino_weights_operand_order(h, l):
     T, cin, cout = h.shape
     planes = torch.stack([h, l], 0).reshape(2, T, cin // 16, 2, 8, cout // 32, 32)   # [pl, t, kc, hh, e, nt, c]
     return planes.permute(1, 2, 5, 0, 3, 6, 4).reshape(T, cin // 16, cout // 32, 2, 64, 8).contiguous()
-
-
-DIRECT_CONV_FUSED_SPLIT = True   # conv3x3_direct: GroupNorm + split inside the convolution kernel (A/B switch)
 
 
 def conv3_weights_f16(weight):
@@ -618,13 +596,15 @@ def conv3_weights_f16(weight):
     return p7.reshape(cin // 16, kk * kk, cout // 32, 2, 64, 8).contiguous(), u_scale
 
 
-def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None, bias=None, stats_groups: int = 0):
-    """3x3 stride-1 padding-1 convolution Cin -> Cout (128 or 256) of a channels_last fp32 HIP tensor as a direct
-    (implicit GEMM) fp16 x 3 convolution (gqhip.h:conv3x3_gn_f16x3); ``wf, u_scale`` from conv3_weights_f16, ``x_bound`` >=
-    max|conv input|, ``gn`` as in wino_conv3x3 (then x_bound bounds the activated tensor).  Returns y, or (y, statistics of
-    y) when ``stats_groups`` > 0 (+ bias, + residual in either case)."""
-    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 16 or x.shape[2] % 8 or x.shape[3] % 32:
-        raise GqHipError("conv3x3_direct needs a dense channels_last fp32 HIP tensor, C % 16 == 0, H % 8 == 0, W % 32 == 0")
+def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn, residual=None, bias=None, stats_groups: int = 0):
+    """3x3 stride-1 padding-1 convolution Cin -> Cout (128 or 256) of SiLU(GroupNorm(x)) for a channels_last fp32 HIP tensor x, as
+    a direct (implicit GEMM) fp16 x 3 convolution with the normalisation applied while the patch is staged
+    (gqhip.h:conv3x3_gn_f16x3); ``wf, u_scale`` from conv3_weights_f16, ``x_bound`` >= max|activated tensor|, ``gn`` as in
+    wino_conv3x3.  Returns y, or (y, statistics of y) when ``stats_groups`` > 0 (+ bias, + residual in either case)."""
+    if (image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 32 or x.shape[1] > 512 or x.shape[2] % 8
+            or x.shape[3] % 32 or gn is None):
+        raise GqHipError("conv3x3_direct needs a dense channels_last fp32 HIP tensor, C % 32 == 0, C <= 512, H % 8 == 0, W % 32 == 0, "
+                         "and the GroupNorm that feeds the convolution")
     B, C, H, W = x.shape
     cout = wf.shape[2] * 32
     if wf.shape[0] * 16 != C:
@@ -637,24 +617,11 @@ def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn=None, residual=None
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
         mscale = 1.0 / (v_scale * u_scale)
-        if gn is not None and C <= 512 and C % 32 == 0 and DIRECT_CONV_FUSED_SPLIT:
-            gamma, beta, groups, eps, silu, stats, pre_bias = gn
-            _check(L.conv3x3_gn_f16x3(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(),
-                                      groups, float(eps), 1 if silu else 0, float(v_scale), wf.data_ptr(), _ptr(bias),
-                                      _ptr(residual), y.data_ptr(), _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1),
-                                      mscale, _stream()), "conv3x3_gn_f16x3")
-            return (y, ostats) if stats_groups else y
-        xs = torch.empty((B, C // 16, H, W, 2, 16), dtype=torch.float16, device=x.device)
-        if gn is not None:
-            gamma, beta, groups, eps, silu, stats, pre_bias = gn
-            _check(L.conv3_split_gn_f16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(),
-                                        xs.data_ptr(), B, H, W, C, groups, float(eps), 1 if silu else 0, float(v_scale),
-                                        _stream()), "conv3_split_gn_f16")
-        else:
-            _check(L.conv3_split_gn_f16(x.data_ptr(), None, None, None, None, xs.data_ptr(), B, H, W, C, 1, 0.0, 0,
-                                        float(v_scale), _stream()), "conv3_split_gn_f16")
-        _check(L.conv3x3_f16x3(xs.data_ptr(), wf.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), _ptr(ostats),
-                               B, H, W, C, cout, max(stats_groups, 1), mscale, _stream()), "conv3x3_f16x3")
+        gamma, beta, groups, eps, silu, stats, pre_bias = gn
+        _check(L.conv3x3_gn_f16x3(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(),
+                                  groups, float(eps), 1 if silu else 0, float(v_scale), wf.data_ptr(), _ptr(bias),
+                                  _ptr(residual), y.data_ptr(), _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1),
+                                  mscale, _stream()), "conv3x3_gn_f16x3")
     return (y, ostats) if stats_groups else y
 
 
@@ -851,24 +818,6 @@ def conv3x3_f32(x, wk, cout: int, bias=None, gn=None):
     return y
 
 
-def upconv_im2col(x, scales=None):
-    """2x2 patches (padding 1) of a channels_last fp32 HIP tensor [B, C, H, W] as GEMM rows [B*(H+1)*(W+1), 4C];
-    ``scales`` (device float[2] from f16_scales): the fp16 x 3 operand [rows, 12C] = [h | h | l] of x * scales[0] instead."""
-    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] % 4:
-        raise GqHipError("upconv_im2col needs a dense channels_last fp32 HIP tensor with C % 4 == 0")
-    B, C, H, W = x.shape
-    rows = B * (H + 1) * (W + 1)
-    with torch.cuda.device(x.device):
-        if scales is not None:
-            A = torch.empty((rows, 12 * C), dtype=torch.float16, device=x.device)
-            _check(lib().upconv_im2col_nhwc_f16x3(x.data_ptr(), A.data_ptr(), B, H, W, C, scales.data_ptr(), _stream()),
-                   "upconv_im2col_nhwc_f16x3")
-        else:
-            A = torch.empty((rows, 4 * C), dtype=x.dtype, device=x.device)
-            _check(lib().upconv_im2col_nhwc_f32(x.data_ptr(), A.data_ptr(), B, H, W, C, _stream()), "upconv_im2col_nhwc_f32")
-    return A
-
-
 def f16_scales(stats, amp: float, u_scale: float):
     """Device float[2] = (v_scale, 1 / (v_scale * u_scale)) for an fp16 x 3 GEMM whose activation operand x has the
     GroupNorm statistics ``stats`` (n_bg records of GNSTAT_WORDS int64: gqhip_gnstat_t): v_scale = the largest power of two with
@@ -880,21 +829,6 @@ def f16_scales(stats, amp: float, u_scale: float):
         _check(lib().f16_scales_from_gn_stats(stats.data_ptr(), stats.numel() // GNSTAT_WORDS, float(amp), float(u_scale),
                                               out.data_ptr(), _stream()), "f16_scales_from_gn_stats")
     return out
-
-
-def upconv_shuffle(src, C: int, scales=None):
-    """Pixel shuffle of the sub-pixel upsample+conv: src [B, 4C, H+1, W+1] channels_last -> [B, C, 2H, 2W];
-    ``scales``: multiply by scales[1] (the fp16 x 3 GEMM's result on scaled operands)."""
-    if image_layout(src) != 1 or not src.is_cuda or src.dtype != torch.float32 or src.shape[1] != 4 * C or C % 4:
-        raise GqHipError("upconv_shuffle needs a dense channels_last fp32 HIP tensor [B, 4C, H+1, W+1], C % 4 == 0")
-    B, _, H1, W1 = src.shape
-    y = torch.empty((B, C, 2 * (H1 - 1), 2 * (W1 - 1)), dtype=src.dtype, device=src.device,
-                    memory_format=torch.channels_last)
-    with torch.cuda.device(src.device):
-        ms = None if scales is None else scales.data_ptr() + 4
-        _check(lib().upconv_shuffle_nhwc_f32(src.data_ptr(), y.data_ptr(), B, H1 - 1, W1 - 1, C, ms, _stream()),
-               "upconv_shuffle_nhwc_f32")
-    return y
 
 
 def upsample2x_nhwc(x):

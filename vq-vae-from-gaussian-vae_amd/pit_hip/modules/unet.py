@@ -81,8 +81,8 @@ def _f16_args(conv: nn.Conv2d, x: torch.Tensor, f4: bool):
     bound = getattr(x, "_act_bound", None)
     if not WINOGRAD_F16X3 or bound is None:
         return None
-    u3, u_scale = _wino_weights_f16(conv, f4)
-    return u3, u_scale, bound, (conv._wino_u2t if WINOGRAD_C128_GEMM else None), (conv._wino_wf2 if WINOGRAD_OWN_GEMM else None)
+    u3, u_scale, wf2 = _wino_weights_f16(conv, f4)
+    return u3, u_scale, bound, (wf2 if WINOGRAD_OWN_GEMM else None)
 
 
 def _f16_args_gn(conv: nn.Conv2d, norm: nn.GroupNorm, x: torch.Tensor, f4: bool):
@@ -90,9 +90,8 @@ def _f16_args_gn(conv: nn.Conv2d, norm: nn.GroupNorm, x: torch.Tensor, f4: bool)
     activated tensor, which is never materialised."""
     if not WINOGRAD_F16X3:
         return None
-    u3, u_scale = _wino_weights_f16(conv, f4)
-    return (u3, u_scale, _gn_act_bound(norm, x), (conv._wino_u2t if WINOGRAD_C128_GEMM else None),
-            (conv._wino_wf2 if WINOGRAD_OWN_GEMM else None))
+    u3, u_scale, wf2 = _wino_weights_f16(conv, f4)
+    return u3, u_scale, _gn_act_bound(norm, x), (wf2 if WINOGRAD_OWN_GEMM else None)
 
 
 def _conv(conv: nn.Conv2d, x: torch.Tensor, want_stats: bool = False):
@@ -140,19 +139,14 @@ def _direct_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
         return False
     if conv.out_channels == 128:
         return True
-    return conv.out_channels == 256 and (DIRECT_CONV_OVER_F4 or not (WINOGRAD_F4 and getattr(conv, "_gq_wino4", False)))
+    return conv.out_channels == 256 and not (WINOGRAD_F4 and getattr(conv, "_gq_wino4", False))
 
 
 def _direct_weights(conv: nn.Conv2d):
-    """(Wf, u_scale) of conv3x3_direct, cached until the weight changes."""
-    w = conv.weight
-    key = (w.data_ptr(), w._version, w.device)
-    if getattr(conv, "_direct_key", None) != key:
-        from .. import _lib
+    """(Wf, u_scale) of conv3x3_direct / conv1x1_direct, cached until the weight changes."""
+    from .. import _lib
 
-        conv._direct_wf, conv._direct_us = _lib.conv3_weights_f16(w)
-        conv._direct_key = key
-    return conv._direct_wf, conv._direct_us
+    return _cached(conv, "direct_wf", _wkey(conv.weight), lambda: _lib.conv3_weights_f16(conv.weight))
 
 
 def _stats_of(x: torch.Tensor, pre_bias, groups: int):
@@ -196,12 +190,8 @@ def _norm_act_conv_small(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, p
         from .. import _lib
 
         if _lib.image_layout(x) == 1:
-            w = conv.weight
-            key = (w.data_ptr(), w._version, w.device)
-            if getattr(conv, "_ohwi_key", None) != key:
-                conv._ohwi = w.detach().permute(0, 2, 3, 1).contiguous()
-                conv._ohwi_key = key
-            return _lib.conv3x3_gn_small(x, conv._ohwi, conv.bias, _gn_tuple(norm, x, pre_bias))
+            ohwi = _cached(conv, "ohwi", _wkey(conv.weight), lambda: conv.weight.detach().permute(0, 2, 3, 1).contiguous())
+            return _lib.conv3x3_gn_small(x, ohwi, conv.bias, _gn_tuple(norm, x, pre_bias))
     return conv(_norm_act(norm, x, pre_bias=pre_bias))
 
 
@@ -295,52 +285,44 @@ _WINO_G4 = [[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6]
 def _wino_weights(conv: nn.Conv2d, f4: bool = False) -> torch.Tensor:
     """U = G g G^T of a 3x3 kernel, [16, Cin, Cout] for F(2x2,3x3) or [36, Cin, Cout] for F(4x4,3x3) (formed in
     fp64, rounded once); cached until the weight changes."""
-    w = conv.weight
-    key = (w.data_ptr(), w._version, w.device, f4)
-    if getattr(conv, "_wino_key", None) != key:
+    def build():
+        w = conv.weight
         G = torch.tensor(_WINO_G4 if f4 else _WINO_G2, dtype=torch.float64, device=w.device)
         u = torch.einsum("ik,ockl,jl->ijco", G, w.double(), G).float()
-        conv._wino_u = u.reshape(-1, w.shape[1], w.shape[0]).contiguous()
-        conv._wino_key = key
-    return conv._wino_u
+        return u.reshape(-1, w.shape[1], w.shape[0]).contiguous()
+
+    return _cached(conv, "wino_u", _wkey(conv.weight) + (f4,), build)
 
 
 def _wino_weights_f16(conv: nn.Conv2d, f4: bool = False):
-    """(U3, u_scale): U = G g G^T scaled by a power of two into fp16's comfortable range and split into two fp16 terms,
+    """(U3, u_scale, Wf2): U = G g G^T scaled by a power of two into fp16's comfortable range and split into two fp16 terms,
     stacked along K as [U_h; U_l; U_h] ([T, 3 Cin, Cout] fp16) -- the weight side of the f16x3 GEMM (gqhip.h:
-    wino_in_nhwc_f16x3).  Cached with (and keyed like) the fp32 U."""
-    U = _wino_weights(conv, f4)
-    if getattr(conv, "_wino_f16_key", None) != conv._wino_key:
+    wino_in_nhwc_f16x3) -- and, where libgqhip's own GEMM applies (Cin % 32 == 0, Cout % 128 == 0), (U_h, U_l) in MFMA operand
+    order for wino_gemm_f16x2 (the [h | l] route).  Cached like (and keyed like) the fp32 U."""
+    def build():
+        U = _wino_weights(conv, f4)
         amax = float(U.abs().max())
         u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0
         us = U * u_scale
         h = us.half()
         l = (us - h.float()).half()
-        conv._wino_u3 = torch.cat([h, l, h], 1).contiguous()
-        # 128 -> 128 channels: (U_h^T, U_l^T) [T, 2, Cout, Cin] for wino_gemm_c128_f16x2 (k contiguous per output column)
-        conv._wino_u2t = (torch.stack([h, l], 1).transpose(2, 3).contiguous()
-                          if WINOGRAD_C128_GEMM and tuple(U.shape[1:]) == (128, 128) else None)
-        # wider levels: (U_h, U_l) in MFMA operand order for wino_gemm_f16x2 (the [h | l] route beyond 128 channels)
-        if WINOGRAD_OWN_GEMM and conv._wino_u2t is None and U.shape[1] % 32 == 0 and U.shape[2] % 128 == 0:
+        wf2 = None
+        if WINOGRAD_OWN_GEMM and U.shape[1] % 32 == 0 and U.shape[2] % 128 == 0:
             from .. import _lib
 
-            conv._wino_wf2 = _lib.wino_weights_operand_order(h, l)
-        else:
-            conv._wino_wf2 = None
-        conv._wino_u_scale = u_scale
-        conv._wino_f16_key = conv._wino_key
-    return conv._wino_u3, conv._wino_u_scale
+            wf2 = _lib.wino_weights_operand_order(h, l)
+        return torch.cat([h, l, h], 1).contiguous(), u_scale, wf2
+
+    return _cached(conv, "wino_u3", _wkey(conv.weight) + (f4, WINOGRAD_OWN_GEMM), build)
 
 
 def _gn_act_bound(norm: nn.GroupNorm, x: torch.Tensor) -> float:
     """A rigorous bound on |SiLU(GroupNorm(x))|: a group of n elements has |(x - mean) / sqrt(var + eps)| <= sqrt(n - 1),
     so |y| <= sqrt(n - 1) max|gamma| + max|beta| and |SiLU(y)| <= |y|.  (max|gamma|, max|beta| cached per weight.)"""
-    key = (norm.weight.data_ptr(), norm.weight._version, norm.bias.data_ptr(), norm.bias._version)
-    if getattr(norm, "_gb_key", None) != key:
-        norm._gb_max = (float(norm.weight.detach().abs().max()), float(norm.bias.detach().abs().max()))
-        norm._gb_key = key
+    gb = _cached(norm, "gb_max", _wkey(norm.weight, norm.bias),
+                 lambda: (float(norm.weight.detach().abs().max()), float(norm.bias.detach().abs().max())))
     n = (x.shape[1] // norm.num_groups) * x.shape[2] * x.shape[3]
-    return math.sqrt(max(n - 1, 1)) * norm._gb_max[0] + norm._gb_max[1]
+    return math.sqrt(max(n - 1, 1)) * gb[0] + gb[1]
 
 
 class _WeightGuard:
@@ -404,16 +386,14 @@ def _guarded(module: nn.Module, run, x: torch.Tensor):
 
 
 def invalidate_caches(module: nn.Module) -> None:
-    """Drop every weight-derived cache under ``module`` (Winograd U matrices, the sub-pixel phase matrices, the fused
-    q/k/v matrix).  The caches are keyed on (data_ptr, _version, device), which follows ``load_state_dict``, optimizer
-    steps, ``.to()`` and any in-place op on the parameter -- but NOT writes through ``param.data`` (EMA weight swaps
-    typically do that): they bump no version counter.  Call this after such an update; ``AutoencodingEngine
-    .init_from_ckpt`` and the modules' ``load_state_dict`` do it themselves."""
+    """Drop every weight-derived cache under ``module`` (Winograd U matrices, operand-order fp16 splits, the sub-pixel phase
+    matrices, the fused q/k/v matrix, operand bounds): every one of them lives in the owning module's ``_gq_cache`` dict
+    (see ``_cached``), keyed on the parameters' (data_ptr, _version, device) -- which follows ``load_state_dict``, optimizer
+    steps, ``.to()`` and any in-place op on the parameter.  Writes through ``param.data`` bump no version counter: those are
+    caught by the content-hash guard of every inference forward (``_WeightGuard``), which calls this function itself, so
+    nobody has to remember to."""
     for m in module.modules():
         m.__dict__.pop("_gq_cache", None)
-        for attr in ("_wino_key", "_wino_f16_key", "_direct_key", "_ohwi_key", "_vb_key", "_qkb_key", "_qkv_wf_key", "_s2_key", "_qkv_key", "_phase_key", "_phase_f16_key", "_phase_direct_key", "_gb_key"):
-            if getattr(m, attr, None) is not None:
-                setattr(m, attr, None)
 
 
 def _drop_caches_after_load(module, incompatible_keys) -> None:
@@ -459,10 +439,7 @@ WINOGRAD_F4 = True       # decoder: F(4x4,3x3) (36 GEMMs on 6x6 tiles) instead o
 # for hipBLASLt's fp32 GEMM (itself a split-bf16 emulation on gfx950), at 1.2x (128 channels) to 2.5x (512) its speed
 # (tools/bmm_bf16x3.py).  False: the library's fp32 GEMM.
 WINOGRAD_F16X3 = True
-# 128 -> 128-channel Winograd GEMMs (256 x 256 level: HBM-bound at K = N = 128) through libgqhip's own kernel on the
-# [h | l] operand (4 instead of 6 bytes per element of V): same splits and products as the library route
-WINOGRAD_C128_GEMM = True
-# ... and the 256- / 512-channel Winograd GEMMs through libgqhip's wino_gemm_f16x2 on the same [h | l] operand (weights in MFMA
+# the 256- / 512-channel Winograd GEMMs through libgqhip's wino_gemm_f16x2 on the [h | l] operand (weights in MFMA
 # operand order, three products in the kernel) where its grid fills the chip (_lib.own_gemm_fits: everything but the
 # 32 x 32 levels' 36 x 1024-tile GEMMs); else the library GEMM over [h | h | l]
 WINOGRAD_OWN_GEMM = True
@@ -479,7 +456,6 @@ CONV_F32 = True
 # every inference forward of Encoder / Decoder on a HIP device checks its weight-derived caches against a content hash of the
 # parameters (catches ``param.data`` writes, which bump no version counter); see _WeightGuard
 WEIGHT_GUARD = os.environ.get("GQHIP_WEIGHT_GUARD", "1") != "0"   # (the env switch: A/B timing)
-DIRECT_CONV_OVER_F4 = False   # ... also where the alternative is F(4x4,3x3) (decoder, 256 channels at 128 x 128): A/B switch
 # GroupNorm+SiLU applied inside the Winograd input transforms (F(2x2,3x3) / F(4x4,3x3)): the normalised tensor is never
 # written or re-read.  Bit-identical V to gn_apply + plain transform (same folded scale / shift, same silu_f32); pays
 # since the loads of a tile are issued ahead of the activations (branch-free borders): 53.4 -> 50.8 ms / step.
@@ -488,8 +464,9 @@ FUSED_WINO_GN_F4 = True
 # also in the encoder: measured perturbation of z 4.2e-6 vs the CPU reference (direct MIOpen convs: 3.4e-6), no index
 # change on the CPU golden nor on 16 384 rows against the direct-conv encoder (tools/encoder_winograd_check.py)
 WINOGRAD_ENCODER = True
-DIRECT_UPCONV = True     # ... computed directly by libgqhip's upconv2x_f16x3 (one kernel; else im2col + library GEMM + pixel shuffle)
-SUBPIXEL_UPCONV = True   # Upsample: nearest x2 + conv3x3 as four 2x2 phase convs of the low-res input (2.25x fewer flops)
+# Upsample: nearest x2 + conv3x3 as four 2x2 phase convolutions of the low-resolution input (2.25x fewer flops), computed directly by
+# libgqhip's upconv2x_f16x3 (one kernel); shapes it does not tile: NHWC upsample copy + the ordinary convolution routes
+DIRECT_UPCONV = True
 FUSED_QKV = True         # attention: q, k, v as one GEMM with fused biases (channels_last)
 FUSED_ADD_STATS = True   # residual add also produces the next GroupNorm's statistics (channels_last only)
 GN_GROUPS = 32     # unet.py:54-57: every Normalize is GroupNorm(32, C, eps=1e-6)
@@ -603,13 +580,13 @@ class AttnBlock(nn.Module):
     def _qkv_weights(self):
         """([c, 3c] GEMM matrix, [3c] bias) of the q / k / v 1x1 convolutions; cached until a weight changes."""
         ps = (self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias)
-        key = tuple((p.data_ptr(), p._version) for p in ps)
-        if getattr(self, "_qkv_key", None) != key:
+
+        def build():
             c = self.q.weight.shape[0]
-            self._qkv_w = torch.cat([p.reshape(c, c) for p in ps[:3]], 0).t().contiguous()
-            self._qkv_b = torch.cat(ps[3:], 0).contiguous()
-            self._qkv_key = key
-        return self._qkv_w, self._qkv_b
+            return (torch.cat([p.detach().reshape(c, c) for p in ps[:3]], 0).t().contiguous(),
+                    torch.cat([p.detach() for p in ps[3:]], 0).contiguous())
+
+        return _cached(self, "qkv", _wkey(*ps), build)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b, c, h, w = x.shape
@@ -626,10 +603,9 @@ class AttnBlock(nn.Module):
                     # ... as libgqhip's fp16 x 3 GEMM over the pixels (the fp32 library GEMM runs at ~130 TFLOP/s)
                     from .. import _lib
 
-                    if getattr(self, "_qkv_wf_key", None) != self._qkv_key:
-                        self._qkv_wf, self._qkv_us = _lib.conv3_weights_f16(wqkv.t().reshape(3 * c, c, 1, 1))
-                        self._qkv_wf_key = self._qkv_key
-                    qkv = _lib.conv1x1_direct(y, self._qkv_wf, self._qkv_us, _gn_act_bound(self.norm, x), bias=bqkv)
+                    qkv_wf, qkv_us = _cached(self, "qkv_wf", _wkey(self.q.weight, self.k.weight, self.v.weight),
+                                             lambda: _lib.conv3_weights_f16(wqkv.t().reshape(3 * c, c, 1, 1)))
+                    qkv = _lib.conv1x1_direct(y, qkv_wf, qkv_us, _gn_act_bound(self.norm, x), bias=bqkv)
                     qkv = qkv.permute(0, 2, 3, 1).reshape(b, 1, h * w, 3 * c)
                 else:
                     qkv = torch.addmm(bqkv, y.permute(0, 2, 3, 1).reshape(b * h * w, c), wqkv).view(b, 1, h * w, 3 * c)
@@ -674,23 +650,24 @@ class AttnBlock(nn.Module):
     def _qk_bound(self, y_bound: float) -> float:
         """max(|q|, |k|) for |y| <= y_bound: q = W_q y + b_q, k = W_k y + b_k."""
         ps = (self.q.weight, self.k.weight, self.q.bias, self.k.bias)
-        key = tuple((p.data_ptr(), p._version) for p in ps)
-        if getattr(self, "_qkb_key", None) != key:
+
+        def build():
             c = self.q.weight.shape[0]
             rs = max(float(self.q.weight.detach().reshape(c, -1).abs().sum(1).max()),
                      float(self.k.weight.detach().reshape(c, -1).abs().sum(1).max()))
-            self._qkb = (rs, max(float(self.q.bias.detach().abs().max()), float(self.k.bias.detach().abs().max())))
-            self._qkb_key = key
-        return y_bound * self._qkb[0] + self._qkb[1]
+            return rs, max(float(self.q.bias.detach().abs().max()), float(self.k.bias.detach().abs().max()))
+
+        qkb = _cached(self, "qk_bound", _wkey(*ps), build)
+        return y_bound * qkb[0] + qkb[1]
 
     def _v_bound(self, y_bound: float) -> float:
         """max|v| for |y| <= y_bound: v = W_v y + b_v."""
-        key = (self.v.weight.data_ptr(), self.v.weight._version, self.v.bias.data_ptr(), self.v.bias._version)
-        if getattr(self, "_vb_key", None) != key:
+        def build():
             wv = self.v.weight.detach().reshape(self.v.weight.shape[0], -1)
-            self._vb = (float(wv.abs().sum(1).max()), float(self.v.bias.detach().abs().max()))
-            self._vb_key = key
-        return y_bound * self._vb[0] + self._vb[1]
+            return float(wv.abs().sum(1).max()), float(self.v.bias.detach().abs().max())
+
+        vb = _cached(self, "v_bound", _wkey(self.v.weight, self.v.bias), build)
+        return y_bound * vb[0] + vb[1]
 
 
 class Downsample(nn.Module):
@@ -718,13 +695,9 @@ class Downsample(nn.Module):
             from .. import _lib
 
             if _lib.gn_nhwc_ok(x.shape[1], GN_GROUPS) and _lib.gn_nhwc_ok(conv.out_channels, GN_GROUPS):
-                w = conv.weight
-                key = (w.data_ptr(), w._version, w.device)
-                if getattr(conv, "_s2_key", None) != key:
-                    conv._s2_wf, conv._s2_us = _lib.conv3s2_weights_f16(w)
-                    conv._s2_key = key
-                scales = _lib.f16_scales(_stats_of(x, None, GN_GROUPS), 1.0, conv._s2_us)
-                y, st = _lib.conv3x3s2_direct(x, conv._s2_wf, conv._s2_us, scales, bias=conv.bias, stats_groups=GN_GROUPS)
+                s2_wf, s2_us = _cached(conv, "s2_wf", _wkey(conv.weight), lambda: _lib.conv3s2_weights_f16(conv.weight))
+                scales = _lib.f16_scales(_stats_of(x, None, GN_GROUPS), 1.0, s2_us)
+                y, st = _lib.conv3x3s2_direct(x, s2_wf, s2_us, scales, bias=conv.bias, stats_groups=GN_GROUPS)
                 y._gn_stats = (st, GN_GROUPS)
                 return y, None
         if self.mode == "constant":
@@ -744,13 +717,11 @@ class Upsample(nn.Module):
             self.conv = _conv3(ch, ch, padding_mode)
 
     def _phase_weights(self) -> torch.Tensor:
-        """[4*Cin, 4*Cout] GEMM matrix of the 3x3 kernel folded onto the low-resolution grid: one 2x2 kernel per
-        output phase (a, b); tap u of phase a collects the kernel rows that land on source row i-1+a+u:
-        a=0: {0}, {1,2};  a=1: {0,1}, {2} (same for columns).  Row index (2u+v)*Cin + ci, column (2a+b)*Cout + co.
-        Cached until the weight changes."""
-        w = self.conv.weight
-        key = (w.data_ptr(), w._version, w.device)
-        if getattr(self, "_phase_key", None) != key:
+        """[4*Cin, 4*Cout] matrix of the 3x3 kernel folded onto the low-resolution grid: one 2x2 kernel per output phase
+        (a, b); tap u of phase a collects the kernel rows that land on source row i-1+a+u: a=0: {0}, {1,2};  a=1: {0,1}, {2}
+        (same for columns).  Row index (2u+v)*Cin + ci, column (2a+b)*Cout + co.  Cached until the weight changes."""
+        def build():
+            w = self.conv.weight.detach()
             rows = (((0,), (1, 2)), ((0, 1), (2,)))
             cout, cin = w.shape[0], w.shape[1]
             m = w.new_zeros(2, 2, cin, 2, 2, cout)          # [u, v, ci, a, b, co]
@@ -761,64 +732,35 @@ class Upsample(nn.Module):
                             for kh in rows[a][u]:
                                 for kw in rows[b][v]:
                                     m[u, v, :, a, b, :] += w[:, :, kh, kw].t()
-            self._phase_w = m.reshape(4 * cin, 4 * cout).contiguous()
-            self._phase_key = key
-        return self._phase_w
+            return m.reshape(4 * cin, 4 * cout).contiguous()
 
-    def _phase_weights_f16(self):
-        """([3 * 4Cin, 4Cout] fp16 = [W_h; W_l; W_h] of the phase matrix * u_scale, u_scale): weight side of the fp16 x 3 GEMM."""
-        wm = self._phase_weights()
-        if getattr(self, "_phase_f16_key", None) != self._phase_key:
-            amax = float(wm.abs().max())
-            u_scale = 2.0 ** math.floor(math.log2(16384.0 / max(amax, 1e-30))) if amax > 0 else 1.0
-            ws = wm * u_scale
-            h = ws.half()
-            l = (ws - h.float()).half()
-            self._phase_w3 = torch.cat([h, l, h], 0).contiguous()
-            self._phase_u_scale = u_scale
-            self._phase_f16_key = self._phase_key
-        return self._phase_w3, self._phase_u_scale
+        return _cached(self, "phase_w", _wkey(self.conv.weight), build)
 
     def forward(self, x: torch.Tensor):
         """Returns (y, pending_bias) -- see ``_conv``."""
         fast = (FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
                 and x.shape[1] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
-        if (fast and SUBPIXEL_UPCONV and self.with_conv and _defer_ok(x, self.conv) and self.conv.kernel_size == (3, 3)
-                and self.conv.stride == (1, 1) and self.conv.padding == (1, 1) and self.conv.out_channels % 4 == 0):
-            # nearest x2 then conv3x3 == four 2x2 convolutions of the low-resolution input (one per output phase):
-            # 16 instead of 36 tap evaluations per source pixel, no upsampled tensor; the phases are computed as
-            # 4*Cout columns of ONE GEMM over the 2x2 patches (MIOpen's immediate mode picks a slow kernel for a
-            # 2x2 filter: 9 ms per call) and interleaved by a pixel-shuffle kernel
+        if (fast and DIRECT_UPCONV and self.with_conv and _defer_ok(x, self.conv) and self.conv.kernel_size == (3, 3)
+                and self.conv.stride == (1, 1) and self.conv.padding == (1, 1)):
+            # nearest x2 then conv3x3 == four 2x2 convolutions of the low-resolution input (one per output phase): 16 instead
+            # of 36 tap evaluations per source pixel, no upsampled tensor -- computed directly by libgqhip's upconv2x_f16x3 (one
+            # kernel per Upsample), with the bias added and the statistics of the next ResnetBlock's norm1 left behind; the
+            # scale of x comes, on the device, from the statistics its producer left (sqrt of a group's sum of squares bounds
+            # its largest element)
             from .. import _lib
 
             b, c, h, w = x.shape
             st = getattr(x, "_gn_stats", None)
             cout = self.conv.out_channels
-            if (DIRECT_UPCONV and st is not None and cout in (128, 256, 512) and c % 16 == 0 and h % 8 == 0 and w % 32 == 0
+            if (st is not None and cout in (128, 256, 512) and c % 16 == 0 and h % 8 == 0 and w % 32 == 0
                     and self.conv.bias is not None and _lib.gn_nhwc_ok(cout, GN_GROUPS)):
-                # ... computed directly (libgqhip's upconv2x_f16x3: one kernel per Upsample, no patch matrix, no pixel-shuffle
-                # pass), with the bias added and the statistics of the next ResnetBlock's norm1 left behind
-                wm = self._phase_weights()
-                if getattr(self, "_phase_direct_key", None) != self._phase_key:
-                    self._phase_wf, self._phase_wf_us = _lib.upconv_weights_f16(wm, c, cout)
-                    self._phase_direct_key = self._phase_key
-                scales = _lib.f16_scales(st[0], 1.0, self._phase_wf_us)
-                y, ostats = _lib.upconv2x_direct(x, self._phase_wf, self._phase_wf_us, scales, bias=self.conv.bias,
-                                                 stats_groups=GN_GROUPS)
+                wf, wf_us = _cached(self, "phase_wf", _wkey(self.conv.weight),
+                                    lambda: _lib.upconv_weights_f16(self._phase_weights(), c, cout))
+                scales = _lib.f16_scales(st[0], 1.0, wf_us)
+                y, ostats = _lib.upconv2x_direct(x, wf, wf_us, scales, bias=self.conv.bias, stats_groups=GN_GROUPS)
                 y._gn_stats = (ostats, GN_GROUPS)
                 return y, None
-            if WINOGRAD_F16X3 and st is not None:
-                # the GEMM as fp16 x 3 over K (see WINOGRAD_F16X3); the activation's scale comes, on the device, from the
-                # GroupNorm statistics its producer left behind (sqrt of a group's sum of squares bounds its largest element)
-                w3, u_scale = self._phase_weights_f16()
-                scales = _lib.f16_scales(st[0], 1.0, u_scale)
-                full = torch.mm(_lib.upconv_im2col(x, scales), w3, out_dtype=torch.float32)
-            else:
-                scales = None
-                full = torch.matmul(_lib.upconv_im2col(x), self._phase_weights())      # hipBLASLt fp32 GEMM
-            full = full.view(b, h + 1, w + 1, 4 * self.conv.out_channels).permute(0, 3, 1, 2)   # NHWC view
-            return _lib.upconv_shuffle(full, self.conv.out_channels, scales), self.conv.bias
-        if fast:
+        if fast:   # shapes the direct kernel does not tile: upsample (a plain NHWC copy kernel), then the convolution
             from .. import _lib
 
             x = _lib.upsample2x_nhwc(x)   # ATen's NHWC nearest kernel runs at ~1.6 TB/s; this one is a plain copy
