@@ -96,8 +96,8 @@ __device__ __forceinline__ void tile_mfma_bf16(const u32x4 (&cv)[BfLayout<NV>::N
 }
 
 // ---- MIXED (round 2): the same filter value from ONE fp16 product and fp8 corrections.  Every operand q is split as
-// q = q_h + q_l with q_h = fp16(q) (|q_l| <= 2^-12 |q|):
-//     A s  =  A_h s_h  +  A_h s_l  +  A_l s_h  (+ A_l s_l <= 2^-24 |A s|)
+// q = q_h + q_l with q_h = fp16(q) (11 significant bits: |q_l| <= 2^-11 |q|):
+//     A s  =  A_h s_h  +  A_h s_l  +  A_l s_h  (+ A_l s_l <= 2^-22 |A s|)
 // The main product A_h s_h runs on v_mfma_f32_32x32x16_f16 (two K = 16 steps for the 32 slots of dim 16); both
 // correction types together are ONE v_mfma_scale_f32_32x32x64_f8f6f4 with OCP e4m3 operands: K block 0 = (s_l 2^11) x
 // (A_h 2^-6), K block 1 = s_h x (A_l 2^6), the E8M0 block scales 2^-11 2^6 and 2^-6 put them back (constants: the row's

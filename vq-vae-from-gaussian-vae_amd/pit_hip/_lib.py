@@ -524,6 +524,23 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
     return y
 
 
+_BMM_OUT_DTYPE = None
+
+
+def bmm_out_dtype_ok(device) -> bool:
+    """torch.bmm / torch.mm(..., out_dtype=torch.float32) on fp16 operands (fp32 accumulation AND fp32 result: what the fp16 x 3
+    library-GEMM routes need) exists in recent PyTorch-ROCm only.  Probed once, on the device, with a 16 x 16 product; the conv
+    stack takes its fp32-GEMM routes when it is missing (pit_hip/modules/unet.py) instead of raising a TypeError mid-forward."""
+    global _BMM_OUT_DTYPE
+    if _BMM_OUT_DTYPE is None:
+        try:
+            a = torch.ones(1, 16, 16, dtype=torch.float16, device=device)
+            _BMM_OUT_DTYPE = bool(torch.bmm(a, a, out_dtype=torch.float32).dtype == torch.float32)
+        except (TypeError, RuntimeError):
+            _BMM_OUT_DTYPE = False
+    return _BMM_OUT_DTYPE
+
+
 ATTN_L_OK = (64, 256, 1024, 2304, 4096)   # token counts attn_softmax_split_f16x3 is instantiated for
 
 

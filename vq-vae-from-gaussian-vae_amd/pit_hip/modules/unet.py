@@ -1,4 +1,4 @@
-"""SD3-style conv encoder / decoder, kept in PyTorch-ROCm (MIOpen / hipBLASLt).
+"""SD3-style conv encoder / decoder as ``torch.nn`` modules over libgqhip's conv-stack kernels.
 
 Mirror of the reference's ``pit/modules/unet.py`` interface for the hot path:
 ``Encoder(**params)(x) -> [B, 2*z, H/8, W/8]`` (unet.py:317-436) and
@@ -6,6 +6,12 @@ Mirror of the reference's ``pit/modules/unet.py`` interface for the hot path:
 laid out so that ``state_dict()`` keys equal the reference's (``conv_in``,
 ``down.{i}.block.{j}.norm1`` ... ``up.{i}.upsample.conv``), so a reference
 checkpoint's ``encoder.*`` / ``decoder.*`` tensors load unchanged.
+
+Two execution paths.  A module left in NCHW runs ATen / MIOpen convolutions with libgqhip's fused GroupNorm and residual
+kernels (the drop-in default).  A module converted with ``.to(memory_format=torch.channels_last)`` -- the bench
+configuration -- runs every convolution but ``conv_in`` in libgqhip (direct fp16 x 3 implicit GEMMs, Winograd transforms
+around fp16 GEMMs, fp32 matrix-core convolutions for the layers next to z) and is bit-reproducible run to run; which kernel
+serves which layer: profiles/r03/route_table.txt.  Training / autograd / CPU tensors always take the ATen ops.
 
 Only what the shipped SD3-UNet configs use is built: ``attn_type`` "vanilla"
 (single-head SDPA, unet.py:166-206) or "none"; ``temb_channels`` is always 0 on
@@ -75,11 +81,18 @@ def _defer_ok(x: torch.Tensor, conv: nn.Conv2d) -> bool:
             and conv.bias is not None and conv.padding_mode == "zeros")
 
 
+def _f16_gemm_ok(x: torch.Tensor) -> bool:
+    """The library-GEMM half of the fp16 x 3 routes needs bmm(out_dtype=fp32) (recent PyTorch-ROCm): probed once."""
+    from .. import _lib
+
+    return _lib.bmm_out_dtype_ok(x.device)
+
+
 def _f16_args(conv: nn.Conv2d, x: torch.Tensor, f4: bool):
     """(U3, u_scale, bound) for _lib.wino_conv3x3's fp16 x 3 route, or None: needs a rigorous bound on |x| (left on the
     tensor by _norm_act: every Winograd convolution of this UNet is fed by GroupNorm + swish)."""
     bound = getattr(x, "_act_bound", None)
-    if not WINOGRAD_F16X3 or bound is None:
+    if not WINOGRAD_F16X3 or bound is None or not _f16_gemm_ok(x):
         return None
     u3, u_scale, wf2 = _wino_weights_f16(conv, f4)
     return u3, u_scale, bound, (wf2 if WINOGRAD_OWN_GEMM else None)
@@ -88,7 +101,7 @@ def _f16_args(conv: nn.Conv2d, x: torch.Tensor, f4: bool):
 def _f16_args_gn(conv: nn.Conv2d, norm: nn.GroupNorm, x: torch.Tensor, f4: bool):
     """_f16_args for a convolution whose GroupNorm + swish runs inside the input transform: the bound is that of the
     activated tensor, which is never materialised."""
-    if not WINOGRAD_F16X3:
+    if not WINOGRAD_F16X3 or not _f16_gemm_ok(x):
         return None
     u3, u_scale, wf2 = _wino_weights_f16(conv, f4)
     return u3, u_scale, _gn_act_bound(norm, x), (wf2 if WINOGRAD_OWN_GEMM else None)
@@ -613,7 +626,7 @@ class AttnBlock(nn.Module):
             else:
                 qkv = None
                 q, k, v = (f(y).permute(0, 2, 3, 1).reshape(b, 1, h * w, c) for f in (self.q, self.k, self.v))
-            if ATTN_F16X3 and qkv is not None and qkv.is_contiguous() and c % 4 == 0:
+            if ATTN_F16X3 and qkv is not None and qkv.is_contiguous() and c % 4 == 0 and _f16_gemm_ok(qkv):
                 from .. import _lib
 
                 if (h * w) in _lib.ATTN_L_OK:
