@@ -1,0 +1,122 @@
+// Calibration: what write rate does THIS device sustain for the compat op's output pattern?  The score matrix is
+// rows x n fp32 (16 384 x 65 536: rows 256 KiB apart); an MFMA tile hands a wave TR rows x a few hundred bytes at a time, so the
+// stream a wave emits is "a short run in each of TR rows", not the linear sweep a fill makes (6.9 TB/s).  This program emits
+// pure stores (no loads, no matrix work) in parameterised patterns:
+//   TR    rows per wave tile            TC   bytes per row and tile        NT  tiles a wave walks along its rows
+//   vec   1: one dword per lane (256-byte run per instruction), 4: dwordx4 (TC >= 1024: 1 KiB run of one row; else 4 rows x 256 B)
+//   order 0: rows inner (all rows of a 256-byte / 1 KiB column piece, then the next piece)   1: columns inner
+//   rot   1: row block b starts at tile (5 b) % NT of its split and wraps
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/store_pattern tools/store_pattern.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct P {
+  float *out;
+  long row_bytes;
+  int rows, TR, TC, NT, vec, order, rot, nsplit;
+};
+
+__global__ __launch_bounds__(256) void store_kernel(const P p) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int split = blockIdx.x % p.nsplit, rowblk = blockIdx.x / p.nsplit;
+  const long row0 = ((long)rowblk * 4 + wave) * p.TR;
+  if (row0 >= p.rows) return;
+  char *base = reinterpret_cast<char *>(p.out) + row0 * p.row_bytes + (long)split * p.NT * p.TC;
+  const int start = p.rot ? (int)((unsigned)rowblk * 5u % (unsigned)p.NT) : 0;
+  const float v = (float)lane;
+  for (int t0 = 0; t0 < p.NT; ++t0) {
+    int t = t0 + start;
+    t = t >= p.NT ? t - p.NT : t;
+    char *tb = base + (long)t * p.TC;
+    if (p.vec == 1) {
+      const int pieces = p.TC / 256;
+      if (p.order == 0) {
+        for (int c = 0; c < pieces; ++c)
+          for (int r = 0; r < p.TR; ++r) *reinterpret_cast<float *>(tb + r * p.row_bytes + c * 256 + lane * 4) = v;
+      } else {
+        for (int r = 0; r < p.TR; ++r)
+          for (int c = 0; c < pieces; ++c) *reinterpret_cast<float *>(tb + r * p.row_bytes + c * 256 + lane * 4) = v;
+      }
+    } else if (p.TC >= 1024) {
+      const int pieces = p.TC / 1024;
+      const f32x4 vv = {v, v, v, v};
+      if (p.order == 0) {
+        for (int c = 0; c < pieces; ++c)
+          for (int r = 0; r < p.TR; ++r) *reinterpret_cast<f32x4 *>(tb + r * p.row_bytes + c * 1024 + lane * 16) = vv;
+      } else {
+        for (int r = 0; r < p.TR; ++r)
+          for (int c = 0; c < pieces; ++c) *reinterpret_cast<f32x4 *>(tb + r * p.row_bytes + c * 1024 + lane * 16) = vv;
+      }
+    } else {
+      const int per = 1024 / p.TC;         // rows per instruction
+      const int lanes_per_row = 64 / per;
+      const f32x4 vv = {v, v, v, v};
+      for (int r = 0; r < p.TR; r += per)
+        *reinterpret_cast<f32x4 *>(tb + (r + lane / lanes_per_row) * p.row_bytes + (lane % lanes_per_row) * 16) = vv;
+    }
+  }
+}
+
+int main(int argc, char **argv) {
+  const int rows = 16384;
+  const long row_bytes = 65536L * 4;
+  float *out;
+  if (hipMalloc(&out, rows * row_bytes) != hipSuccess) return 1;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  // plain fill for reference
+  {
+    hipMemsetAsync(out, 0, rows * row_bytes, 0);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 5; ++i) hipMemsetAsync(out, 0, rows * row_bytes, 0);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("hipMemsetAsync: %.3f ms -> %.0f GB/s\n", ms / 5, rows * row_bytes / (ms / 5) / 1e6);
+  }
+  struct Cfg { int TR, TC, span, vec, order, rot; };   // span: bytes of a row one wave walks
+  const Cfg cfgs[] = {
+      {64, 256, 32768, 1, 0, 0},    // the shipped kernel: 64 rows x 256 B, 8 splits
+      {64, 256, 32768, 1, 0, 1},
+      {32, 256, 32768, 1, 0, 1},
+      {64, 256, 32768, 4, 0, 1},    // WIDE
+      {32, 512, 32768, 1, 0, 1},    // two pieces, rows inner
+      {32, 512, 32768, 1, 1, 1},    // two pieces, columns inner
+      {32, 1024, 32768, 1, 0, 1},
+      {32, 1024, 32768, 1, 1, 1},
+      {32, 1024, 32768, 4, 0, 1},   // 1 KiB runs in one instruction
+      {16, 1024, 32768, 4, 0, 1},
+      {32, 2048, 32768, 4, 1, 1},
+      {32, 4096, 32768, 4, 1, 1},
+      {16, 4096, 32768, 4, 1, 1},
+      {8, 4096, 32768, 4, 1, 1},
+      {32, 1024, 8192, 4, 0, 1},
+      {32, 1024, 262144, 4, 0, 0},  // one wave walks whole rows
+      {32, 1024, 1024, 4, 0, 0},    // one tile per wave (256 splits)
+      {64, 256, 1024, 1, 0, 0},
+      {4, 262144, 262144, 4, 1, 0}, // whole rows, columns inner: nearly linear
+      {1, 262144, 262144, 4, 1, 0},
+  };
+  for (const Cfg &c : cfgs) {
+    P p{};
+    p.out = out; p.row_bytes = row_bytes; p.rows = rows;
+    p.TR = c.TR; p.TC = c.TC; p.NT = c.span / c.TC; p.vec = c.vec; p.order = c.order; p.rot = c.rot;
+    p.nsplit = (int)(row_bytes / c.span);
+    const int row_blocks = rows / (4 * c.TR);
+    const unsigned grid = (unsigned)(row_blocks * p.nsplit);
+    hipLaunchKernelGGL(store_kernel, dim3(grid), dim3(256), 0, 0, p);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(store_kernel, dim3(grid), dim3(256), 0, 0, p);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("TR %3d  TC %6d  span %6d  vec %d  order %d  rot %d  grid %5u: %.3f ms -> %.0f GB/s\n", c.TR, c.TC, c.span, c.vec, c.order,
+           c.rot, grid, ms / 5, rows * row_bytes / (ms / 5) / 1e6);
+  }
+  return 0;
+}

@@ -12,11 +12,16 @@
 // accumulator register holds one code column for 16 rows.  Block = 4 waves x RT row tiles of 32 rows; blockIdx % nsplit =
 // code split (multiple of 8: each XCD's L2 streams 1/8 of the codebook), chunks of CT tiles staged through LDS exactly
 // like gq_filter_kernel.  Tiles are processed in PAIRS so that a store instruction writes one 256-byte run (below).
-// Where the time goes at 16 384 x 65 536 x dim 16 (4.29 GB; diagnostic builds, profiles/r03/scores_ablation.txt): the
-// matrix work alone 0.55 ms (80 % of the fp32 MFMA peak), the store stream alone 0.86 ms = 5.0 TB/s (a torch fill of the same
-// buffer: 6.9 TB/s -- one dword per lane and instruction is what the store path issues here, whatever the run length:
-// 128-byte and 256-byte runs measured the same, and so did 32 instead of 128 write streams per wave quartet), both
-// together 1.05 ms = 4.1 TB/s: the two overlap only partly because a wave's stores follow its own MFMAs.
+// Where the time goes at 16 384 x 65 536 x dim 16 (4.29 GB; diagnostic builds and counters, profiles/r03/scores_ablation.txt,
+// scores_pmc.txt, store_pattern.txt): the matrix work alone 0.55 ms (1.20 M shader cycles at 2.18 GHz, matrix pipes 88 % busy),
+// the store stream alone 0.83-0.86 ms (2.02 M cycles at 2.35 GHz = 5.0-5.3 TB/s; a kernel that ONLY stores reaches 5.4-5.7 TB/s
+// on this device whatever the pattern -- 64 rows x 256 B, 32 rows x 1 KiB in one dwordx4 instruction, whole rows -- and a
+// torch fill 6.9), both together 1.05-1.09 ms = 1.91 M cycles: in CYCLES the two overlap completely (fewer cycles than the
+// stores alone), but under fp32 MFMA load the chip holds 1.75 GHz instead of 2.35, and the store path moves ~2150 bytes per
+// shader cycle either way.  Tried on top and measured within 4 %: dwordx4 stores through a wave-private LDS transpose, stores
+// of the previous tile issued between the MFMAs of the next (ping-pong accumulators), one row tile per wave at 4 blocks per CU,
+// waves of a block sharing rows, 16 ... 256 code splits.  What does help the store-bound dims (4 / 8: 61-63 % -> 66-67 %) is
+// the rotation below: blocks that run together no longer write the same column phase of rows 256 KiB apart.
 // The expansion differs from the per-pair formula by ~2^-24 * sum_i |terms| (cancellation between n^2/sd^2, mu n/sd^2 and
 // mu^2/sd^2): relative to the score's own magnitude that is a few ulp, and the arg-max can differ from the per-pair
 // formula's only at rounding ties -- the same caveat the CUDA kernel's own rounding carries (its bits cannot be pinned
@@ -32,6 +37,7 @@ struct ScoresParams {
   int rows, n;
   double beta;
   int nsplit, tiles_total, tiles_per_split;
+  int rot;          // bit 0: chunk order rotated by the row block, bit 1: pair order rotated by the wave (see the kernel)
 };
 
 template <int DIM, int RT, int CT>
@@ -124,14 +130,19 @@ __global__ __launch_bounds__(256, 2) void gq_scores_mfma_kernel(const ScoresPara
 
   const int ntiles = t_end - t_begin;
   const int nchunks = ntiles > 0 ? (ntiles + CT - 1) / CT : 0;
+  // Rotation: every block of a split walks the same columns, and rows are n * 4 bytes apart (256 KiB at 65 536 codes) -- without
+  // it all blocks that run together write the same few column phases at the same time, i.e. the same few memory channels.
+  // Block rowblk starts at chunk rot0 of its split and wraps; inside a chunk wave w starts at pair w.
+  const int rot0 = (p.rot & 1) && nchunks > 1 ? (int)((unsigned)rowblk * 5u % (unsigned)nchunks) : 0;
+  auto chunk_of = [&](int ch) { const int k = ch + rot0; return k >= nchunks ? k - nchunks : k; };
   if (nchunks > 0) {
-    load_chunk(t_begin);
+    load_chunk(t_begin + chunk_of(0) * CT);
     store_chunk(0);
   }
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
-    const int tile0 = t_begin + ch * CT;
-    if (ch + 1 < nchunks) load_chunk(tile0 + CT);
+    const int tile0 = t_begin + chunk_of(ch) * CT;
+    if (ch + 1 < nchunks) load_chunk(t_begin + chunk_of(ch + 1) * CT);
     const int nt = min(CT, t_end - tile0);
     const float *val = lds[ch & 1][0] + c * DIM;
     const float *sq = lds[ch & 1][1] + c * DIM;
@@ -161,7 +172,10 @@ __global__ __launch_bounds__(256, 2) void gq_scores_mfma_kernel(const ScoresPara
     // v_permlane32_swap exchanges A's upper half with B's lower half, so one register then holds 64 CONSECUTIVE codes of row
     // ro and the other those of row ro + 4: every store instruction writes one 256-byte run instead of two 128-byte runs in
     // two rows (measured with the matrix work compiled out: 5.0 -> ... TB/s; a plain fill of the buffer runs at 6.9).
-    for (; tt + 1 < nt; tt += 2) {
+    const int npairs = nt >> 1;
+    const int prot = (p.rot & 2) ? wave_u % max(npairs, 1) : 0;
+    for (int tp = 0; tp < npairs; ++tp) {
+      tt = 2 * (tp + prot >= npairs ? tp + prot - npairs : tp + prot);
       f32x16 d0[RT], d1[RT];
       compute(tt, d0);
       compute(tt + 1, d1);
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gq_scores_mfma_kernel(const ScoresPara
 #if defined(GQHIP_ABL) && (GQHIP_ABL & 32)       // diagnostic build: no stores (what the matrix work alone takes)
       if (d0[0][0] == 12345.678f && d1[RT - 1][15] == 0.5f)
 #endif
-      if (code0 + 2 * kTileCodes <= p.n) {          // wave-uniform: the swap below is a cross-lane operation
+      if (code0 + 2 * kTileCodes <= p.n) {   // wave-uniform: the swap below is a cross-lane operation
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           float *base = p.out + (tile_row0 + 32 * rt) * p.n + code0 + lane;     // row 0 of the tile, this lane's column
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gq_scores_mfma_kernel(const ScoresPara
         }
       }
     }
-    for (; tt < nt; ++tt) {          // an odd tile at the end of the split
+    for (tt = 2 * npairs; tt < nt; ++tt) {          // an odd tile at the end of the split
       f32x16 d[RT];
       compute(tt, d);
       const int code0 = (tile0 + tt) * kTileCodes;

@@ -618,10 +618,15 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
     ScoresParams sp{};
     sp.mu = mu; sp.sd = sd; sp.cb = cb; sp.out = out; sp.rows = (int)rows; sp.n = (int)n; sp.beta = beta;
     sp.tiles_total = (int)((n + kTileCodes - 1) / kTileCodes);
+    // diagnostics (tools/scores_sweep.sh): code splits per row block; bit 0 / 1 of the rotation (gq_scores.h), default both
+    static const int env_nsplit = getenv("GQHIP_SCORES_NSPLIT") ? atoi(getenv("GQHIP_SCORES_NSPLIT")) : 0;
+    static const int env_rot = getenv("GQHIP_SCORES_ROT") ? atoi(getenv("GQHIP_SCORES_ROT")) : 3;
+    sp.rot = env_rot;
     constexpr int RT = 2;
     const int row_blocks = (int)((rows + 128 * RT - 1) / (128 * RT));
     int s = (512 + row_blocks - 1) / row_blocks;      // ~2 blocks per CU; splits in multiples of 8 (XCD = blockIdx % 8)
     s = ((s + 7) / 8) * 8;
+    if (env_nsplit > 0) s = env_nsplit;
     if (s > sp.tiles_total) s = sp.tiles_total;
     if (s < 1) s = 1;
     sp.tiles_per_split = (sp.tiles_total + s - 1) / s;
