@@ -86,8 +86,13 @@ __device__ __forceinline__ bool conv3_tile(const Conv3Params &p, Conv3Tile &t, l
 __device__ __forceinline__ void conv3_tap(const unsigned char *A, int dy, const f16x8 (&bq)[4], f32x16 (&acc)[4][2]) {
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 256)        // diagnostic build: one A operand per tap instead of eight
+    const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + dy * kC3RS * 32);
+    const f16x8 al = ah;
+#else
     const f16x8 ah = *reinterpret_cast<const f16x8 *>(A + (rr + dy) * kC3RS * 32);
     const f16x8 al = *reinterpret_cast<const f16x8 *>(A + (rr + dy) * kC3RS * 32 + kC3Plane);
+#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       acc[rr][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[2 * j], acc[rr][j], 0, 0, 0);
@@ -159,6 +164,9 @@ struct Conv3GnParams {
   float scale;
 };
 
+#ifdef GQHIP_CLOCK_STAMPS
+__device__ unsigned long long g_c3_stamps[4 * 8192];   // diagnostic build: per-block timeline (tools/c3_timeline.py)
+#endif
 template <int SILU, int COUT>
 __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnParams pp) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -168,6 +176,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
   __shared__ __attribute__((aligned(16))) float sAff[2][512];   // folded scale, shift per input channel (cin <= 512)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   Conv3Tile t;
   if (!conv3_tile(p, t)) return;
   const int H = p.H, W = p.W, cin = pp.cin;
@@ -256,6 +267,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
   }
   __syncthreads();
 
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int chunk = 0; chunk < p.nch; ++chunk) {
     const bool more = chunk + 1 < p.nch;
     const unsigned char *A = sA + (chunk & 1) * kC3Buf;
@@ -263,18 +277,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ks = chunk * 9 + tap;
+#if !(defined(GQHIP_ABL) && (GQHIP_ABL & 128))     // diagnostic build: weights loaded once
       load_b(ks + 2 < nks ? ks + 2 : nks - 1, bs[(tap + 2) % 3]);
+#endif
       conv3_tap(A + aoff[tap % 3], tap / 3, bs[tap % 3], acc);
+#if !(defined(GQHIP_ABL) && (GQHIP_ABL & 64))      // diagnostic build: no staging of the next chunk
       if (more) {
         if (tap >= 3) convert(tap - 3, chunk + 1, nbuf);
         if (tap < kC3Loads) issue(tap, chunk + 1);
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting the LDS reads of later taps (spills otherwise)
     }
     __syncthreads();
   }
+#ifdef GQHIP_CLOCK_STAMPS
+  const unsigned long long st_r2 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 512)         // diagnostic build: no epilogue
+  if (acc[0][0][0] == 12345.678f)
+#endif
   conv3_epilogue<COUT>(p, t, acc, red, tid, wm, wn, c, h);
+#ifdef GQHIP_CLOCK_STAMPS
+  if (tid == 0 && blockIdx.x < 8192) {
+    unsigned long long *o = g_c3_stamps + 4 * blockIdx.x;
+    o[0] = st_r0;
+    o[1] = __builtin_amdgcn_s_memrealtime();
+    o[2] = ((st_r1 - st_r0) << 32) | (st_r2 - st_r0);   // prologue end, loop end (100 MHz ticks from block start)
+    o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
 }
+
+// Where the time goes (round 3; profiles/r03/conv3_diagnosis.txt): per block (16 x 256 x 256 x 128 -> 128, 4096 blocks, two per
+// CU) prologue 12 us, main loop 106 us, epilogue 21 us; the matrix pipes are busy 54 % of 1.65 M cycles at the 1.62 GHz the chip
+// holds.  Diagnostic builds (make ablu ABL=...): without the weight loads 1.34 M cycles, without staging the next chunk 1.27 M,
+// without the epilogue 1.37 M, one A operand per tap instead of eight 1.79 M (LDS reads cost nothing), all off 0.98 M cycles
+// (pipes 90 % busy at 1.88 GHz).  Tried and measured within 2 %: delaying the second block of every CU by 10-80 us (the two
+// blocks' phases are already spread: both are inside their main loop 50 % of the time, one 46 %), one block per CU (1124 vs
+// 1019 us: a wave alone on its SIMD runs its main loop almost twice as fast), weight loads pinned to the top of the tap and the
+// conversion's ~60 VALU instructions spread between the MFMAs with sched_group_barrier (hipcc keeps them in one block; 8 spills),
+// a wave owning 8 rows x 32 channels (two weight operands per tap instead of four, none loaded twice per block, 16 A reads:
+// bit-identical, no spills, 1045 vs 1031-1052 us).  The texture addresser is busy 26 % of the cycles, L2 read latency averages
+// 317 cycles, 67 % of the L2 requests hit: no unit of the memory pipeline is saturated -- the waves' in-order waits are.
 
 // Measured alternative (round 2, removed): a wave-specialised persistent variant -- one block of 8 waves per CU, waves 0-3
 // only multiplying (every operand from LDS, next tap's operands read under the current tap's MFMAs), waves 4-7 only

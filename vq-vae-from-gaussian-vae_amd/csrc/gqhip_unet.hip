@@ -325,6 +325,12 @@ int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, cons
   return check_launch();
 }
 
+#ifdef GQHIP_CLOCK_STAMPS
+extern "C" int gqhip_debug_c3_stamps(unsigned long long *out, int64_t words) {   // diagnostic build only
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c3_stamps), sizeof(unsigned long long) * words) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf, const float *scales_dev_or_null, float scale,
                   float mscale, const float *bias_or_null, const float *res_or_null, float *y, int64_t *stats_out_or_null, int64_t B, int64_t HW,
                   int64_t Cin, int64_t Cout, int64_t groups_out, void *stream) {
