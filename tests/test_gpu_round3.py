@@ -295,3 +295,31 @@ def test_fp16x3_routes_hold_fp32_grade_accuracy_with_checkpoint_like_weights(whi
     assert torch.isfinite(y_cl).all()
     assert e_cl <= max(2.0 * e_lib, 1e-5), (e_cl, e_lib)
     assert e_cl <= 5e-5, e_cl
+
+
+# ------------------------------------------------------------------------------------------ compat op: every tiling path
+@pytest.mark.parametrize("dim,rows,n", [(16, 600, 65536 + 40), (4, 300, 4096 + 33), (32, 520, 8192), (8, 37, 65536), (16, 257, 96)])
+def test_compat_scores_tile_pairs_chunk_rotation_and_ragged_edges(dim, rows, n):
+    """gq_scores_f32's matrix-core kernel beyond the small cases of test_compat_scores_op_matches_cuda_formula: several row
+    blocks (the chunk order is rotated by the row block), several chunks per code split with a ragged last one, tile pairs
+    (two tiles leave as one 256-byte run per row) with the pair order rotated by the wave, a codebook that ends inside a
+    pair, a row count that ends inside a wave's tile.  Against the per-pair restatement of gq_cuda.cu:31-38 (oracle)."""
+    import oracle.gq_oracle as O
+    from pit_hip import _lib
+
+    g = torch.Generator().manual_seed(dim * 1000 + rows)
+    mu = 0.9 * torch.randn(rows, dim, generator=g)
+    sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(rows, dim, generator=g)))
+    cb = torch.randn(n, dim, generator=g).clamp(-4.6, 4.6)
+    out = torch.full((rows, n), float("nan"), device=DEV)
+    _lib.gq_scores(mu.to(DEV), sd.to(DEV), cb.to(DEV), out, 1.0)
+    got = out.cpu().numpy()
+    ref = O.cuda_formula_scores(mu.numpy(), sd.numpy(), cb.numpy(), 1.0)
+    assert np.isfinite(got).all()                    # every element written (the buffer started as NaN)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert np.abs(got - ref).max() <= 2e-5 * scale.max()
+    np.testing.assert_allclose(got, ref, rtol=5e-5, atol=2e-5 * float(scale.max()))
+    # the same kernel launched again writes the same bits (fixed tiling, no atomics)
+    out2 = torch.empty_like(out)
+    _lib.gq_scores(mu.to(DEV), sd.to(DEV), cb.to(DEV), out2, 1.0)
+    assert torch.equal(out, out2)
