@@ -315,8 +315,9 @@ int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, cons
   gp.x = x; gp.gamma = gamma; gp.beta = beta; gp.pre_bias = pre_bias_or_null; gp.stats_in = stats_in;
   gp.cin = (int)Cin; gp.cpg_in = (int)(Cin / groups_in); gp.eps = eps; gp.scale = scale;
   const dim3 grid((unsigned)(8 * cp.tiles_per_xcd * cp.nnb));
+  static const int env_dyn = getenv("GQHIP_C3_DYNLDS") ? atoi(getenv("GQHIP_C3_DYNLDS")) : 0;   // diagnostic: extra LDS -> one block per CU
   if (Cout == 128) {
-    if (apply_silu) hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<1, 128>), grid, dim3(256), 0, st, gp);
+    if (apply_silu) hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<1, 128>), grid, dim3(256), env_dyn, st, gp);
     else hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<0, 128>), grid, dim3(256), 0, st, gp);
   } else {
     if (apply_silu) hipLaunchKernelGGL((conv3x3_gn_f16x3_kernel<1, 256>), grid, dim3(256), 0, st, gp);
