@@ -95,7 +95,11 @@ int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim);
 
 /* ---- compat op: the reference's native boundary ---------------------------
  * out[r, j] = sum_i -((cb[j,i]-mu[r,i])/sd[r,i])^2 + cb[j,i]^2 * beta
- * mu, sd [rows, dim]; cb [n, dim]; out [rows, n]; all fp32 contiguous. */
+ * mu, sd [rows, dim]; cb [n, dim]; out [rows, n]; all fp32 contiguous.
+ * dims 4 / 8 / 16 / 32: the expanded form [beta - 1/sd^2 | 2 mu/sd^2] x [cb^2 | cb] + const on the matrix cores (fp32 MFMA at
+ * dims 4 / 8; three fp16 products of two-term splits with fp32 accumulation at dims 16 / 32 -- error vs an fp64 evaluation
+ * <= ~4e-7 of sum_i |terms| per element in either form, the level of the per-pair formula in fp32); other dims, n < 32 or a
+ * NaN beta: the per-pair formula.  Environment: GQHIP_SCORES=f32 (fp32 MFMA at dims 16 / 32 too), =direct (per-pair always). */
 int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
                   int64_t dim, int64_t rows, int64_t n, double beta,
                   void *stream);

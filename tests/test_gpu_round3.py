@@ -323,3 +323,57 @@ def test_compat_scores_tile_pairs_chunk_rotation_and_ragged_edges(dim, rows, n):
     out2 = torch.empty_like(out)
     _lib.gq_scores(mu.to(DEV), sd.to(DEV), cb.to(DEV), out2, 1.0)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dim,beta", [(16, 1.0), (32, 1.0), (16, 0.25)])
+def test_compat_scores_fp16_products_ranges_and_out_of_range_chunks(dim, beta):
+    """Dims 16 / 32 of gq_scores_f32 run as three fp16 products of two-term splits (csrc/gq_scores_f16.h).  What that form has
+    to get right beyond random data: rows whose coefficients 1/sd^2 span 1e-6 ... 1e8 (per-row power-of-two scaling), one
+    dominant dimension, large means, a chunk of codes with a value outside fp16's range (|n| > 255: recomputed by the per-pair
+    formula in the kernel's second pass) or with an infinite one, tiny code values (fp16 subnormals: absolute error), a row with
+    sd = 0 (non-finite row, neighbours untouched).  Gate: |out - fp64| <= 8e-7 of sum_i |terms| per element (+ the absolute floor of
+    sub-normal code values) -- the level of the fp32 kernels (measured on random data: 2.9-3.8e-7 here, 4.5-6.5e-7 for the fp32 MFMA kernel, 4.9-5.0e-7 per pair)."""
+    from pit_hip import _lib
+
+    rows, n = 200, 4096 + 17
+    g = torch.Generator().manual_seed(dim + int(beta * 100))
+    mu = 0.9 * torch.randn(rows, dim, generator=g)
+    sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(rows, dim, generator=g)))
+    cb = torch.randn(n, dim, generator=g).clamp(-4.6, 4.6)
+    sd[3, :] = 1e-4
+    sd[4, :] = 1e3
+    sd[5, 2] = 1e-5
+    mu[6, :] = 50.0
+    sd[8, :] = torch.logspace(-3, 2, dim)
+    cb[700, 3] = 300.0             # out of fp16's range for n^2: its chunk takes the second pass
+    cb[2000, :] = 1e-5             # squares far below fp16's subnormals
+    cb[2001, :] = 0.0
+    cb[3000, 1] = float("inf")
+    sd[7, 0] = 0.0
+    out = torch.full((rows, n), float("nan"), device=DEV)
+    _lib.gq_scores(mu.to(DEV), sd.to(DEV), cb.to(DEV), out, beta)
+    got = out.cpu().double()
+    m, s_, c = mu.double()[:, None, :], sd.double()[:, None, :], cb.double()[None, :, :]
+    with np.errstate(all="ignore"):
+        ref = (-((c - m) / s_) ** 2 + beta * c * c).sum(-1)
+        terms = (((beta - 1.0 / s_ ** 2).abs() * c * c) + (2 * m / s_ ** 2 * c).abs() + (m / s_) ** 2).sum(-1)
+    ok_rows = torch.ones(rows, dtype=torch.bool)
+    ok_rows[7] = False
+    ok_cols = torch.ones(n, dtype=torch.bool)
+    ok_cols[3000] = False
+    sub = lambda t: t[ok_rows][:, ok_cols]
+    assert torch.isfinite(sub(got)).all()
+    # code values below fp16's normal range (|n| or n^2 < 2^-14 after the split) keep an absolute quantisation <= 2^-25 each:
+    # the floor 2^-24 sum_i (|A'_i| + |B'_i|) next to the relative term (row 4 x code 2000 is that case: n^2 = 1e-10)
+    floor = 2.0 ** -24 * ((beta - 1.0 / s_ ** 2).abs() + (2 * m / s_ ** 2).abs()).sum(-1).expand(rows, n)
+    excess = (sub(got) - sub(ref)).abs() - floor[ok_rows][:, ok_cols]
+    rel = excess / sub(terms)
+    assert float(rel.max()) <= 8e-7, float(rel.max())
+    assert not torch.isfinite(got[7]).any()                       # sd = 0: the whole row is inf / NaN, as in the per-pair formula
+    assert not torch.isfinite(got[ok_rows][:, 3000]).any()        # an infinite code value: that column only
+    # the chunk that went through the second pass (codes 512 ... 767 at 8 tiles of 32) agrees with the oracle's per-pair formula
+    import oracle.gq_oracle as O
+
+    ref32 = O.cuda_formula_scores(mu.numpy(), sd.numpy(), cb.numpy(), beta)
+    blk = got[ok_rows][:, 512:768].float().numpy()
+    np.testing.assert_allclose(blk, ref32[ok_rows.numpy()][:, 512:768], rtol=2e-5, atol=2e-5 * float(np.abs(ref32[ok_rows.numpy()][:, 512:768]).max()))

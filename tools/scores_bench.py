@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dims", default="16")
 ap.add_argument("--rows", default="1024,4096,16384")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--accuracy", action="store_true", help="error of the selected kernel against an fp64 evaluation, 512 rows x 8192 codes")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -36,6 +37,21 @@ def timed(fn, iters):
     return s.elapsed_time(e) / iters
 
 
+if a.accuracy:
+    for dim in [int(d) for d in a.dims.split(",")]:
+        cb = torch.randn(8192, dim, generator=g).clamp(-4.6, 4.6).to(dev)
+        mu = (0.9 * torch.randn(512, dim, generator=g)).to(dev)
+        sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(512, dim, generator=g))).to(dev)
+        out = torch.empty(512, 8192, device=dev)
+        _lib.gq_scores(mu, sd, cb, out, 1.0)
+        m, s_, c = mu.double()[:, None, :], sd.double()[:, None, :], cb.double()[None, :, :]
+        ref = (-((c - m) / s_) ** 2 + c * c).sum(-1)
+        terms = (((1.0 - 1.0 / s_ ** 2).abs() * c * c) + (2 * m / s_ ** 2 * c).abs() + (m / s_) ** 2).sum(-1)
+        err = (out.double() - ref).abs()
+        print(f"accuracy dim {dim} (GQHIP_SCORES={os.environ.get('GQHIP_SCORES', 'default')}): max |out - fp64| = {float(err.max()):.3e}; "
+              f"max over elements of |out - fp64| / sum|terms| = {float((err / terms).max()):.3e} (2^-24 = 5.96e-08); "
+              f"relative to |score|: {float((err / ref.abs().clamp_min(1e-3)).max()):.3e}")
+    sys.exit(0)
 for dim in [int(d) for d in a.dims.split(",")]:
     cb = torch.randn(n, dim, generator=g).clamp(-4.6, 4.6).to(dev)
     for rows in [int(r) for r in a.rows.split(",")]:

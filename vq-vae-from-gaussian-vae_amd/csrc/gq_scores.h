@@ -22,6 +22,8 @@
 // of the previous tile issued between the MFMAs of the next (ping-pong accumulators), one row tile per wave at 4 blocks per CU,
 // waves of a block sharing rows, 16 ... 256 code splits.  What does help the store-bound dims (4 / 8: 61-63 % -> 66-67 %) is
 // the rotation below: blocks that run together no longer write the same column phase of rows 256 KiB apart.
+// Dims 16 and 32 run the same product as three fp16 products of two-term splits instead (gq_scores_f16.h: a fifth of the matrix
+// cycles, 62-65 % of 8 TB/s at dim 16); this kernel serves dims 4 / 8 and GQHIP_SCORES=f32.
 // The expansion differs from the per-pair formula by ~2^-24 * sum_i |terms| (cancellation between n^2/sd^2, mu n/sd^2 and
 // mu^2/sd^2): relative to the score's own magnitude that is a few ulp, and the arg-max can differ from the per-pair
 // formula's only at rounding ties -- the same caveat the CUDA kernel's own rounding carries (its bits cannot be pinned

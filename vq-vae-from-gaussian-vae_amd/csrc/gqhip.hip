@@ -21,6 +21,7 @@
 #include "gq_prep.h"
 #include "gq_rerank.h"
 #include "gq_scores.h"
+#include "gq_scores_f16.h"
 #include "gq_tail.h"
 
 using namespace gqhip;
@@ -610,8 +611,9 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
   if (rows == 0) return GQHIP_OK;
   if (!mu || !sd || !cb || !out) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // Default: the score matrix on the fp32 matrix cores (gq_scores.h; HBM-write bound).  GQHIP_SCORES=direct: the
-  // per-pair restatement of the CUDA kernel's formula (VALU bound, ~3x slower).  Non-finite beta, dims outside
+  // Default: the score matrix on the matrix cores, HBM-write bound -- dims 16 / 32 as three fp16 products of two-term splits
+  // (gq_scores_f16.h), dims 4 / 8 on the fp32 matrix cores (gq_scores.h; GQHIP_SCORES=f32: at every dim).  GQHIP_SCORES=direct:
+  // the per-pair restatement of the CUDA kernel's formula (VALU bound, ~3x slower).  Non-finite beta, dims outside
   // {4, 8, 16, 32}: per-pair kernels.
   static const bool env_direct = getenv("GQHIP_SCORES") && getenv("GQHIP_SCORES")[0] == 'd';
   if (!env_direct && (dim == 4 || dim == 8 || dim == 16 || dim == 32) && beta == beta && n >= 32) {
@@ -632,6 +634,16 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
     sp.tiles_per_split = (sp.tiles_total + s - 1) / s;
     sp.nsplit = (sp.tiles_total + sp.tiles_per_split - 1) / sp.tiles_per_split;
     const dim3 grid((unsigned)(row_blocks * sp.nsplit));
+    // dims 16 / 32: three fp16 products of two-term splits (gq_scores_f16.h) unless GQHIP_SCORES=f32
+    static const bool env_f32 = getenv("GQHIP_SCORES") && getenv("GQHIP_SCORES")[0] == 'f';
+    if (!env_f32 && dim == 16) {
+      hipLaunchKernelGGL((gq_scores_f16x3_kernel<16, RT, 8>), grid, dim3(256), 0, st, sp);
+      return check_launch();
+    }
+    if (!env_f32 && dim == 32) {
+      hipLaunchKernelGGL((gq_scores_f16x3_kernel<32, RT, 4>), grid, dim3(256), 0, st, sp);
+      return check_launch();
+    }
     switch (dim) {
       case 4: hipLaunchKernelGGL((gq_scores_mfma_kernel<4, RT, 8>), grid, dim3(256), 0, st, sp); break;
       case 8: hipLaunchKernelGGL((gq_scores_mfma_kernel<8, RT, 8>), grid, dim3(256), 0, st, sp); break;
