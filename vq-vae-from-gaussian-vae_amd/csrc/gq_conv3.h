@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_f16x3_kernel(const Conv3GnP
 // conversion's ~60 VALU instructions spread between the MFMAs with sched_group_barrier (hipcc keeps them in one block; 8 spills),
 // a wave owning 8 rows x 32 channels (two weight operands per tap instead of four, none loaded twice per block, 16 A reads:
 // bit-identical, no spills, 1045 vs 1031-1052 us), s_setprio 1 / 3 around the tap's MFMAs or around the conversion instead
-// (1068-1080 us).  The texture addresser is busy 26 % of the cycles, L2 read latency averages
+// (1068-1080 us), __builtin_amdgcn_iglp_opt(0) per tap (-1 %, at the noise level).  The texture addresser is busy 26 % of the cycles, L2 read latency averages
 // 317 cycles, 67 % of the L2 requests hit: no unit of the memory pipeline is saturated -- the waves' in-order waits are.
 
 // Measured alternative (round 2, removed): a wave-specialised persistent variant -- one block of 8 waves per CU, waves 0-3
