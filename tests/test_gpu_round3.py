@@ -298,7 +298,8 @@ def test_fp16x3_routes_hold_fp32_grade_accuracy_with_checkpoint_like_weights(whi
 
 
 # ------------------------------------------------------------------------------------------ compat op: every tiling path
-@pytest.mark.parametrize("dim,rows,n", [(16, 600, 65536 + 40), (4, 300, 4096 + 33), (32, 520, 8192), (8, 37, 65536), (16, 257, 96)])
+@pytest.mark.parametrize("dim,rows,n", [(16, 600, 65536 + 40), (4, 300, 4096 + 33), (32, 520, 8192), (8, 37, 65536), (16, 257, 96),
+                                        (16, 1, 32), (32, 1, 33), (32, 129, 65)])
 def test_compat_scores_tile_pairs_chunk_rotation_and_ragged_edges(dim, rows, n):
     """gq_scores_f32's matrix-core kernel beyond the small cases of test_compat_scores_op_matches_cuda_formula: several row
     blocks (the chunk order is rotated by the row block), several chunks per code split with a ragged last one, tile pairs
