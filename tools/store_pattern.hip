@@ -18,6 +18,47 @@ struct P {
   int rows, TR, TC, NT, vec, order, rot, nsplit;
 };
 
+// Store cache policies (round 4): 0 plain, 1 __builtin_nontemporal_store (the `nt` bit), 2 `sc0 sc1` (system-scope write-through),
+// 3 `nt sc0 sc1`.  A write-once 4.29 GB stream through a write-back L2 + the 256 MB Infinity Cache is what these bits exist for.
+template <int POL>
+__device__ __forceinline__ void st4(f32x4 *p, f32x4 v) {
+  if constexpr (POL == 0) *p = v;
+  else if constexpr (POL == 1) __builtin_nontemporal_store(v, p);
+  else if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+
+// "Code-stationary" pattern: block b owns the column segment [b W, (b + 1) W) bytes of EVERY row and walks the rows in order,
+// wave w of the block writing rows rt * 4 TR + w TR .. + TR of its segment in 1 KiB (or W-byte) runs.  All blocks advance through the
+// rows together, so at any time the chip writes a window of a few dozen complete rows -- a linear sweep through memory, like a
+// fill -- instead of 64 rows x 256 B per wave scattered over the whole matrix.
+struct Q {
+  float *out;
+  long row_bytes;
+  int rows, TR, W;
+};
+template <int POL>
+__global__ __launch_bounds__(256) void colstat_kernel(const Q q) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char *seg = reinterpret_cast<char *>(q.out) + (long)blockIdx.x * q.W;
+  const f32x4 vv = {(float)lane, 1.f, 2.f, 3.f};
+  const int lanes_per_row = q.W >= 1024 ? 64 : q.W / 16, per = 64 / lanes_per_row;    // rows per store instruction
+  for (int r0 = wave * q.TR; r0 < q.rows; r0 += 4 * q.TR) {
+    for (int r = 0; r < q.TR; r += per) {
+      char *rowp = seg + (long)(r0 + r + lane / lanes_per_row) * q.row_bytes + (lane % lanes_per_row) * 16;
+      for (int c = 0; c < q.W; c += 1024) st4<POL>(reinterpret_cast<f32x4 *>(rowp + c), vv);
+    }
+  }
+}
+
+// Plain linear fill, many short blocks (what a torch fill_ launches): block b writes bytes [b BB, (b + 1) BB).
+template <int POL>
+__global__ __launch_bounds__(256) void linear_kernel(float *out, int BB) {
+  char *base = reinterpret_cast<char *>(out) + (long)blockIdx.x * BB + threadIdx.x * 16;
+  const f32x4 vv = {1.f, 2.f, 3.f, 4.f};
+  for (int c = 0; c < BB; c += 4096) st4<POL>(reinterpret_cast<f32x4 *>(base + c), vv);
+}
+
 __global__ __launch_bounds__(256) void store_kernel(const P p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int split = blockIdx.x % p.nsplit, rowblk = blockIdx.x / p.nsplit;
@@ -118,5 +159,36 @@ int main(int argc, char **argv) {
     printf("TR %3d  TC %6d  span %6d  vec %d  order %d  rot %d  grid %5u: %.3f ms -> %.0f GB/s\n", c.TR, c.TC, c.span, c.vec, c.order,
            c.rot, grid, ms / 5, rows * row_bytes / (ms / 5) / 1e6);
   }
+  // ---- round 4: linear fills and the code-stationary pattern, every store policy ----
+  auto timeit = [&](auto launch, const char *label) {
+    launch();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 5; ++i) launch();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%s: %.3f ms -> %.0f GB/s\n", label, ms / 5, rows * row_bytes / (ms / 5) / 1e6);
+  };
+  const long total = rows * row_bytes;
+  char label[256];
+  for (int BB : {4096, 16384, 65536, 1 << 20}) {
+    const unsigned grid = (unsigned)(total / BB);
+#define LIN(POL)                                                                                          \
+    snprintf(label, sizeof label, "linear fill, %7d B per block, grid %7u, policy %d", BB, grid, POL);    \
+    timeit([&] { hipLaunchKernelGGL(linear_kernel<POL>, dim3(grid), dim3(256), 0, 0, out, BB); }, label);
+    LIN(0) LIN(1) LIN(2) LIN(3)
+#undef LIN
+  }
+  for (int W : {256, 512, 1024, 2048, 4096})
+    for (int TR : {8, 32}) {
+      Q q{out, row_bytes, rows, TR, W};
+      const unsigned grid = (unsigned)(row_bytes / W);
+#define CS(POL)                                                                                                           \
+      snprintf(label, sizeof label, "code-stationary, segment %5d B, %2d rows per wave step, grid %4u, policy %d", W, TR, grid, POL); \
+      timeit([&] { hipLaunchKernelGGL(colstat_kernel<POL>, dim3(grid), dim3(256), 0, 0, q); }, label);
+      CS(0) CS(1) CS(2) CS(3)
+#undef CS
+    }
   return 0;
 }
