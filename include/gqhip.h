@@ -80,7 +80,7 @@ int gqhip_set_filter(int kind);
 int gqhip_get_filter(void);
 
 /* Diagnostics: launch plan and workspace layout of the fused arg-max for a shape.  out8 = { byte offset of the
- * candidate records, code splits, tiles per candidate group, tiles per split, filter (0 fp32, 1 split-bf16, 2 fp16 + fp8), coefficient of the
+ * candidate records, code splits, tiles per candidate group, tiles per split, filter kernel the plan selects (0 fp32 MFMA, 1 split-bf16, 2 fp16 + fp8, 3 fp16 main product: the default at dims 8 / 16 / 32), coefficient of the
  * filter error bound (E_f = coeff * 2^-24 * T), row tiles per wave, waves per filter block }. */
 int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8);
 

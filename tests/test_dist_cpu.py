@@ -73,20 +73,48 @@ def _worker(rank, world, port, n, bs, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,bs", [(37, 4), (16, 2)])
-def test_two_rank_gloo_gather_and_reinterleave(n, bs):
+def _run_world(world, n, bs):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, bs, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, bs, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out = q.get(timeout=240)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("n,bs", [(43, 2), (61, 3), (5, 1)])
+def test_eight_rank_gloo_gather_and_reinterleave(n, bs):
+    """The rank count of BASELINE configs[2] (eval.py:78-107 on 8 GPUs), N not divisible by 8 bs.  (43, 2): the sampler pads 43 -> 48 by
+    wrapping to the first samples and the wrapped items are INSIDE the kept batches; (61, 3): every rank gets 8 items and the loader's
+    drop_last drops its ragged third batch (the wrapped items with it); (5, 1): fewer images than ranks.  Restored order
+    [j % W][j // W] (eval.py:213-214) must be dataset order with the wrap."""
+    from pit_hip.eval_dist import shard_batches
+
+    world = 8
+    out = _run_world(world, n, bs)
+    steps = -(-n // world) // bs
+    assert steps == len(shard_batches(n, world, 0, bs)) >= 1
+    total = steps * bs * world
+    want_ids = np.arange(total) % n
+    want_tok = (want_ids[:, None] * 7 + np.arange(4)[None]) % 65536
+    assert np.array_equal(out["indices"], want_tok)
+    assert out["psnr"].shape == (total,)
+    if (n, bs) == (43, 2):
+        assert total == 48 and list(want_ids[43:]) == [0, 1, 2, 3, 4]          # the wrap is inside what is kept
+    if (n, bs) == (61, 3):
+        assert total == 48 < 64                                                  # drop_last bit: 2 of every rank's 8 items
+
+
+@pytest.mark.parametrize("n,bs", [(37, 4), (16, 2)])
+def test_two_rank_gloo_gather_and_reinterleave(n, bs):
+    out = _run_world(2, n, bs)
     steps = -(-n // 2) // bs
     total = steps * bs * 2
     want_ids = np.arange(total) % n  # dataset order (the sampler wraps when it pads)

@@ -242,26 +242,7 @@ def test_checksum_tensors_sees_every_word():
 
 
 # ------------------------------------------------------------------------------------------ checkpoint-shaped weights
-def _checkpoint_like_(module, seed):
-    """Re-draw the parameters of an Encoder / Decoder the way trained SD-VAE stacks look: GroupNorm
-    gamma in [0.05, 8] (log-uniform, a few at the ends), beta in +-3, conv weights with a 10^3 dynamic range across output
-    channels (per-channel log-uniform gains on the default init) and a few large biases."""
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for m in module.modules():
-            if isinstance(m, torch.nn.GroupNorm):
-                gam = torch.exp(torch.rand(m.weight.shape, generator=g) * (np.log(8.0) - np.log(0.05)) + np.log(0.05))
-                gam[0], gam[-1] = 8.0, 0.05
-                m.weight.copy_(gam.to(m.weight.device))
-                m.bias.copy_(((torch.rand(m.bias.shape, generator=g) * 2 - 1) * 3.0).to(m.bias.device))
-            elif isinstance(m, torch.nn.Conv2d):
-                gain = torch.exp((torch.rand(m.weight.shape[0], generator=g) * 2 - 1) * np.log(1000.0) / 2)   # 1e-1.5 .. 1e1.5
-                gain = gain / gain.mean()
-                # keep the layer's overall scale near the init's (a trained net is not exploding): normalise the RMS gain
-                gain = gain / float((gain ** 2).mean().sqrt())
-                m.weight.mul_(gain.to(m.weight.device)[:, None, None, None])
-                if m.bias is not None:
-                    m.bias.copy_((torch.randn(m.bias.shape, generator=g) * 0.3).to(m.bias.device))
+from ckpt_like import checkpoint_like_ as _checkpoint_like_  # noqa: E402  (shared with tests/golden/make_golden_r4.py)
 
 
 @pytest.mark.parametrize("which", ["encoder", "decoder"])

@@ -59,6 +59,28 @@ __global__ __launch_bounds__(256) void linear_kernel(float *out, int BB) {
   for (int c = 0; c < BB; c += 4096) st4<POL>(reinterpret_cast<f32x4 *>(base + c), vv);
 }
 
+// Page-placement probe (round 4): every block iteration writes ONE 4 KiB page (256 threads x 16 B).  Which page:
+//   mode 0: page = b + G it                    -- block b keeps the class b % 8 of its pages (blocks are dealt round-robin over the
+//                                                 8 XCDs: the XCD of block b writes pages = b (mod 8) only)
+//   mode 1: as 0 with the class rotated by s:  page = (b & ~7 | (b + s) & 7) + G it
+//   mode 2: page = b iters + it                -- a block writes a contiguous run of pages (every class in turn)
+//   mode 3: as 0, but the class is taken from the hardware XCC id instead of b % 8 (slot = b / 8)
+template <int POL>
+__global__ __launch_bounds__(256) void paged_kernel(float *out, int G, int iters, int mode, int s) {
+  const int b = blockIdx.x;
+  const f32x4 vv = {1.f, 2.f, 3.f, 4.f};
+  int cls = b & 7;
+  if (mode == 3) cls = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;      // HW_REG_XCC_ID, bits [3:0]
+  for (int it = 0; it < iters; ++it) {
+    long page;
+    if (mode == 0) page = (long)b + (long)G * it;
+    else if (mode == 1) page = (long)((b & ~7) | ((b + s) & 7)) + (long)G * it;
+    else if (mode == 2) page = (long)b * iters + it;
+    else page = (long)((b & ~7) | cls) + (long)G * it;
+    st4<POL>(reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(out) + page * 4096 + threadIdx.x * 16), vv);
+  }
+}
+
 __global__ __launch_bounds__(256) void store_kernel(const P p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int split = blockIdx.x % p.nsplit, rowblk = blockIdx.x / p.nsplit;
@@ -179,6 +201,21 @@ int main(int argc, char **argv) {
     timeit([&] { hipLaunchKernelGGL(linear_kernel<POL>, dim3(grid), dim3(256), 0, 0, out, BB); }, label);
     LIN(0) LIN(1) LIN(2) LIN(3)
 #undef LIN
+  }
+  {
+    const long pages = total / 4096;
+    for (int G : {2048, 16384, 131072, (int)pages})
+      for (int mode : {0, 1, 1, 2, 3}) {
+        static int flip = 0;
+        const int sh = mode == 1 ? ((flip++ & 1) ? 4 : 1) : 0;
+        const int iters = (int)(pages / G);
+        snprintf(label, sizeof label, "paged: grid %7d x %4d pages per block, mode %d shift %d, policy 0", G, iters, mode, sh);
+        timeit([&] { hipLaunchKernelGGL(paged_kernel<0>, dim3(G), dim3(256), 0, 0, out, G, iters, mode, sh); }, label);
+        if (mode == 0) {
+          snprintf(label, sizeof label, "paged: grid %7d x %4d pages per block, mode %d shift %d, policy 2", G, iters, mode, sh);
+          timeit([&] { hipLaunchKernelGGL(paged_kernel<2>, dim3(G), dim3(256), 0, 0, out, G, iters, mode, sh); }, label);
+        }
+      }
   }
   for (int W : {256, 512, 1024, 2048, 4096})
     for (int TR : {8, 32}) {

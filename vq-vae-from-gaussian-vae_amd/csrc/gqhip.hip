@@ -272,12 +272,18 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
   const dim3 fblock((unsigned)(64 * pl.waves));
   ProfScope prof;
   if (pl.f16) {
-#define GQ_LAUNCH_F16(NV, R, C)                                                                                      \
-  do {                                                                                                             \
-    if (prof.on)                                                                                                   \
-      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2>), grid, fblock, 0, st, prof.a, prof.b, 0, fp); \
-    else                                                                                                           \
-      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2>), grid, fblock, 0, st, fp);                      \
+    static const int env_pd = getenv("GQHIP_FILTER_PD") ? atoi(getenv("GQHIP_FILTER_PD")) : 2;   // diagnostics: 1 = round 3's pipeline
+#define GQ_LAUNCH_F16P(NV, R, C, PD)                                                                                     \
+  do {                                                                                                                 \
+    if (prof.on)                                                                                                       \
+      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2, PD>), grid, fblock, 0, st, prof.a, prof.b, 0, fp); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2, PD>), grid, fblock, 0, st, fp);                      \
+  } while (0)
+#define GQ_LAUNCH_F16(NV, R, C)                    \
+  do {                                             \
+    if (env_pd == 1) GQ_LAUNCH_F16P(NV, R, C, 1);  \
+    else GQ_LAUNCH_F16P(NV, R, C, 2);              \
   } while (0)
     switch (dim * 10 + pl.rt) {
       case 81: GQ_LAUNCH_F16(1, 1, 16); break;
@@ -289,6 +295,7 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
       default: return GQHIP_ERR_INVALID_ARG;
     }
 #undef GQ_LAUNCH_F16
+#undef GQ_LAUNCH_F16P
     return check_launch();
   }
 #define GQ_LAUNCH_BF1(NV, R, C, G, W)                                                                       \
