@@ -593,10 +593,19 @@ def test_upsample_fallback_route_matches_upsample_then_conv():
         x = torch.randn(2, ch, H, W).to(DEV).contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
             y, b = up(x)
-            ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), up.conv.weight, up.conv.bias, 1, 1)
+            xu = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            ref = F.conv2d(xu, up.conv.weight, up.conv.bias, 1, 1)
+            ref64 = F.conv2d(xu.double(), up.conv.weight.double(), up.conv.bias.double(), 1, 1)
+            mag = F.conv2d(xu.double().abs(), up.conv.weight.double().abs(), None, 1, 1)      # sum |x||w| per output
         assert y.shape == (2, ch, 2 * H, 2 * W) and y.is_contiguous(memory_format=torch.channels_last)
         got = y if b is None else y + b[None, :, None, None]
-        assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4), float((got - ref).abs().max())
+        # error model instead of a measured atol: every route here accumulates in fp32 over K = 9 ch terms -- at most
+        # ~2^-24 sqrt(K)-ish of sum|x||w| in practice, charged generously at 4e-7 (the fp32 library GEMM's own figure is 2.6-3.5e-7,
+        # Winograd F(4x4)'s transforms amplify by a few); the library reference itself is held to the same yardstick
+        e_got = float(((got.double() - ref64).abs() / mag).max())
+        e_ref = float(((ref.double() - ref64).abs() / mag).max())
+        print(f"upsample fallback {ch} ch {H}x{W}: error / sum|x||w|: this route {e_got:.2e}, F.conv2d {e_ref:.2e}")
+        assert e_got <= max(4e-7 * (4 if ch >= 128 else 1), 2.0 * e_ref), (e_got, e_ref)
 
 
 def test_winograd_conv3x3_matches_direct_conv():

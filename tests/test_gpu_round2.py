@@ -506,10 +506,23 @@ def test_gn_act_bound_is_a_bound_and_unet_agrees_with_fp32_gemms():
             U.WINOGRAD_F16X3 = flag
             outs.append((dec(z).float(), enc(img).float()))
     U.WINOGRAD_F16X3 = True
-    d_dec = float((outs[0][0] - outs[1][0]).abs().max()) / max(1.0, float(outs[1][0].abs().max()))
-    d_enc = float((outs[0][1] - outs[1][1]).abs().max())
-    print(f"f16x3 vs fp32 GEMMs: decoder rel diff {d_dec:.2e}, encoder z abs diff {d_enc:.2e}")
-    assert d_dec <= 3e-5 and d_enc <= 3e-5     # measured 1.2-2.0e-5: both routes are ~1e-5 from fp64 at this depth
+    # Error model instead of a measured tolerance: both routes carry ~2.5e-7 of sum|a||b| per GEMM (fp16 x 3: 22-bit
+    # operands, fp32 accumulation; the "fp32" library GEMM on gfx950: a split-bf16 emulation), amplified alike by the ~25 layers
+    # behind them, so each is judged against an fp64 run of the same module on the CPU: the fp16 x 3 route may be at most
+    # twice as far from fp64 as the fp32-GEMM route (floor 1e-5 of the output scale), and the two routes can then differ from
+    # each other by at most the sum of their distances.
+    with torch.no_grad():
+        dec64, enc64 = dec.to("cpu", memory_format=torch.contiguous_format).double(), enc.to("cpu", memory_format=torch.contiguous_format).double()
+        ref_dec = dec64(z.cpu().contiguous().double())
+        ref_enc = enc64(img.cpu().contiguous().double())
+    for name, k, ref in (("decoder", 0, ref_dec), ("encoder", 1, ref_enc)):
+        scale = max(1.0, float(ref.abs().max()))
+        e_f16 = float((outs[0][k].double().cpu() - ref).abs().max()) / scale
+        e_f32 = float((outs[1][k].double().cpu() - ref).abs().max()) / scale
+        d = float((outs[0][k] - outs[1][k]).abs().max()) / scale
+        print(f"{name}: vs fp64: fp16 x 3 route {e_f16:.2e}, fp32-GEMM route {e_f32:.2e}; route-to-route {d:.2e} (of |y| max {scale:.3g})")
+        assert e_f16 <= max(2.0 * e_f32, 1e-5), (name, e_f16, e_f32)
+        assert d <= e_f16 + e_f32 + 1e-7
 
 
 def test_fused_groupnorm_transforms_bit_identical_on_the_f16_routes():

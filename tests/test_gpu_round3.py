@@ -128,10 +128,11 @@ def test_encoder_and_decoder_are_bit_reproducible(size, batches):
                 assert torch.equal(vae.decode(zq0), r0), f"decoder run {i} at B={B}, {size}^2 differs"
 
 
-def test_nchw_encoder_is_bit_reproducible_too():
-    """The NCHW module (no channels_last conversion: ATen / MIOpen convolutions, libgqhip's NCHW GroupNorm): the statistics
-    are order-independent there as well; the conv libraries' picks are outside our control, so this asserts what we own --
-    the tokens of two passes agree exactly when the encoder's z does."""
+def test_nchw_encoder_tokens_follow_z_between_passes():
+    """The NCHW module (no channels_last conversion: ATen / MIOpen convolutions, libgqhip's NCHW GroupNorm) is NOT claimed to be
+    bit-reproducible: MIOpen's pick for conv_out (512 -> 32) is a split-K kernel with floating-point atomics, and conv3x3_f32
+    needs channels_last (README / INTEGRATION: only the channels_last path is bit-reproducible).  What we own is asserted: two passes
+    whose z agree give identical tokens; when z differs by the library's rounding, at most a near-tie token moves."""
     vae = _engine().to(DEV)
     g = torch.Generator().manual_seed(77)
     x = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).to(DEV)

@@ -170,11 +170,7 @@ __device__ __forceinline__ void tile_mfma_f16(const u32x4 (&cv)[NCV], const u32x
 // waits and epilogues behind (measured per block with GQHIP_CLOCK_STAMPS: 104 / 149 us).  One block per CU also
 // halves the L2 -> LDS staging traffic (one chunk copy serves 8 waves).
 // FK: 0 = split-bf16, 1 = fp16 + fp8 (MIXED), 2 = fp16 main product only (F16).
-// PD (round 4): depth of the software pipeline between a tile's MFMAs and its fold.  PD = 1: the fold of tile t - 1 sits between the
-// MFMAs of tile t -- but tile t - 1's last MFMAs were issued just before, behind the partner wave's in the SIMD's matrix pipe, so the
-// in-order wave stalls on them with both pipes idle (PMC, profiles/r04: matrix pipes 41 % busy at dim 8, 77 % at dim 16, VALU a third).
-// PD = 2: the fold of tile t - 2, whose accumulators are a whole step old: no VALU instruction of the loop waits for an MFMA any more.
-template <int NV, int RT, int CT, int GT, int WAVES, int FK = 0, int PD = 1>
+template <int NV, int RT, int CT, int GT, int WAVES, int FK = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16_kernel(const FilterBfParams p) {
   constexpr bool MIXED = FK == 1, F16 = FK == 2;
   static_assert(!MIXED || NV == 2, "fp16 + fp8 filter: dim 16");
@@ -303,12 +299,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
   //   * step CT-1 then prefetches tile 0 of the next chunk under its own MFMAs, so no step ever starts with an LDS read.
   constexpr int W0 = CT / 2 - 1, WSTEPS = CT - 1 - W0;
   static_assert(CT >= 4 && WSTEPS >= 1, "chunk too short for the staggered staging");
-  f32x16 dprev[RT], dprev2[RT];
+  f32x16 dprev[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dprev[rt][r] = dprev2[rt][r] = NEG_INF;
-  int tprev = t_begin - 1, tprev2 = t_begin - 2;
+    for (int r = 0; r < 16; ++r) dprev[rt][r] = NEG_INF;
+  int tprev = t_begin - 1;
   bool have_prev = false;
   u32x4 cv[NCV];
   if (nchunks > 0) read_ops(lds[0] + h * 32 + c, cv);
@@ -340,33 +336,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         // every tile began with its own operand reads and lgkmcnt waits, the prefetch existed only in the source)
         __builtin_amdgcn_sched_barrier(0);
         f32x16 d[RT];
-        if constexpr (PD == 2) {
-          // tile TT - 2 of this chunk (or the last tiles of the previous one): t_begin and the chunk starts are multiples of GT
-          constexpr bool P2_CLOSES = ((TT + 2 * GT - 2) % GT) == GT - 1;
-          tile_mfma(IC0{}, ICS0{}, cv, d);
-          fold(dprev2, tprev2, P2_CLOSES);
-          tile_mfma(ICS0{}, ICNM{}, cv, d);
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) { dprev2[rt] = dprev[rt]; dprev[rt] = d[rt]; }
-          tprev2 = tprev;
-          tprev = tile0 + TT;
-#pragma unroll
-          for (int v = 0; v < NCV; ++v) cv[v] = cvn[v];
-          // every MFMA of this tile followed by an equal slice of the fold of tile TT - 2: nothing in it depends on an MFMA in flight
-          constexpr int BUDGET2 = (P2_CLOSES ? (TOP4 ? 20 : 16) : 8) * RT, NMF = NM * RT;
-          constexpr int PER2 = BUDGET2 / NMF, EXTRA2 = BUDGET2 % NMF;
-#pragma unroll
-          for (int k = 0; k < EXTRA2; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, PER2 + 1, 0);
-          }
-#pragma unroll
-          for (int k = EXTRA2; k < NMF; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if constexpr (PER2 > 0) __builtin_amdgcn_sched_group_barrier(0x002, PER2, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
         tile_mfma(IC0{}, ICS0{}, cv, d);
         fold(dprev, tprev, PREV_CLOSES);
         tile_mfma(ICS0{}, ICNM{}, cv, d);
@@ -399,7 +368,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        }
 #if !(defined(GQHIP_ABL) && (GQHIP_ABL & 1))    // diagnostic build: no chunk barriers
         if constexpr (TT == CT - 2) __syncthreads();
 #endif
@@ -410,7 +378,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
       have_prev = true;
     } else {
       // the one partial chunk (always the last): staged by the previous chunk (or the prologue), plain loop
-      if (have_prev && PD == 2) fold(dprev2, tprev2, (tprev2 % GT) == GT - 1);
       if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);
       have_prev = false;
       for (int tt = 0; tt < nt; ++tt) {
@@ -422,7 +389,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
       }
     }
   }
-  if (have_prev && PD == 2) fold(dprev2, tprev2, (tprev2 % GT) == GT - 1);
   if (have_prev) fold(dprev, tprev, (tprev % GT) == GT - 1);
 #ifdef GQHIP_CLOCK_STAMPS
   const unsigned long long st_r2 = __builtin_amdgcn_s_memrealtime();

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     p.hdr->fb2_count = 0;
     p.hdr->reranked = 0ull;
     p.hdr->bar_count = 0u;
+    p.hdr->bar_gen = 0u;          // (an aborted barrier leaves kBarAbort here: nothing of it outlives the call)
     p.hdr->bar_timeout = 0;
     p.hdr->bar_abort = 0;
   }

@@ -911,44 +911,62 @@ __device__ __forceinline__ void second_stage(const RerankParams &p) {
 // Grid barrier of the tail kernel.  The host sizes the grid so that every block is co-resident (occupancy API x CU
 // count), but nothing in HIP guarantees that: a CU mask, another stream holding CUs or a profiler can leave blocks
 // queued behind spinning ones.  So the barrier is allowed to FAIL: it returns false when this block's spin ran out or
-// any block has reported that (hdr->bar_abort).  From then on nobody waits at a barrier, and every block finishes
+// any block has reported that (hdr->bar_gen == kBarAbort).  From then on nobody waits at a barrier, and every block finishes
 // list A through exhaustive_rows() below, which depends on no other block (gq_tail.h) -- a failed barrier costs time,
 // never a wrong index.  A block only consumes other blocks' data behind a barrier that returned true, i.e. after
 // all `nblocks` arrivals, each made after the arriving block's own phase was complete and released.
 // Producer side: every wave drains its stores, the block meets, lane 0 releases at agent scope and arrives;
 // consumer side: relaxed agent-scope poll, ONE acquire, block barrier (MI355X_MICROARCH.md, inter-workgroup
 // visibility: per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores).
+// The OUTCOME of a barrier is one atomic decision (round 4): the last arriver compare-and-swaps `bar_gen` from this
+// barrier's generation to the next one, a block whose wait ran out compare-and-swaps it to kBarAbort; whichever lands first stands
+// (an aborted `bar_gen` never changes again within the call), and EVERY block derives its return value from that one final word --
+// never from its own view of the race.  So either all blocks pass a barrier or all of them leave it for the barrier-free finish.
+constexpr unsigned kBarAbort = 0xffffffffu;
+__device__ __forceinline__ bool barrier_aborted(WsHeader *hdr) {
+  return __hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kBarAbort;
+}
 __device__ __forceinline__ bool grid_barrier(WsHeader *hdr, unsigned nblocks, int spin_limit) {
   __shared__ int sh_ok;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned gen = __hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned arrived = __hip_atomic_fetch_add(&hdr->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived == nblocks - 1) {
-      __hip_atomic_store(&hdr->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = false;
+    if (gen != kBarAbort) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(&hdr->bar_gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      // bounded (MI355X_MICROARCH.md: "bound every spin"): the default limit is ~0.5 s, orders of magnitude beyond
-      // any real wait of a co-resident grid
-      int spins = 0;
-      while (__hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen &&
-             __hip_atomic_load(&hdr->bar_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > spin_limit) {
-          __hip_atomic_store(&hdr->bar_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_add(&hdr->bar_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
+      const unsigned arrived = __hip_atomic_fetch_add(&hdr->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (arrived == nblocks - 1) {
+        __hip_atomic_store(&hdr->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned expect = gen;
+        const unsigned next = gen + 1u == kBarAbort ? 0u : gen + 1u;
+        (void)__hip_atomic_compare_exchange_strong(&hdr->bar_gen, &expect, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);      // fails only against an abort: that stands
+      } else {
+        // bounded (MI355X_MICROARCH.md: "bound every spin"): the default limit is ~0.5 s, orders of magnitude beyond
+        // any real wait of a co-resident grid
+        int spins = 0;
+        while (__hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > spin_limit) {
+            unsigned expect = gen;
+            if (__hip_atomic_compare_exchange_strong(&hdr->bar_gen, &expect, kBarAbort, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+              __hip_atomic_store(&hdr->bar_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (diagnostics mirror)
+            __hip_atomic_fetch_add(&hdr->bar_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the one final word: the next generation (every block had arrived first) or the abort (a wait had run out first)
+      ok = __hip_atomic_load(&hdr->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kBarAbort;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    sh_ok = __hip_atomic_load(&hdr->bar_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    sh_ok = ok;
   }
   __syncthreads();
   return sh_ok != 0;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 1) void gq_tail_kernel(const RerankParams p, c
   const int count_a = p.hdr->fb_count;       // final: written by the previous launch
   if (count_a == 0) return;
   if (p.cascade && count_a > kCascadeMin) {
-    bool ok = __hip_atomic_load(&p.hdr->bar_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    bool ok = !barrier_aborted(p.hdr);   // a block that starts after an abort goes straight to the barrier-free finish
     if (ok) {
       const int nvb_f = ((count_a + 127) / 128) * f2.nsplit;
       for (int vb = blockIdx.x; vb < nvb_f; vb += gridDim.x) {

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__res
 // V3 U3 = h U_h + h U_l + l U_h, error ~3 * 2^-22 per product -- the level of hipBLASLt's own fp32 (split-bf16) GEMM, at
 // 2-2.5x its speed (tools/bmm_bf16x3.py).  `scale` is a power of two chosen by the caller so that |v * scale| < 65504.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-// F16X3 = 2 ("f16x2"): V2 [k][tile][2C] = [ h | l ] only -- the operand of wino_gemm_c128_f16x2_kernel, which forms the
+// F16X3 = 2 ("f16x2"): V2 [k][tile][2C] = [ h | l ] only -- the operand of wino_gemm_f16x2_kernel / wino_gemm_f16x2_w8_kernel (gq_wino_gemm.h), which form the
 // three products itself (4 instead of 6 bytes per element).
 template <int F16X3, typename VEC>
 __device__ __forceinline__ void wino_store_v(void *V, int k, long tiles, long tile, int CV, int q, VEC v, float scale) {

@@ -272,18 +272,12 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
   const dim3 fblock((unsigned)(64 * pl.waves));
   ProfScope prof;
   if (pl.f16) {
-    static const int env_pd = getenv("GQHIP_FILTER_PD") ? atoi(getenv("GQHIP_FILTER_PD")) : 2;   // diagnostics: 1 = round 3's pipeline
-#define GQ_LAUNCH_F16P(NV, R, C, PD)                                                                                     \
-  do {                                                                                                                 \
-    if (prof.on)                                                                                                       \
-      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2, PD>), grid, fblock, 0, st, prof.a, prof.b, 0, fp); \
-    else                                                                                                               \
-      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2, PD>), grid, fblock, 0, st, fp);                      \
-  } while (0)
-#define GQ_LAUNCH_F16(NV, R, C)                    \
-  do {                                             \
-    if (env_pd == 1) GQ_LAUNCH_F16P(NV, R, C, 1);  \
-    else GQ_LAUNCH_F16P(NV, R, C, 2);              \
+#define GQ_LAUNCH_F16(NV, R, C)                                                                                      \
+  do {                                                                                                             \
+    if (prof.on)                                                                                                   \
+      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2>), grid, fblock, 0, st, prof.a, prof.b, 0, fp); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2>), grid, fblock, 0, st, fp);                      \
   } while (0)
     switch (dim * 10 + pl.rt) {
       case 81: GQ_LAUNCH_F16(1, 1, 16); break;
@@ -295,7 +289,6 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
       default: return GQHIP_ERR_INVALID_ARG;
     }
 #undef GQ_LAUNCH_F16
-#undef GQ_LAUNCH_F16P
     return check_launch();
   }
 #define GQ_LAUNCH_BF1(NV, R, C, G, W)                                                                       \
@@ -891,7 +884,7 @@ int gqhip_debug_barrier(const void *workspace, int64_t *timeouts_host, int64_t *
   WsHeader h;
   if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
   if (timeouts_host) *timeouts_host = h.bar_timeout;
-  if (aborted_host) *aborted_host = h.bar_abort;
+  if (aborted_host) *aborted_host = (h.bar_gen == kBarAbort || h.bar_abort) ? 1 : 0;
   return GQHIP_OK;
 }
 

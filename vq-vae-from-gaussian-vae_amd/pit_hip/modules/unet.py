@@ -354,7 +354,10 @@ class _WeightGuard:
         from .. import _lib
 
         params = [p for p in module.parameters()]
-        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        # the checksum kernel reads numel() words from data_ptr(): only DENSE parameters (contiguous, or a dense channels_last
+        # layout) -- an expanded or strided view would be read past its own storage, so such a module runs unguarded
+        dense = lambda p: p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 and dense(p) for p in params):
             return False
         key = tuple(p.data_ptr() for p in params)
         if key != self.key:
@@ -367,24 +370,33 @@ class _WeightGuard:
             self.event = torch.cuda.Event()
             self.baseline = None
             self.key = key
+        self.versions = tuple(p._version for p in params)
         _lib.checksum_tensors(self.table, self.sums)
         self.host.copy_(self.sums, non_blocking=True)
         self.event.record()
         return True
 
     def changed(self) -> bool:
+        """True when some parameter's bytes changed WITHOUT its version counter moving (the only case the caches cannot see by
+        themselves: an update that bumps ``_version`` -- load_state_dict, an optimizer step -- already changed the cache keys, so the
+        speculative run rebuilt what it needed and is not repeated)."""
         self.event.synchronize()
         cur = self.host.clone()
-        if self.baseline is not None and torch.equal(cur, self.baseline):
+        base, base_v = self.baseline, getattr(self, "baseline_versions", None)
+        self.baseline, self.baseline_versions = cur, self.versions
+        if base is None or torch.equal(cur, base):
             return False
-        first = self.baseline is None
-        self.baseline = cur
-        return not first
+        moved = (cur != base).tolist()
+        return any(m and v == bv for m, v, bv in zip(moved, self.versions, base_v))
 
 
 def _guarded(module: nn.Module, run, x: torch.Tensor):
-    """run(x) with the module's weight caches verified against the parameters' bytes (see _WeightGuard)."""
-    if not (WEIGHT_GUARD and x.is_cuda and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
+    """run(x) with the module's weight caches verified against the parameters' bytes (see _WeightGuard).  Costs one host wait per
+    forward (for a copy queued at the forward's start: the host stays at most one module ahead of the device).  A caller that
+    never writes parameters through ``.data`` and wants a fully asynchronous forward opts out per module:
+    ``encoder.weight_guard = False`` (or process-wide: GQHIP_WEIGHT_GUARD=0)."""
+    if not (WEIGHT_GUARD and getattr(module, "weight_guard", True) and x.is_cuda and not torch.is_grad_enabled()
+            and not torch.cuda.is_current_stream_capturing()):
         return run(x)
     guard = module.__dict__.get("_gq_guard")
     if guard is None:
