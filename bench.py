@@ -516,7 +516,7 @@ def main():
     def step():
         zhat, info = vae.encode(x, return_reg_log=True)
         rec = vae.decode(zhat)
-        record = layout.pack(info["indices"], psnr_zero_mean(x, rec)[:, None])
+        record = layout.pack_with_psnr(info["indices"], x, rec)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = gather_step(record, world)
@@ -535,7 +535,7 @@ def main():
     def init_pass():
         with torch.no_grad():
             zhat, info = vae.encode(x, return_reg_log=True)
-            layout.pack(info["indices"], psnr_zero_mean(x, vae.decode(zhat))[:, None])
+            layout.pack_with_psnr(info["indices"], x, vae.decode(zhat))
         torch.cuda.synchronize()
 
     if world > 1:
@@ -583,7 +583,7 @@ def main():
                 e[2].record()
                 rec = vae.decode(zhat)
                 e[3].record()
-                layout.pack(info["indices"], psnr_zero_mean(x, rec)[:, None])
+                layout.pack_with_psnr(info["indices"], x, rec)
                 e[4].record()
         torch.cuda.synchronize()
         med = lambda i: sorted(e[i].elapsed_time(e[i + 1]) for e in ev)[reps // 2]

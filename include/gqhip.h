@@ -38,10 +38,12 @@
 extern "C" {
 #endif
 
-#define GQHIP_ABI_VERSION 5   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
+#define GQHIP_ABI_VERSION 6   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
                                * 4: four-launch fused arg-max (no caller-cached max|cb|; noise / zhat_noquant in gq_quantize_z_f32), profile_reserve;
                                * 5: GroupNorm statistics as order-independent fixed-point records (gqhip_gnstat_t), conv3x3_f32 (fp32 matrix
-                               *    cores: conv_in / conv_out of the encoder and decoder), gqhip_debug_barrier / gqhip_debug_tail */
+                               *    cores: conv_in / conv_out of the encoder and decoder), gqhip_debug_barrier / gqhip_debug_tail;
+                               * 6: three-launch fused arg-max -- undecided rows are finished inside the re-rank, the tail kernel with its grid
+                               *    barriers is gone and gqhip_debug_barrier / gqhip_debug_tail with it; psnr_zero_mean_f32, gq_pack_step_record */
 
 /* GroupNorm statistics of one (image, group): GQHIP_GNSTAT_WORDS int64 words = {sum: 3 limbs, sum of squares: 3 limbs, poison,
  * unused}; value = q0 2^-56 + q1 2^-16 + q2 2^24.  Every kernel that leaves statistics behind adds its threads' fp32 partial
@@ -66,8 +68,8 @@ int gqhip_last_hip_error(void);
 
 /* Filter kernel of the fused arg-max (gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32).  AUTO: the fp16 main-product
  * filter (ONE fp16 MFMA product per fp32 product, no correction terms; its rounding error is covered by a bound the re-rank
- * derives from the row's own data) at every MFMA dim (4/8/16/32), Gaussian score and VQ; rows a filter cannot decide cascade
- * through the fp32 MFMA filter, then an fp64 stage.  FP32: always the fp32 MFMA filter.  BF16: the split-bf16 filter (three
+ * derives from the row's own data) at every MFMA dim (4/8/16/32), Gaussian score and VQ; rows whose candidate records are incomplete
+ * are finished inside the re-rank kernel by a complete scan of the record sets in question (csrc/gq_rerank.h).  FP32: always the fp32 MFMA filter.  BF16: the split-bf16 filter (three
  * bf16 products per fp32 product).  MIXED: round 2's fp16 + fp8 filter (one fp16 product + block-scaled fp8 corrections) at
  * dim 16 with the Gaussian score, split-bf16 elsewhere.  All feed the same exact re-rank: the indices are identical.
  * Process-wide; initial value from the environment (GQHIP_FILTER=fp32|bf16|mixed).  The workspace size depends on it:
@@ -365,6 +367,19 @@ int gq_indices_to_u16(const int64_t *idx, uint16_t *out, int64_t count,
 int gq_indices_from_u16(const uint16_t *in, int64_t *idx, int64_t count,
                         void *stream);
 
+/* One rank's per-step record in ONE launch -- what eval.py:165-169 (per-image PSNR: pit/evaluations/psnr.py:17-28 with
+ * zero_mean = True, images in [-1, 1]) and eval.py:152-154 (the batch's code indices) publish per batch, in the packed wire
+ * format of pit_hip/eval_dist.py:StepRecord with one metric:
+ *     rec [B + (n_idx + 1) / 2] int32 = [ B PSNRs as fp32 bits | indices as uint16 pairs, low half first (odd count: zero pad) ].
+ * x, x_rec: B images of `per_image` floats each in the SAME dense layout (NCHW or channels_last: the metric is elementwise);
+ * idx: n_idx values in [0, 65536) (not checked; a wider value is truncated to its low 16 bits).  The squared differences are
+ * formed in the reference's fp32 op order and summed in fp64 in a fixed order (bit-reproducible; within 2e-6 of torch's fp32
+ * mean).  workspace: gq_step_record_workspace_bytes(B, per_image) bytes, ZERO when first used; every call leaves it zero
+ * again, so one allocation serves a stream of calls (one stream at a time).  Asynchronous on `stream`, no allocation. */
+int64_t gq_step_record_workspace_bytes(int64_t B, int64_t per_image);
+int gq_step_record_f32(const float *x, const float *x_rec, const int64_t *idx, int32_t *rec, int64_t B, int64_t per_image,
+                       int64_t n_idx, void *workspace_zeroed, int64_t workspace_bytes, void *stream);
+
 /* ---- profiling recorder ------------------------------------------------------
  * When enabled, every launch of the MFMA filter kernel is bracketed with
  * hipEvents on its own stream.  gqhip_profile_collect synchronises those
@@ -384,15 +399,6 @@ int gqhip_profile_collect(int *launches_host, double *total_ms_host);
 int gqhip_debug_enable(int on);
 int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
                          int64_t *reranked_halftiles_host);
-/* The tail kernel's grid barriers (cascade path of an ill-conditioned call) are allowed to fail: a block whose
- * wait runs out, or that learns of another block's, finishes the undecided rows through the barrier-free exhaustive
- * path, so a failed barrier costs time and never an index (the reference's plain launch, gq_cuda.cu:114-116, cannot
- * mis-answer either).  gqhip_debug_barrier: blocks that timed out / whether the call aborted its barriers, for the
- * last call on `workspace` (synchronous copy).  gqhip_debug_tail: TEST HOOK -- multiply the tail grid beyond what is
- * co-resident (1 = normal) and set the barrier wait in polls of ~0.25 us (default 2^21), to force that path. */
-int gqhip_debug_barrier(const void *workspace, int64_t *timeouts_host, int64_t *aborted_host);
-int gqhip_debug_tail(int grid_mult, int spin_limit);
-
 #ifdef __cplusplus
 }
 #endif

@@ -55,8 +55,6 @@ int main() {
   bad += conv3x3_f32(nullptr, nullptr, nullptr, nullptr, nullptr, 32, 1e-6, 1, nullptr, nullptr, nullptr, 1, 32, 32, 512, 3, nullptr) == GQHIP_OK;
   bad += gqhip_checksum_tensors(nullptr, 4, nullptr, nullptr) == GQHIP_OK;
   bad += gqhip_checksum_tensors(nullptr, -1, nullptr, nullptr) == GQHIP_OK;
-  bad += gqhip_debug_tail(0, 10) == GQHIP_OK;
-  bad += gqhip_debug_tail(1, 1 << 21) != GQHIP_OK;
   if (bad) { std::printf("FAIL %d argument checks\n", bad); return 1; }
   std::printf("ok: %ld launch plans, argument validation of the entry points, under ASan + UBSan (host side)\n", plans);
   return 0;

@@ -81,3 +81,51 @@ def test_g15_trained_operating_point_end_to_end_vs_reference_golden(channels_las
     if same.any():
         err = float((rec.cpu()[same] - ref[same]).abs().max())
         assert err <= GATES["recon_max_abs_if_indices_equal"] * max(1.0, scale), (err, scale)
+
+
+# ------------------------------------------------------------------------------------------ the per-step record in one launch
+@pytest.mark.parametrize("B,C,H,W,K,cl", [(16, 3, 256, 256, 1, True), (3, 3, 64, 48, 2, True), (2, 3, 17, 5, 1, False), (1, 1, 3, 3, 3, False)])
+def test_step_record_one_launch_matches_the_torch_expressions(B, C, H, W, K, cl):
+    """StepRecord.pack_with_psnr on the device (gq_step_record_f32: PSNR reduction + uint16 packing in ONE launch) against
+    pack(indices, psnr_zero_mean(x, x_rec)) -- eval.py:165-169 / pit/evaluations/psnr.py:17-28 and the wire format of
+    eval_dist.StepRecord: packed index words identical, PSNR within 2e-6 (fp64 sum of the reference's fp32 terms vs torch's fp32
+    mean), odd index counts, per_image not a multiple of 4, channels_last and NCHW, a non-contiguous index view, repeated calls on
+    one workspace, identical images -> +inf."""
+    from pit_hip.eval_dist import StepRecord, psnr_zero_mean
+
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = (torch.rand(B, C, H, W, generator=g) * 2 - 1).to(DEV)
+    xr = (x + 0.05 * torch.randn(B, C, H, W, generator=g).to(DEV)).clamp(-1, 1)
+    if cl:
+        x, xr = x.contiguous(memory_format=torch.channels_last), xr.contiguous(memory_format=torch.channels_last)
+    h, w = max(H // 8, 1), max(W // 8, 1)
+    idx = torch.randint(0, 65536, (B, h, w, K), generator=g).to(DEV).permute(0, 3, 1, 2)      # [B, K, h, w] view of NHWC memory
+    idx[0, 0, 0, 0], idx[-1, -1, -1, -1] = 65535, 0
+    lay = StepRecord(B, K * h * w, n_metrics=1)
+    want = lay.pack(idx, psnr_zero_mean(x, xr)[:, None])
+    for _ in range(3):                                       # the workspace resets itself
+        got = lay.pack_with_psnr(idx, x, xr)
+    torch.cuda.synchronize()
+    assert torch.equal(got[B:], want[B:])
+    gi, gm = lay.unpack(got)
+    wi, wm = lay.unpack(want)
+    assert torch.equal(gi, wi) and torch.equal(gi.reshape(-1), idx.reshape(-1))
+    np.testing.assert_allclose(gm.cpu().numpy(), wm.cpu().numpy(), rtol=2e-6)
+    same = lay.pack_with_psnr(idx, x, x.clone(memory_format=torch.preserve_format))
+    assert torch.isinf(lay.unpack(same)[1]).all()
+    # mixed layouts fall back to the torch expressions (same answer)
+    if cl:
+        fb = lay.pack_with_psnr(idx, x, xr.contiguous())
+        np.testing.assert_allclose(lay.unpack(fb)[1].cpu().numpy(), wm.cpu().numpy(), rtol=2e-6)
+
+
+def test_step_record_psnr_matches_reference_golden():
+    """golden g12 (pit/evaluations/psnr.py captured from the reference) through the one-launch record."""
+    from pit_hip.eval_dist import StepRecord
+
+    d = np.load(os.path.join(G, "g12_psnr.npz"))
+    x, xr = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["x_rec"]).to(DEV)
+    B = x.shape[0]
+    lay = StepRecord(B, 4, n_metrics=1)
+    rec = lay.pack_with_psnr(torch.zeros(B, 1, 2, 2, dtype=torch.int64, device=DEV), x, xr)
+    np.testing.assert_allclose(lay.unpack(rec)[1].reshape(-1).cpu().numpy(), d["psnr_zero_mean"], rtol=2e-6)

@@ -20,8 +20,9 @@ pl = _lib.debug_plan(rows, n, dim)
 rpb = 32 * pl['waves'] * pl['rt']
 nblk = ((rows + rpb - 1) // rpb) * pl['nsplit']
 print('plan:', pl, 'blocks:', nblk)
-# workspace layout: hdr(512) | rec (nsplit*rows*32) | fb (rows*4) | mu ...
-off = 512 + pl['nsplit'] * rows * 32 + ((rows * 4 + 255) // 256) * 256 + 33792   # hdr | rec | fb | spread slots
+# workspace layout (csrc/gqhip.hip:ws_layout): hdr (4096) | rec (record sets * rows * 32) | fb (rows * 4) | dbg (64 KiB: the stamps) | ...
+a256 = lambda v: (v + 255) // 256 * 256
+off = 4096 + a256(pl['nsplit'] * rows * 32) + a256(rows * 4)
 raw = ws.buf[off:off + nblk * 32].cpu().numpy().view(np.uint64).reshape(nblk, 4)
 t0 = raw[:, 0].min()
 start = (raw[:, 0] - t0) / 100.0   # us

@@ -237,4 +237,74 @@ __global__ __launch_bounds__(256) void from_u16_kernel(const uint16_t *__restric
   if (i < count) idx[i] = (int64_t)in[i];
 }
 
+
+// ---- one rank's per-step record in ONE launch (round 4): per-image PSNR + the uint16 index wire format -----------------------
+// rec (int32 words) = [ B per-image PSNRs as fp32 bits | indices as uint16 pairs, low half first ] -- pit_hip/eval_dist.py:StepRecord
+// with n_metrics = 1, i.e. what eval.py:165-169 (get_psnr(zero_mean=True), pit/evaluations/psnr.py:17-28) and the index gather
+// of eval.py:152-154 publish per batch.  Blocks [0, B * chunks): one contiguous chunk of one image, the squared differences in
+// the reference's fp32 op order ((x + 1) 127.5 - (x_rec + 1) 127.5, squared), summed in fp64; the LAST block of an image (a ticket
+// per image, reset for the next call) adds the chunk sums in chunk order -- a fixed order: the value is bit-reproducible -- and
+// writes 20 log10(255 / sqrt(mse)).  The blocks after those pack the indices.
+struct StepRecordParams {
+  const float *x, *x_rec;     // [B, per_image] in the SAME dense layout
+  const int64_t *idx;         // [n_idx]
+  int *rec;                   // [B + (n_idx + 1) / 2]
+  double *partial;            // [B, chunks]      (workspace)
+  int *ticket;                // [B], all zero between calls (workspace)
+  long per_image, n_idx;
+  int B, chunks, psnr_blocks;
+};
+constexpr int kPsnrChunk = 256 * 4 * 8;      // floats per block: eight 16-byte loads per thread
+
+__global__ __launch_bounds__(256) void step_record_kernel(const StepRecordParams p) {
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= p.psnr_blocks) {
+    const long w = (long)(blockIdx.x - p.psnr_blocks) * 256 + tid;        // one packed word per thread
+    if (2 * w < p.n_idx) {
+      const unsigned lo = (unsigned)p.idx[2 * w] & 0xffffu;
+      const unsigned hi = 2 * w + 1 < p.n_idx ? (unsigned)p.idx[2 * w + 1] & 0xffffu : 0u;
+      p.rec[p.B + w] = (int)(lo | (hi << 16));
+    }
+    return;
+  }
+  const int b = blockIdx.x / p.chunks, ch = blockIdx.x % p.chunks;
+  const long e0 = (long)ch * kPsnrChunk, e1 = e0 + kPsnrChunk < p.per_image ? e0 + kPsnrChunk : p.per_image;
+  const float *xa = p.x + (long)b * p.per_image, *xb = p.x_rec + (long)b * p.per_image;
+  double acc = 0.0;
+  auto term = [&](float u, float v) {
+#pragma clang fp contract(off)
+    const float a = (u + 1.0f) * 127.5f, c = (v + 1.0f) * 127.5f;
+    const float d = a - c;
+    acc += (double)(d * d);
+  };
+  if ((p.per_image & 3) == 0) {
+    for (long e = e0 + 4 * tid; e < e1; e += 1024) {
+      const f32x4 u = *reinterpret_cast<const f32x4 *>(xa + e), v = *reinterpret_cast<const f32x4 *>(xb + e);
+      term(u.x, v.x); term(u.y, v.y); term(u.z, v.z); term(u.w, v.w);
+    }
+  } else {
+    for (long e = e0 + tid; e < e1; e += 256) term(xa[e], xb[e]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ double sh[4];
+  __shared__ int sh_last;
+  if ((tid & 63) == 0) sh[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    p.partial[(long)b * p.chunks + ch] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __threadfence();
+    sh_last = atomicAdd(&p.ticket[b], 1) == p.chunks - 1;
+  }
+  __syncthreads();
+  if (!sh_last || tid != 0) return;
+  __threadfence();
+  double sum = 0.0;
+  for (int k = 0; k < p.chunks; ++k) sum += __hip_atomic_load(&p.partial[(long)b * p.chunks + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float mse = (float)(sum / (double)p.per_image);
+  const float psnr = (float)(20.0 * log10(255.0 / sqrt((double)mse)));      // identical images: +inf, like the reference
+  p.rec[b] = __float_as_int(psnr);
+  p.ticket[b] = 0;                             // ready for the next call on this workspace
+}
+
 }  // namespace gqhip

@@ -29,20 +29,14 @@ struct __attribute__((aligned(32))) Rec {
 };
 
 // Workspace header (first 4 KiB of the caller's workspace).  Everything in it is (re)written by the kernels of ONE
-// call: gq_prep_kernel resets the counters and writes the max|cb| partials, the level-1 re-rank reduces them to
-// `absmax` for the tail kernel.  Nothing here is read across calls.
+// call: gq_prep_kernel resets the counters and writes the max|cb| partials, the re-rank reduces them per wave.
+// Nothing here is read across calls.
 constexpr int kAbsmaxParts = 256;
 struct WsHeader {
-  int fb_count;                       // rows the first filter + re-rank could not decide (list A)
-  int fb2_count;                      // rows still undecided after the fp32 second-level filter (list B)
+  int fb_count;                       // rows the candidates could not decide (finished by the in-block scan; exhaustive kernel: its list)
+  int pad0;
   unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly
-  float absmax;                       // max |cb|, reduced from absmax_part by the level-1 re-rank
-  unsigned bar_count, bar_gen;        // grid barrier of the tail kernel (cascade path only)
-  int bar_timeout;                    // blocks whose barrier spin ran out (gqhip_debug_counters reports it)
-  int bar_abort;                      // set by the first such block: nobody waits at a barrier any more, every block
-                                      // finishes list A through the barrier-free exhaustive path (gq_tail.h)
-  float r2;                           // max_j |cb_j|^2 (fp32, as summed by gq_prep_kernel), reduced from r2_part likewise
-  int pad1[22];
+  int pad1[28];
   float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
   int pad2[128];

@@ -44,11 +44,6 @@ struct FilterParams {
   int nsplit, tiles_total, tiles_per_split;
   WsHeader *hdr;
   void *dbg;            // diagnostic builds only
-  // second-level use (behind the split-bf16 filter): only the rows listed in row_list[0 .. *row_count) are
-  // processed, and only if there are more than min_count of them; records are still indexed by row id
-  const int *row_list;
-  const int *row_count;
-  int min_count;
 };
 
 // LDS image of a chunk: code rows of DIM floats = DIM/4 slots of 16 bytes.  Row-major rows of
@@ -164,11 +159,7 @@ __device__ __forceinline__ void filter_block(const FilterParams &p, const int vb
 #ifdef GQHIP_CLOCK_STAMPS
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  int nrows = p.rows;
-  if (p.row_list) {
-    nrows = *p.row_count;
-    if (nrows <= p.min_count || rowblk * (128 * RT) >= nrows) return;   // block-uniform
-  }
+  const int nrows = p.rows;
 
   // ---- row coefficients (B operands), fixed for the whole kernel ----------
   float coefA[RT][HD], coefB[RT][HD];
@@ -176,7 +167,6 @@ __device__ __forceinline__ void filter_block(const FilterParams &p, const int vb
   for (int rt = 0; rt < RT; ++rt) {
     int row = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
     row = min(row, nrows - 1);
-    if (p.row_list) row = p.row_list[row];
     const float *pm = p.mu + (long)row * DIM + h * HD;
 #pragma unroll
     for (int s = 0; s < HD; ++s) {
@@ -377,7 +367,7 @@ __device__ __forceinline__ void filter_block(const FilterParams &p, const int vb
     top4_insert_value(b4, a3, a4);
     const int pos = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
     if (h == 0 && pos < nrows) {
-      const int row = p.row_list ? p.row_list[pos] : pos;
+      const int row = pos;
       Rec r;
       r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.m4 = a4; r.id1 = j1; r.id2 = j2; r.id3 = j3;
       r.pad = 0;

@@ -89,12 +89,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
 
   if (blockIdx.x == 0 && tid == 0) {           // header for the kernels that follow on the stream
     p.hdr->fb_count = 0;
-    p.hdr->fb2_count = 0;
     p.hdr->reranked = 0ull;
-    p.hdr->bar_count = 0u;
-    p.hdr->bar_gen = 0u;          // (an aborted barrier leaves kBarAbort here: nothing of it outlives the call)
-    p.hdr->bar_timeout = 0;
-    p.hdr->bar_abort = 0;
   }
 
   if ((int)blockIdx.x >= p.row_blocks) {
@@ -241,7 +236,8 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   // -------------------------------------------------------------------- rows
   __shared__ __attribute__((aligned(16))) float s_mu[256], s_sd[256], s_lsd[256];
   __shared__ __attribute__((aligned(16))) unsigned short s_hi[RB][2 * DIM], s_lo[RB][2 * DIM];
-  __shared__ double s_sum[256][4];
+  __shared__ double s_sum[256][F16 ? 9 : 4];     // per-element terms of the row sums (F16: + the five sums of the data-dependent bound)
+  __shared__ float s_scale[RB];                  // MIXED / F16: the row's power-of-two normalisation (NaN: none usable)
   __shared__ __attribute__((aligned(16))) float s_coef[RB][2 * DIM];
   const long row0 = (long)blockIdx.x * RB;
   // element of the tile handled in phase 1: rows fastest for BCHW (consecutive l -> coalesced z reads), else dims fastest
@@ -320,7 +316,25 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   s_sum[lr * DIM + g][1] = t1;
   s_sum[lr * DIM + g][2] = t2;
   s_sum[lr * DIM + g][3] = t3;
+  if constexpr (F16) {
+    // This element's terms of the data-dependent bound (gq_rerank.h:f16_bound), from the fp32 coefficients the filter multiplies.
+    // A coordinate is a "well" when A < 0 and the vertex mu' = B / (2 |A|) of its parabola lies within |mu'| <= 6 (any
+    // classification is valid; this one keeps M_well small); everything else is charged at its worst case over |n| <= N1.
+    // (Round 4: one fp64 division per THREAD here instead of DIM of them in a serial loop of 256 / DIM lanes.)
+    const double A = (double)cA, B = (double)cB;
+    const double a = fabs(A), b = fabs(B);
+    const bool well = A < 0.0 && b <= 12.0 * a;
+    s_sum[lr * DIM + g][4] = well ? B * B / (4.0 * a) : 0.0;      // M_well
+    s_sum[lr * DIM + g][5] = well ? 0.0 : (A > 0.0 ? A : 0.0);     // P
+    s_sum[lr * DIM + g][6] = well ? 0.0 : a;                       // Q
+    s_sum[lr * DIM + g][7] = well ? 0.0 : b;                       // Rb
+    s_sum[lr * DIM + g][8] = B * B;                                // |B|^2
+  }
   __syncthreads();
+  if constexpr (MIXED || F16) {
+    if (tid < RB) s_scale[tid] = mixed_row_scale(&s_coef[tid][0], 2 * DIM);     // once per row
+    __syncthreads();
+  }
 
   // ---- phase 2: everything leaves the block as contiguous runs ----
   const long e_out = row0 * DIM + tid;               // the tile is contiguous in [rows, dim]
@@ -345,39 +359,37 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
 #pragma unroll
     for (int i = 0; i < DIM; ++i) acc += s_sum[r * DIM + i][q];
     if constexpr (MIXED || F16) {
-      const float sc = mixed_row_scale(&s_coef[r][0], 2 * DIM);
+      const float sc = s_scale[r];
       if (sc != sc) acc = __builtin_nan("");     // no usable normalisation: the row's bound is NaN -> undecided
     }
     p.rowsum[(row0 + r) * 4 + q] = acc;
   }
   if constexpr (F16) {
-    // The sums of the data-dependent bound (gq_rerank.h:f16_bound), from the fp32 coefficients the filter multiplies.  A
-    // coordinate is a "well" when A < 0 and the vertex mu' = B / (2 |A|) of its parabola lies within |mu'| <= 6 (any
-    // classification is valid; this one keeps M_well small); everything else is charged at its worst case over |n| <= N1.
-    if (tid < RB && row0 + tid < p.rows) {
-      double Mw = 0.0, P = 0.0, Q = 0.0, Rb = 0.0, B2 = 0.0, Amax = 0.0, cmax = 0.0;
+    // The sums of the data-dependent bound, ascending dim order (deterministic), each rounded UP to fp32: thread (row, q) adds the
+    // per-element terms phase 1 left in LDS; q = 5, 6: the two maxima max|A|, max(|A|, |B|).
+    for (int w = tid; w < RB * 8; w += 256) {
+      const int r = w >> 3, q = w & 7;
+      if (row0 + r >= p.rows) continue;
+      double acc = 0.0;
+      if (q < 5) {
 #pragma unroll
-      for (int i = 0; i < DIM; ++i) {
-        const double A = (double)s_coef[tid][i], B = (double)s_coef[tid][DIM + i];
-        const double a = fabs(A), b = fabs(B);
-        const bool well = A < 0.0 && b <= 12.0 * a;
-        if (well) Mw += B * B / (4.0 * a);
-        else { P += A > 0.0 ? A : 0.0; Q += a; Rb += b; }
-        B2 += B * B;
-        Amax = a > Amax ? a : Amax;
-        cmax = a > cmax ? a : cmax;
-        cmax = b > cmax ? b : cmax;
+        for (int i = 0; i < DIM; ++i) acc += s_sum[r * DIM + i][4 + q];
+      } else if (q < 7) {
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) {
+          m = __builtin_fmaxf(m, fabsf(s_coef[r][i]));
+          if (q == 6) m = __builtin_fmaxf(m, fabsf(s_coef[r][DIM + i]));
+        }
+        acc = (double)m;
       }
-      f32x4 o0 = {f32_up(Mw), f32_up(P), f32_up(Q), f32_up(Rb)}, o1 = {f32_up(B2), f32_up(Amax), f32_up(cmax), 0.0f};
-      f32x4 *dst = reinterpret_cast<f32x4 *>(p.rowaux + (row0 + tid) * 8);
-      dst[0] = o0;
-      dst[1] = o1;
+      p.rowaux[(row0 + r) * 8 + q] = q < 7 ? f32_up(acc) : 0.0f;
     }
     if (p.rowimg && tid < RB * NVEC * 2) {
       // row image: vector m, half h = fp16 of the normalised [A | B] slots 16 m + 8 h .. + 7 (DIM 4: half 0 holds all 8, half 1 zeros)
       const int r = tid / (NVEC * 2), v = (tid / 2) % NVEC, h = tid % 2;
       if (row0 + r < p.rows) {
-        float sc = mixed_row_scale(&s_coef[r][0], 2 * DIM);
+        float sc = s_scale[r];
         if (v == 0 && h == 0) p.rowscale[row0 + r] = sc != sc ? sc : 1.0f / sc;     // 2^e_r (exact)
         if (sc != sc) sc = 0.0f;
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
       // parts * 2^-6 for slots 16h .. 16h + 15 (h = 0: A of all dims, h = 1: B), vector 3: fp8 of the fp16 residuals * 2^6
       const int r = tid / 8, v = (tid / 2) % 4, h = tid % 2;
       if (row0 + r < p.rows) {
-        float sc = mixed_row_scale(&s_coef[r][0], 2 * DIM);
+        float sc = s_scale[r];
         if (v == 0 && h == 0) p.rowscale[row0 + r] = sc != sc ? sc : 1.0f / sc;     // 2^e_r (exact)
         if (sc != sc) sc = 0.0f;
         u32x4 out;

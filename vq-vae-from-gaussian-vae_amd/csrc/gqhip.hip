@@ -22,7 +22,6 @@
 #include "gq_rerank.h"
 #include "gq_scores.h"
 #include "gq_scores_f16.h"
-#include "gq_tail.h"
 
 using namespace gqhip;
 
@@ -54,8 +53,6 @@ struct Plan {
   bool bf16;            // split-bf16 filter (gq_filter_bf16.h) instead of the fp32 MFMA one
   int ct;               // tiles per LDS chunk of the split-bf16 filter
   int waves;            // waves per block: 8 (one block per CU) for the split-bf16 filter, else 4
-  // second level of the cascade behind the split-bf16 filter: the fp32 MFMA filter (RT 1) on the undecided rows
-  int nsplit2, tiles_per_split2, gt2;
   bool mixed;           // dim 16, Gaussian score: fp16 main product + fp8 corrections instead of three bf16 products
   bool f16;             // fp16 main product only + the data-dependent bound of the re-rank (round 3: the default filter)
 };
@@ -116,18 +113,11 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   static const int env_ct = getenv("GQHIP_BF16_CT") ? atoi(getenv("GQHIP_BF16_CT")) : 0;
   pl.ct = dim == 32 ? 4 : ((dim == 16 && pl.waves == 8 && env_ct != 8) ? 16 : 8);
 
-  static const int env_bgt = getenv("GQHIP_BF16_GT") ? atoi(getenv("GQHIP_BF16_GT")) : 0;
-  // Candidate granularity of the split-bf16 filter: GT tiles per half-group.  The tracker's top-4 insert (12 VALU) runs
-  // once per GT tiles, and VALU issue is what the loop is short of (two waves per SIMD: ~83 % of the issue slots at GT 1),
-  // so coarse candidates make the filter faster (measured at config 2: GT 1 162 us, 2 157, 4 153); the re-rank's fp32
-  // pre-filter makes their 16 GT codes cheap to go through.  GT 1 / 2 / 8: diagnostics (2 and 8: dim 16, RT 2 only).
-  if (pl.bf16) {
-    pl.gt = 4;
-    if (env_bgt == 1 && dim != 4) pl.gt = 1;
-    if ((env_bgt == 2 || env_bgt == 8) && dim == 16 && pl.waves == 8 && pl.rt == 2 && pl.ct == 16) pl.gt = env_bgt;
-  } else {
-    pl.gt = dim <= 8 ? 4 : 2;
-  }
+  // Candidate granularity: GT tiles per half-group.  Behind the bf16 / fp16 filters 4 (64-code candidates): the tracker's top-4
+  // insert (12 VALU) runs once per GT tiles, and VALU issue is what those loops are short of (measured at config 2 with the
+  // split-bf16 filter: GT 1 162 us, 2 157, 4 153; GT 8: filter -2 us, re-rank +14 us); the re-rank's fp32 pre-filter makes their
+  // 16 GT codes cheap to go through.
+  pl.gt = pl.bf16 ? 4 : (dim <= 8 ? 4 : 2);
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   pl.mixed = pl.bf16 && want_mixed_filter() && dim == 16 && pl.waves == 8 && pl.ct == 16 && pl.gt == 4;
@@ -141,17 +131,13 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
     pl.tiles_per_split = ((pl.tiles_total + s3 - 1) / s3 + pl.gt - 1) / pl.gt * pl.gt;
     pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   }
-  pl.gt2 = dim <= 8 ? 4 : 2;
-  int s2 = pl.tiles_total < 16 ? pl.tiles_total : 16;          // 16 splits: 4096 codes per block at N = 65 536
-  pl.tiles_per_split2 = ((pl.tiles_total + s2 - 1) / s2 + pl.gt2 - 1) / pl.gt2 * pl.gt2;
-  pl.nsplit2 = (pl.tiles_total + pl.tiles_per_split2 - 1) / pl.tiles_per_split2;
   return pl;
 }
 
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WsLayout {
-  int64_t hdr, rec, fb, fb2, rec2, spread, mu, sd, lsd, rowsum, coef, cbimg, rowimg, rowscale, rowaux, total;
+  int64_t hdr, rec, fb, dbg, mu, sd, lsd, rowsum, coef, cbimg, rowimg, rowscale, rowaux, total;
 };
 
 WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
@@ -161,10 +147,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.hdr = off; off += (int64_t)sizeof(WsHeader);
   w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit * ((pl.mixed || pl.f16) ? 2 : 1) : 0));
   w.fb = off;  off += align256(4 * rows);
-  // cascade behind the split-bf16 filter: list B + the second-level fp32 filter's records (kCascadeSplit splits)
-  w.fb2 = off;  off += pl.bf16 ? align256(4 * rows) : 0;
-  w.rec2 = off; off += pl.bf16 ? align256((int64_t)sizeof(Rec) * rows * pl.nsplit2) : 0;
-  w.spread = off; off += align256((int64_t)sizeof(SpreadSlot) * kSpreadRows);
+  w.dbg = off; off += 64 * 1024;      // diagnostic builds only (GQHIP_CLOCK_STAMPS: per-block timeline records of the filter)
   w.mu = off;  off += align256(4 * rows * dim);
   w.sd = off;  off += align256(4 * rows * dim);
   w.lsd = off; off += align256(4 * rows * dim);
@@ -244,20 +227,20 @@ int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t s
   return check_launch();
 }
 
-// re-rank: 16 lanes per row, 16 rows per block; row operands (DIM) and the first candidate's GT code rows in registers
+// re-rank: 16 lanes per row, 16 rows per block; NSI = record passes per lane (1 covers up to 16 record sets: every BASELINE shape)
 template <int MODE>
 int launch_rerank(const RerankParams &rp, int64_t rows, int dim, hipStream_t st) {
   const dim3 grid((unsigned)((rows + 15) / 16));
-#define GQ_RR(D, G) hipLaunchKernelGGL((gq_rerank_kernel<MODE, D, G>), grid, dim3(256), 0, st, rp)
+#define GQ_RR(D, G)                                                                                  \
+  do {                                                                                               \
+    if (rp.nsplit <= 16) hipLaunchKernelGGL((gq_rerank_kernel<MODE, D, G, 1>), grid, dim3(256), 0, st, rp); \
+    else hipLaunchKernelGGL((gq_rerank_kernel<MODE, D, G, 4>), grid, dim3(256), 0, st, rp);           \
+  } while (0)
   switch (dim * 100 + rp.gt) {
     case 404: GQ_RR(4, 4); break;
-    case 801: GQ_RR(8, 1); break;
     case 804: GQ_RR(8, 4); break;
-    case 1601: GQ_RR(16, 1); break;
     case 1602: GQ_RR(16, 2); break;
     case 1604: GQ_RR(16, 4); break;
-    case 1608: GQ_RR(16, 8); break;
-    case 3201: GQ_RR(32, 1); break;
     case 3202: GQ_RR(32, 2); break;
     case 3204: GQ_RR(32, 4); break;
     default: return GQHIP_ERR_INVALID_ARG;
@@ -300,9 +283,7 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
   } while (0)
 #define GQ_LAUNCH_BF(NV, R, C)                                                                            \
   do {                                                                                                    \
-    if (pl.waves == 8 && pl.gt == 4) GQ_LAUNCH_BF1(NV, R, C, 4, 8);                                       \
-    else if (pl.waves == 8) GQ_LAUNCH_BF1(NV, R, C, 1, 8);                                                \
-    else if (pl.gt == 1) GQ_LAUNCH_BF1(NV, R, C, 1, 4);                                                   \
+    if (pl.waves == 8) GQ_LAUNCH_BF1(NV, R, C, 4, 8);                                                     \
     else GQ_LAUNCH_BF1(NV, R, C, 4, 4);                                                                   \
   } while (0)
   if (pl.rt == 2) {
@@ -316,10 +297,7 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
           else
             hipLaunchKernelGGL((gq_filter_bf16_kernel<2, 2, 16, 4, 8, 1>), grid, fblock, 0, st, fp);
         }
-        else if (pl.ct == 16 && pl.gt == 2) GQ_LAUNCH_BF1(2, 2, 16, 2, 8);
-        else if (pl.ct == 16 && pl.gt == 8) GQ_LAUNCH_BF1(2, 2, 16, 8, 8);
-        else if (pl.ct == 16 && pl.gt == 4) GQ_LAUNCH_BF1(2, 2, 16, 4, 8);
-        else if (pl.ct == 16) GQ_LAUNCH_BF1(2, 2, 16, 1, 8);
+        else if (pl.ct == 16) GQ_LAUNCH_BF1(2, 2, 16, 4, 8);
         else GQ_LAUNCH_BF(2, 2, 8);
         break;
       default: GQ_LAUNCH_BF(4, 2, 4); break;
@@ -342,53 +320,6 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
   }
 #undef GQ_LAUNCH_BF
 #undef GQ_LAUNCH_BF1
-  return check_launch();
-}
-
-// Diagnostics of the tail kernel's barrier-failure path (gqhip_debug_tail): the grid multiplied beyond what is
-// co-resident, and a spin limit short enough that a test does not wait half a second per barrier.
-std::atomic<int> g_tail_grid_mult{1};
-std::atomic<int> g_tail_spin_limit{1 << 21};   // polls of ~0.25 us: ~0.5 s
-
-// Grid of the tail kernel: every block should be co-resident (it contains grid barriers on the cascade path), so it
-// is sized from the device: min(occupancy API, 2) blocks per CU x CU count, cached per (device, kernel).  Should the
-// blocks not be co-resident after all, the barriers time out and the kernel finishes barrier-free (gq_tail.h).
-int tail_grid(const void *kernel) {
-  static std::mutex mu;
-  static std::map<std::pair<int, const void *>, int> cache;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = cache.find({dev, kernel});
-  if (it != cache.end()) return it->second;
-  int cus = 0, nb = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) return 0;
-  static const int env_per_cu = getenv("GQHIP_TAIL_BLOCKS_PER_CU") ? atoi(getenv("GQHIP_TAIL_BLOCKS_PER_CU")) : 0;
-  int per_cu = nb < 2 ? nb : 2;
-  if (env_per_cu == 1) per_cu = 1;   // diagnostics
-  const int grid = cus * per_cu;
-  cache[{dev, kernel}] = grid;
-  return grid;
-}
-
-template <int MODE>
-int launch_tail(const RerankParams &rp, const FilterParams &f2, int dim, hipStream_t st) {
-#define GQ_TAIL(D)                                                                               \
-  do {                                                                                           \
-    int g = tail_grid(reinterpret_cast<const void *>(&gq_tail_kernel<MODE, D>));                  \
-    if (g < 1) return GQHIP_ERR_LAUNCH;                                                          \
-    g *= g_tail_grid_mult.load(std::memory_order_relaxed);                                       \
-    hipLaunchKernelGGL((gq_tail_kernel<MODE, D>), dim3((unsigned)g), dim3(256), 0, st, rp, f2);  \
-  } while (0)
-  switch (dim) {
-    case 4: GQ_TAIL(4); break;
-    case 8: GQ_TAIL(8); break;
-    case 16: GQ_TAIL(16); break;
-    case 32: GQ_TAIL(32); break;
-    default: return GQHIP_ERR_INVALID_ARG;
-  }
-#undef GQ_TAIL
   return check_launch();
 }
 
@@ -428,8 +359,9 @@ int launch_prep(const PrepParams &pp, int dim, bool mixed, bool f16, hipStream_t
   return check_launch();
 }
 
-// prep -> filter -> re-rank -> tail (MFMA dims) | prep -> exhaustive (other dims), shared by GQ and VQ.
-// Four launches per call; nothing derived from the codebook or the rows survives the call.
+// prep -> filter -> re-rank (MFMA dims) | prep -> exhaustive (other dims), shared by GQ and VQ.
+// Three launches per call (round 4: the rows the candidates cannot decide are finished inside the re-rank, gq_rerank.h);
+// nothing derived from the codebook or the rows survives the call.
 template <int MODE>
 int run_argmax(const PrepInput &in, const float *mu, const float *sd, const float *lsd, const float *cb, int64_t *idx,
                float *zhat, int64_t dim, int64_t rows, int64_t n, double beta, void *workspace,
@@ -458,10 +390,6 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   rp.rec = reinterpret_cast<const Rec *>(ws + w.rec);
   rp.idx = idx; rp.zhat = zhat; rp.hdr = hdr;
   rp.fb_list = reinterpret_cast<int *>(ws + w.fb);
-  rp.fb2_list = reinterpret_cast<int *>(ws + w.fb2);
-  rp.cascade = pl.bf16 ? 1 : 0;
-  rp.level = 1;
-  rp.spread = reinterpret_cast<SpreadSlot *>(ws + w.spread);
   rp.rows = (int)rows; rp.n = (int)n; rp.dim = (int)dim;
   const bool mixed = pl.mixed && MODE == kModeGQ;
   const bool f16 = pl.f16;
@@ -475,7 +403,8 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   if (env_ef > 0.0) rp.ef_coeff = (float)env_ef;
   rp.beta = (float)beta; rp.nsplit = (mixed || f16) ? 2 * pl.nsplit : pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
-  rp.bar_spin_limit = g_tail_spin_limit.load(std::memory_order_relaxed);
+  rp.rec_halves = (mixed || f16) ? 2 : 1;
+  rp.tiles_per_split = pl.tiles_per_split; rp.tiles_total = pl.tiles_total;
 
   if (!pl.mfma) {
     // dims outside {4, 8, 16, 32}: exact score of every code (gq_exhaustive_kernel)
@@ -514,7 +443,6 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   if (rc != GQHIP_OK) return rc;
 
   // ---- launch 2: the filter ---------------------------------------------------------------------------------
-  FilterParams f2{};   // second level of the cascade (tail kernel); unused behind the fp32 filter
   if (pl.bf16) {
     FilterBfParams fp{};
     fp.cbimg = pp.cbimg; fp.rowimg = pp.rowimg;
@@ -522,18 +450,10 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     fp.rows = (int)rows; fp.n = (int)n;
     fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
     fp.hdr = hdr;
-    fp.dbg = ws + w.rec2;   // diagnostic builds only (the cascade's records: unused until the tail kernel)
+    fp.dbg = ws + w.dbg;    // diagnostic builds only
     fp.rowscale = (mixed || f16) ? reinterpret_cast<const float *>(ws + w.rowscale) : nullptr;
     rc = launch_filter_bf16<MODE>(pl, fp, (int)dim, mixed, st);
     if (rc != GQHIP_OK) return rc;
-    // Cascade: when more than kCascadeMin rows are undecided (ill-conditioned inputs: the split-bf16 margin is ~16x
-    // the fp32 one), the tail kernel sends them through the fp32 MFMA filter + re-rank before the fp64 second stage.
-    f2.mu = r_mu; f2.sd = r_sd; f2.cb = cb;
-    f2.rec = reinterpret_cast<Rec *>(ws + w.rec2);
-    f2.rows = (int)rows; f2.n = (int)n; f2.beta = (float)beta;
-    f2.nsplit = pl.nsplit2; f2.tiles_total = pl.tiles_total; f2.tiles_per_split = pl.tiles_per_split2;
-    f2.hdr = hdr; f2.dbg = nullptr;
-    f2.row_list = rp.fb_list; f2.row_count = &hdr->fb_count; f2.min_count = kCascadeMin;
   } else {
     FilterParams fp{};
     fp.mu = r_mu; fp.sd = r_sd; fp.cb = cb;
@@ -541,23 +461,13 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     fp.rows = (int)rows; fp.n = (int)n; fp.beta = (float)beta;
     fp.nsplit = pl.nsplit; fp.tiles_total = pl.tiles_total; fp.tiles_per_split = pl.tiles_per_split;
     fp.hdr = hdr;
-    fp.dbg = ws + w.spread;   // diagnostic builds only
+    fp.dbg = ws + w.dbg;      // diagnostic builds only
     rc = launch_filter<MODE>(pl, fp, (int)dim, st);
     if (rc != GQHIP_OK) return rc;
   }
 
-  // ---- launch 3: exact re-rank of the candidates ----------------------------------------------------------------
-  rc = launch_rerank<MODE>(rp, rows, (int)dim, st);
-  if (rc != GQHIP_OK) return rc;
-
-  // ---- launch 4: the tail (returns at once when every row was decided) ------------------------------------------
-  RerankParams r2 = rp;
-  if (pl.bf16) {
-    r2.rec = reinterpret_cast<const Rec *>(ws + w.rec2);
-    r2.nsplit = pl.nsplit2; r2.gt = pl.gt2; r2.ef_coeff = (float)(2 * dim + 4); r2.n1_limit = 0.f; r2.rowaux = nullptr;
-  }
-  r2.level = 2;
-  return launch_tail<MODE>(r2, f2, (int)dim, st);
+  // ---- launch 3: exact re-rank of the candidates; rows they cannot decide are finished by their own block --------------
+  return launch_rerank<MODE>(rp, rows, (int)dim, st);
 }
 
 }  // namespace
@@ -813,6 +723,32 @@ int gq_indices_from_u16(const uint16_t *in, int64_t *idx, int64_t count, void *s
   return check_launch();
 }
 
+int64_t gq_step_record_workspace_bytes(int64_t B, int64_t per_image) {
+  if (B < 0 || per_image < 1) return -1;
+  const int64_t chunks = (per_image + kPsnrChunk - 1) / kPsnrChunk;
+  return B * chunks * 8 + ((B * 4 + 7) / 8) * 8;
+}
+
+int gq_step_record_f32(const float *x, const float *x_rec, const int64_t *idx, int32_t *rec, int64_t B, int64_t per_image,
+                       int64_t n_idx, void *workspace_zeroed, int64_t workspace_bytes, void *stream) {
+  if (B < 0 || per_image < 1 || n_idx < 0 || B > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0 && n_idx == 0) return GQHIP_OK;
+  if (!rec || (B > 0 && (!x || !x_rec)) || (n_idx > 0 && !idx)) return GQHIP_ERR_INVALID_ARG;
+  if (B > 0 && (!workspace_zeroed || workspace_bytes < gq_step_record_workspace_bytes(B, per_image))) return GQHIP_ERR_WORKSPACE;
+  StepRecordParams p{};
+  p.x = x; p.x_rec = x_rec; p.idx = idx; p.rec = rec;
+  p.per_image = (long)per_image; p.n_idx = (long)n_idx; p.B = (int)B;
+  p.chunks = (int)((per_image + kPsnrChunk - 1) / kPsnrChunk);
+  if ((int64_t)p.chunks * B > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
+  p.psnr_blocks = p.chunks * (int)B;
+  p.partial = static_cast<double *>(workspace_zeroed);
+  p.ticket = reinterpret_cast<int *>(static_cast<char *>(workspace_zeroed) + B * p.chunks * 8);
+  const int64_t words = (n_idx + 1) / 2;
+  const int64_t blocks = p.psnr_blocks + (words + 255) / 256;
+  hipLaunchKernelGGL(step_record_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
 int gqhip_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
@@ -876,22 +812,6 @@ int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
   if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
   if (fallback_rows_host) *fallback_rows_host = h.fb_count;
   if (reranked_halftiles_host) *reranked_halftiles_host = (int64_t)h.reranked;
-  return GQHIP_OK;
-}
-
-int gqhip_debug_barrier(const void *workspace, int64_t *timeouts_host, int64_t *aborted_host) {
-  if (!workspace) return GQHIP_ERR_INVALID_ARG;
-  WsHeader h;
-  if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
-  if (timeouts_host) *timeouts_host = h.bar_timeout;
-  if (aborted_host) *aborted_host = (h.bar_gen == kBarAbort || h.bar_abort) ? 1 : 0;
-  return GQHIP_OK;
-}
-
-int gqhip_debug_tail(int grid_mult, int spin_limit) {
-  if (grid_mult < 1 || grid_mult > 64 || spin_limit < 1) return GQHIP_ERR_INVALID_ARG;
-  g_tail_grid_mult.store(grid_mult, std::memory_order_relaxed);
-  g_tail_spin_limit.store(spin_limit, std::memory_order_relaxed);
   return GQHIP_OK;
 }
 

@@ -18,7 +18,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
 LIB_PATH = os.environ.get("GQHIP_LIB", os.path.join(_CSRC, "libgqhip.so"))  # GQHIP_LIB: diagnostic builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 GNSTAT_WORDS = 8     # int64 words per (image, group) statistics record (gqhip.h: gqhip_gnstat_t)
 GQHIP_LAYOUT = {"bchw": 0, "blc": 1}
 GQHIP_GROUP_STRIDED = 0
@@ -92,13 +92,13 @@ _SIGNATURES = {
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "gq_indices_from_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "gq_step_record_workspace_bytes": (_i64, [_i64, _i64]),
+    "gq_step_record_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "gqhip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_profile_reserve": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "gqhip_debug_enable": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_debug_counters": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
-    "gqhip_debug_barrier": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
-    "gqhip_debug_tail": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -887,6 +887,33 @@ def indices_from_u16(u16):
     return out
 
 
+def step_record_ok(x, x_rec, idx) -> bool:
+    """gq_step_record_f32 applies: fp32 HIP images of one dense layout (NCHW or channels_last), int64 indices on the same device."""
+    if not (x.is_cuda and x_rec.is_cuda and idx.is_cuda and x.dtype == torch.float32 and x_rec.dtype == torch.float32
+            and idx.dtype == torch.int64 and x.shape == x_rec.shape and x.dim() == 4):
+        return False
+    la, lb = image_layout(x), image_layout(x_rec)
+    return la is not None and la == lb
+
+
+def step_record(x, x_rec, idx, rec, ws_cache: dict):
+    """rec[:] = [ per-image PSNR(x, x_rec; zero_mean) as fp32 bits | idx as uint16 pairs ] in ONE launch (gqhip.h:
+    gq_step_record_f32; eval.py:152-154,165-169).  ``ws_cache``: the caller's dict that keeps the (zeroed, self-resetting)
+    workspace between calls."""
+    B = x.shape[0]
+    per = x[0].numel()
+    idx = idx.contiguous()      # (any memory order of the SAME logical [B, K, h, w] order is fine for the caller; contiguous = logical order)
+    need = lib().gq_step_record_workspace_bytes(B, per)
+    key = (x.device, B, per)
+    ws = ws_cache.get(key)
+    if ws is None:
+        ws = ws_cache[key] = torch.zeros(max(need, 8), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().gq_step_record_f32(x.data_ptr(), x_rec.data_ptr(), idx.data_ptr(), rec.data_ptr(), B, per, idx.numel(),
+                                        ws.data_ptr(), ws.numel(), _stream()), "gq_step_record_f32")
+    return rec
+
+
 def profile_enable(on: bool) -> None:
     lib().gqhip_profile_enable(1 if on else 0)
 
@@ -942,16 +969,3 @@ def debug_counters(ws: Workspace) -> Tuple[int, int]:
     fb, rr = _i64(0), _i64(0)
     _check(lib().gqhip_debug_counters(ws.buf.data_ptr(), ctypes.byref(fb), ctypes.byref(rr)), "gqhip_debug_counters")
     return fb.value, rr.value
-
-
-def debug_barrier(ws: Workspace) -> Tuple[int, int]:
-    """(blocks of the tail kernel whose grid-barrier wait ran out, 1 if the call finished barrier-free) for the last
-    call on ``ws``."""
-    to, ab = _i64(0), _i64(0)
-    _check(lib().gqhip_debug_barrier(ws.buf.data_ptr(), ctypes.byref(to), ctypes.byref(ab)), "gqhip_debug_barrier")
-    return to.value, ab.value
-
-
-def debug_tail(grid_mult: int = 1, spin_limit: int = 1 << 21) -> None:
-    """Test hook: oversubscribe the tail kernel's grid / shorten its barrier wait (gqhip.h)."""
-    _check(lib().gqhip_debug_tail(int(grid_mult), int(spin_limit)), "gqhip_debug_tail")

@@ -107,6 +107,22 @@ class StepRecord:
         rec[self.metric_words:] = u16[0::2] | (u16[1::2] << 16)
         return rec
 
+    def pack_with_psnr(self, indices: torch.Tensor, x: torch.Tensor, x_rec: torch.Tensor) -> torch.Tensor:
+        """pack(indices, psnr_zero_mean(x, x_rec)) for the one-metric layout.  On a HIP device: ONE launch of libgqhip
+        (gq_step_record_f32: the PSNR reduction and the uint16 packing in the same kernel) instead of the ~13 elementwise /
+        reduction kernels of the torch expressions; elsewhere exactly those expressions."""
+        if self.n_metrics == 1 and not self.check_range and indices.is_cuda:
+            from . import _lib
+
+            flat_n = indices.numel()
+            if flat_n != self.bs * self.tokens or x.shape[0] != self.bs:
+                raise ValueError(f"StepRecord.pack_with_psnr: got {flat_n} indices / {x.shape[0]} images, layout is "
+                                 f"{self.bs} x {self.tokens}")
+            if _lib.step_record_ok(x, x_rec, indices):
+                rec = torch.empty(self.words, dtype=torch.int32, device=indices.device)
+                return _lib.step_record(x, x_rec, indices, rec, self.__dict__.setdefault("_ws", {}))
+        return self.pack(indices, psnr_zero_mean(x, x_rec)[:, None])
+
     def unpack(self, rec: torch.Tensor):
         """rec: int32 [..., words] -> (indices int64 [..., bs, tokens], metrics fp32 [..., bs, n_metrics])."""
         lead = rec.shape[:-1]
@@ -180,7 +196,7 @@ def evaluate_sharded(model, images_for, n_images: int, bs: int, rank: int, world
         x = images_for(ids).to(device, non_blocking=True)
         zhat, info = model.encode(x, return_reg_log=True)
         rec_img = model.decode(zhat)
-        rec = layout.pack(info["indices"], psnr_zero_mean(x, rec_img)[:, None])
+        rec = layout.pack_with_psnr(info["indices"], x, rec_img)
         gathered.append(gather_step(rec, world))
     if rank != 0 or not gathered:
         return None
