@@ -598,7 +598,7 @@ def test_upsample_fallback_route_matches_upsample_then_conv():
             ref64 = F.conv2d(xu.double(), up.conv.weight.double(), up.conv.bias.double(), 1, 1)
             mag = F.conv2d(xu.double().abs(), up.conv.weight.double().abs(), None, 1, 1)      # sum |x||w| per output
         assert y.shape == (2, ch, 2 * H, 2 * W) and y.is_contiguous(memory_format=torch.channels_last)
-        got = y if b is None else y + b[None, :, None, None]
+        got = (y if b is None else y + b[None, :, None, None]).detach()
         # error model instead of a measured atol: every route here accumulates in fp32 over K = 9 ch terms -- at most
         # ~2^-24 sqrt(K)-ish of sum|x||w| in practice, charged generously at 4e-7 (the fp32 library GEMM's own figure is 2.6-3.5e-7,
         # Winograd F(4x4)'s transforms amplify by a few); the library reference itself is held to the same yardstick

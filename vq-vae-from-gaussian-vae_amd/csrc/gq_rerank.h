@@ -298,10 +298,7 @@ __device__ __forceinline__ void finish_row_by_scan(const RerankParams &p, long r
       }
       float f = 0.0f;
 #pragma unroll
-      for (int i = 0; i < DIM; ++i) {
-        f = __builtin_fmaf(cA[i], n[i] * n[i], f);
-        f = __builtin_fmaf(cB[i], n[i], f);
-      }
+      for (int i = 0; i < DIM; ++i) f = __builtin_fmaf(__builtin_fmaf(cA[i], n[i], cB[i]), n[i], f);
       if (keep_all || !(f < thr)) {                     // a NaN value passes
         double sc;
         if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(n, ops, p.beta);
@@ -457,13 +454,12 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   // this lane's code t (0 .. GT-1) of candidate id: lane half (id & 1) of tile (id >> 1) * GT + t
   const int code_in_tile = (sub & 3) + 8 * (sub >> 2);
   auto code_of = [&](int id, int t) { return ((id >> 1) * GT + t) * kTileCodes + code_in_tile + 4 * (id & 1); };
-  auto expansion = [&](const float (&n)[DIM]) {   // fp32 FMA chain, the fp32 filter's operands
+  // f^ = sum_i (A_i n_i + B_i) n_i: two FMAs per dimension (round 4: Horner form -- one rounding of A n + B, relative to
+  // |A||n| + |B|, and one of the running sum per dimension: <= (dim + 1) u T, inside the E32 = (2 dim + 4) u T charged for it)
+  auto expansion = [&](const float (&n)[DIM]) {
     float f = 0.0f;
 #pragma unroll
-    for (int i = 0; i < DIM; ++i) {
-      f = __builtin_fmaf(cA[i], n[i] * n[i], f);
-      f = __builtin_fmaf(cB[i], n[i], f);
-    }
+    for (int i = 0; i < DIM; ++i) f = __builtin_fmaf(__builtin_fmaf(cA[i], n[i], cB[i]), n[i], f);
     return f;
   };
   const int wave_total = [&] {   // wave-uniform trip count
