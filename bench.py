@@ -112,8 +112,11 @@ def self_launch(argv, n: int) -> int:
     def relay():
         for line in procs[0].stdout:
             lines.append(line)
-            sys.stdout.write(line)
-            sys.stdout.flush()
+            # stdout carries the ONE JSON line; anything else a library prints there (gloo's "[Gloo] Rank 0 is connected ..."
+            # banner) goes to stderr
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            out.write(line)
+            out.flush()
 
     th = threading.Thread(target=relay, daemon=True)
     th.start()

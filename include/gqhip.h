@@ -43,7 +43,7 @@ extern "C" {
                                * 5: GroupNorm statistics as order-independent fixed-point records (gqhip_gnstat_t), conv3x3_f32 (fp32 matrix
                                *    cores: conv_in / conv_out of the encoder and decoder), gqhip_debug_barrier / gqhip_debug_tail;
                                * 6: three-launch fused arg-max -- undecided rows are finished inside the re-rank, the tail kernel with its grid
-                               *    barriers is gone and gqhip_debug_barrier / gqhip_debug_tail with it; psnr_zero_mean_f32, gq_pack_step_record */
+                               *    barriers is gone and gqhip_debug_barrier / gqhip_debug_tail with it; gq_step_record_f32, conv3x3_cin_small_f32 */
 
 /* GroupNorm statistics of one (image, group): GQHIP_GNSTAT_WORDS int64 words = {sum: 3 limbs, sum of squares: 3 limbs, poison,
  * unused}; value = q0 2^-56 + q1 2^-16 + q2 2^24.  Every kernel that leaves statistics behind adds its threads' fp32 partial
@@ -205,6 +205,14 @@ int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y
  * atomics: independent of the order of the adds).  The conv-stack modules use it to notice parameter writes that bump no
  * version counter (`param.data`): their weight-derived caches are rebuilt when a sum differs (pit_hip/modules/unet.py). */
 int gqhip_checksum_tensors(const void *table_dev, int64_t count, uint64_t *sums_dev, void *stream);
+
+/* The encoder's conv_in (pit/modules/unet.py:411-413: 3 -> ch channels): a 3x3 / stride 1 / pad 1 convolution of a channels_last
+ * image with Cin <= 4 input channels into Cout = 128 channels as fp32 FMAs in a FIXED order (tap-major, then input channel), + bias,
+ * + the statistics of the result for the GroupNorm that follows (stats_out: B * 32 records, zeroed here; groups_out must be 32).
+ * wk [9 Cin, 128]: wk[(tap * Cin + ci) * 128 + co] = weight[co][ci][tap / 3][tap % 3].  H % 8 == 0, W % 32 == 0.  Bit-reproducible;
+ * replaces the last library convolution of the bench shapes (ABI 6). */
+int conv3x3_cin_small_f32(const float *x, const float *wk, const float *bias_or_null, float *y, int64_t *stats_out_or_null,
+                          int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, void *stream);
 
 /* 3x3 convolution, stride 1, zero padding 1, NHWC fp32, on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: an exact fp32 FMA
  * chain) with a FIXED summation order, so the result is bit-identical from run to run -- for the narrow ends of the conv

@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 "$REPO/bench.py" --steps 6 --warmup 3 --no-cpu-baseline > "$OUT/bench_stdout.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 "$REPO/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-reference-gpu > "$OUT/bench_stdout.txt" 2>&1
 # after the timed region bench.py runs 5 (stage split) + 23 (back-to-back quantiser calls) more split-bf16 filter launches
 python3 "$REPO/tools/steady_profile.py" "$OUT/bench_trace" 4 28 > "$OUT/STEADY_STATE.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench_trace" -- python3 "$REPO/tools/kbench.py" --iters 20 > "$OUT/kbench_stdout.txt" 2>&1

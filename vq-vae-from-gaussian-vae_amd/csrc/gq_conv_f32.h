@@ -217,4 +217,90 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_nsplit_kernel(const ConvF3
   }
 }
 
+
+// ---- conv3x3_cin_small_f32 (round 4): the encoder's conv_in, 3 -> 128 channels (pit/modules/unet.py:411-413) ----------------
+// A 3x3 / stride 1 / pad 1 convolution of a channels_last image with CIN <= 4 input channels into 128 output channels: 9 CIN fp32
+// FMAs per output in a FIXED order (tap-major, then input channel), + bias, + the statistics of the result for the GroupNorm
+// that follows (the first ResnetBlock's norm1).  HBM-bound on its 512-byte-per-pixel output.  Why it exists: it was the last
+// convolution of the bench shapes on MIOpen, whose immediate mode runs the first eight calls of a process on a 4 ms naive kernel
+// (profiles/r03, r04: naive_conv_ab_nonpacked_fwd_nhwc_float_double_float x 8 = 32 ms per bench run, three of them inside a
+// default run's timed region) before its CK solver (0.24 ms) takes over; here: one kernel, ~0.1 ms, no library, no statistics pass.
+// Block = 8 x 32 output pixels x 128 channels; lane & 31 = a group of 4 output channels (= one GroupNorm(32) group, its 4 x 9 CIN
+// weights in registers for the whole block), lane >> 5 and the wave pick a PAIR of horizontally adjacent pixels per pass
+// (16 passes): the pair shares 6 of its 12 patch columns' LDS reads, and a wave's stores are 2 KiB contiguous.
+struct ConvInParams {
+  const float *x;        // [B, H, W, CIN]
+  const float *wk;       // [9 CIN, 128]: wk[(tap * CIN + ci) * 128 + co] = weight[co][ci][tap / 3][tap % 3]
+  const float *bias;     // [128] or NULL
+  float *y;              // [B, H, W, 128]
+  int64_t *stats;        // [B, 32, kStatWords] zeroed, or NULL
+  int H, W;
+};
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(const ConvInParams p) {
+  constexpr int TH = 8, TW = 32, COUT = 128, K = 9 * CIN;
+  __shared__ float patch[TH + 2][(TW + 2) * CIN];
+  __shared__ int64_t s_stat[32][kStatWords];
+  const int tid = threadIdx.x;
+  const int tiles_w = p.W / TW, tiles_h = p.H / TH;
+  const int tx = blockIdx.x % tiles_w, ty = (blockIdx.x / tiles_w) % tiles_h, b = blockIdx.x / (tiles_w * tiles_h);
+  const int y0 = ty * TH, x0 = tx * TW;
+  for (int i = tid; i < (TH + 2) * (TW + 2) * CIN; i += 256) {
+    const int r = i / ((TW + 2) * CIN), c = i % ((TW + 2) * CIN);
+    const int yy = y0 + r - 1, xx = x0 + c / CIN - 1;
+    float v = 0.0f;
+    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = p.x[(((long)b * p.H + yy) * p.W + xx) * CIN + c % CIN];
+    patch[r][c] = v;
+  }
+  for (int i = tid; i < 32 * kStatWords; i += 256) (&s_stat[0][0])[i] = 0;
+  const int g = tid & 31, pr = tid >> 5;            // channel group, pixel-pair slot (0 .. 7)
+  float w[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(p.wk + k * COUT + 4 * g);
+    w[k][0] = v.x; w[k][1] = v.y; w[k][2] = v.z; w[k][3] = v.w;
+  }
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4 *>(p.bias + 4 * g);
+  __syncthreads();
+  float s = 0.0f, ss = 0.0f;
+  for (int pass = 0; pass < (TH * TW) / 16; ++pass) {
+    const int q = pass * 8 + pr;                    // pixel pair: pixels 2 q, 2 q + 1 of the tile (row-major)
+    const int py = (2 * q) / TW, px = (2 * q) % TW;
+    float xv[3][4 * CIN];                           // 3 rows x 4 columns x CIN of the patch
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int c = 0; c < 4 * CIN; ++c) xv[dy][c] = patch[py + dy][px * CIN + c];
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const int k = (dy * 3 + dx) * CIN + ci;
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            acc[0][o] = __builtin_fmaf(xv[dy][dx * CIN + ci], w[k][o], acc[0][o]);
+            acc[1][o] = __builtin_fmaf(xv[dy][(dx + 1) * CIN + ci], w[k][o], acc[1][o]);
+          }
+        }
+    float *dst = p.y + (((long)b * p.H + y0 + py) * p.W + x0 + px) * COUT + 4 * g;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const f32x4 o = {acc[e][0] + bias4.x, acc[e][1] + bias4.y, acc[e][2] + bias4.z, acc[e][3] + bias4.w};
+      *reinterpret_cast<f32x4 *>(dst + e * COUT) = o;
+      s += (o.x + o.y) + (o.z + o.w);
+      ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+    }
+  }
+  if (p.stats) {
+    stat_add_f32(&s_stat[g][0], s, ss);
+    __syncthreads();
+    const int64_t v = (&s_stat[0][0])[tid];         // 32 groups x 8 words = 256 words: one per thread
+    stat_flush_word(p.stats + (long)b * 32 * kStatWords + tid, v);
+  }
+}
+
 }  // namespace gqhip

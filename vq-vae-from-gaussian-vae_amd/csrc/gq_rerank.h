@@ -78,6 +78,7 @@ struct RerankParams {
                       // squares must stay below 65504); with any other codebook every row is finished by the in-block scan
   float n1_min;
   const float *rowaux;   // [rows, 8] sums of the data-dependent bound (gq_prep_kernel, F16) or NULL: the classic bound k u T
+  void *dbg;          // diagnostic builds only (GQHIP_CLOCK_STAMPS: phase stamps of wave 0 of the first 1024 blocks)
   int all_rows;       // exhaustive kernel: process every row (no filter ran)
   int stats;          // count re-ranked half-pairs (debug)
   OutMap omap;
@@ -350,6 +351,14 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   const unsigned long long glow = (1ull << GROUP) - 1ull;
   auto group_bits = [&](bool c) { return (__ballot(c) >> gshift) & glow; };
 
+#ifdef GQHIP_CLOCK_STAMPS
+  unsigned long long st[8];
+  int nst = 0;
+#define GQ_RR_STAMP() do { if (nst < 8) st[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GQ_RR_STAMP() do { } while (0)
+#endif
+  GQ_RR_STAMP();     // 0: start
   // ---- everything the row needs, issued together ---------------------------
   const float N1f = wave_absmax(p.hdr->absmax_part, lane);
   const float R2f = p.rowaux ? wave_absmax(p.hdr->r2_part, lane) : 0.0f;   // max_j |cb_j|^2 (F16 bound)
@@ -405,6 +414,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
 #pragma unroll
   for (int o = GROUP / 2; o > 0; o >>= 1) fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, o));
 
+  GQ_RR_STAMP();     // 1: records and sums have arrived (fmax reduced)
   double margin = 2.5 * ((double)p.ef_coeff * u * T + Er) + 1e-30;      // around the filter's row maximum
   if (p.rowaux) {
     // fp16 main-product filter: the data-dependent bound (f16_bound above); 1.25 (Ea + Eb + 2 E_r) keeps the same 25 % slack
@@ -451,6 +461,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  GQ_RR_STAMP();     // 2: bound, margins, candidate lists
   // this lane's code t (0 .. GT-1) of candidate id: lane half (id & 1) of tile (id >> 1) * GT + t
   const int code_in_tile = (sub & 3) + 8 * (sub >> 2);
   auto code_of = [&](int id, int t) { return ((id >> 1) * GT + t) * kTileCodes + code_in_tile + 4 * (id & 1); };
@@ -510,6 +521,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   float F = fb;
 #pragma unroll
   for (int o = GROUP / 2; o > 0; o >>= 1) F = __builtin_fmaxf(F, __shfl_xor(F, o));
+  GQ_RR_STAMP();     // 3: pass 1 (gathers + fp32 expansions)
   const float thr32 = F - margin32;
   const bool keep_all = !(F < __builtin_inff()) || !(margin32 < 1e30f);
 
@@ -557,6 +569,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
       have = true;
     }
   }
+  GQ_RR_STAMP();     // 4: pass 2 (the reference's arithmetic) + the group reduction
   const bool decided = live && !undecided;
   if (p.stats && decided && sub == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)total);
   // the block's RPB consecutive rows leave as contiguous runs (BCHW: along l per channel)
@@ -575,6 +588,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
     }
   }
   __syncthreads();
+  GQ_RR_STAMP();     // 5: block barrier
   const long row0 = (long)vblock * RPB;
   if (threadIdx.x < RPB) {
     const int b = s_best[threadIdx.x];
@@ -587,6 +601,14 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
       if (s_best[lr] >= 0) p.zhat[out_zhat_offset(p.omap, row0 + lr, g, DIM)] = s_zhat[lr][g];
     }
   }
+#ifdef GQHIP_CLOCK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GQ_RR_STAMP();     // 6: results stored
+  if (threadIdx.x == 0 && vblock < 1024 && p.dbg) {
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + 8 * vblock;
+    for (int k = 0; k < 8; ++k) o[k] = k < nst ? st[k] : 0ull;
+  }
+#endif
   // ---- the rows the candidates could not decide: finished here, by the whole block, one after the other ----
   for (int sl = 0; sl < RPB; ++sl) {
     const unsigned long long m = s_scan_mask[sl];     // block-uniform (written before the barrier above)

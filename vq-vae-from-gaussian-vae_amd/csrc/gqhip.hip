@@ -147,7 +147,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.hdr = off; off += (int64_t)sizeof(WsHeader);
   w.rec = off; off += align256((int64_t)sizeof(Rec) * rows * (pl.mfma ? pl.nsplit * ((pl.mixed || pl.f16) ? 2 : 1) : 0));
   w.fb = off;  off += align256(4 * rows);
-  w.dbg = off; off += 64 * 1024;      // diagnostic builds only (GQHIP_CLOCK_STAMPS: per-block timeline records of the filter)
+  w.dbg = off; off += 128 * 1024;     // diagnostic builds only (GQHIP_CLOCK_STAMPS: per-block timeline records of the filter | of the re-rank)
   w.mu = off;  off += align256(4 * rows * dim);
   w.sd = off;  off += align256(4 * rows * dim);
   w.lsd = off; off += align256(4 * rows * dim);
@@ -403,6 +403,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   if (env_ef > 0.0) rp.ef_coeff = (float)env_ef;
   rp.beta = (float)beta; rp.nsplit = (mixed || f16) ? 2 * pl.nsplit : pl.nsplit; rp.gt = pl.gt; rp.all_rows = pl.mfma ? 0 : 1; rp.stats = g_debug_stats;
   rp.omap = omap;
+  rp.dbg = ws + w.dbg + 64 * 1024;
   rp.rec_halves = (mixed || f16) ? 2 : 1;
   rp.tiles_per_split = pl.tiles_per_split; rp.tiles_total = pl.tiles_total;
 

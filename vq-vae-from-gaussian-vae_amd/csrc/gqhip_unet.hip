@@ -431,6 +431,28 @@ int conv3x3_gn_small_f32(const float *x, const float *gamma, const float *beta, 
   return check_launch();
 }
 
+int conv3x3_cin_small_f32(const float *x, const float *wk, const float *bias_or_null, float *y, int64_t *stats_out_or_null,
+                          int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t groups_out, void *stream) {
+  if (B < 0 || H < 8 || W < 32 || H % 8 || W % 32 || Cin < 1 || Cin > 4 || Cout != 128 || B * (H / 8) * (W / 32) > 0x7fffffffL)
+    return GQHIP_ERR_INVALID_ARG;
+  if (stats_out_or_null && groups_out != 32) return GQHIP_ERR_INVALID_ARG;
+  if (B == 0) return GQHIP_OK;
+  if (!x || !wk || !y) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(int64_t) * kStatWords * B * 32, st) != hipSuccess)
+    return check_launch();
+  ConvInParams cp{};
+  cp.x = x; cp.wk = wk; cp.bias = bias_or_null; cp.y = y; cp.stats = stats_out_or_null; cp.H = (int)H; cp.W = (int)W;
+  const dim3 grid((unsigned)(B * (H / 8) * (W / 32)));
+  switch (Cin) {
+    case 1: hipLaunchKernelGGL(conv3x3_cin_small_kernel<1>, grid, dim3(256), 0, st, cp); break;
+    case 2: hipLaunchKernelGGL(conv3x3_cin_small_kernel<2>, grid, dim3(256), 0, st, cp); break;
+    case 3: hipLaunchKernelGGL(conv3x3_cin_small_kernel<3>, grid, dim3(256), 0, st, cp); break;
+    default: hipLaunchKernelGGL(conv3x3_cin_small_kernel<4>, grid, dim3(256), 0, st, cp); break;
+  }
+  return check_launch();
+}
+
 int conv3x3_f32(const float *x, const float *gamma_or_null, const float *beta_or_null, const float *pre_bias_or_null,
                 const int64_t *stats_or_null, int64_t groups_in, double eps, int apply_silu, const float *wk,
                 const float *bias_or_null, float *y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, void *stream) {

@@ -77,6 +77,7 @@ _SIGNATURES = {
                                         _i64, _vp]),
     "conv3x3_gn_small_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _i64, _i64,
                                              _i64, _i64, _i64, _vp]),
+    "conv3x3_cin_small_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "conv3x3_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _i64, _i64, _i64,
                                    _i64, _i64, _vp]),
     "gqhip_checksum_tensors": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
@@ -833,6 +834,33 @@ def conv3x3_f32(x, wk, cout: int, bias=None, gn=None):
                                  1 if silu else 0, wk.data_ptr(), _ptr(bias), y.data_ptr(), B, H, W, C, cout, _stream()),
                "conv3x3_f32")
     return y
+
+
+def conv_cin_small_ok(cin: int, cout: int, H: int, W: int) -> bool:
+    """Shapes conv3x3_cin_small_f32 tiles (gqhip.h): the encoder's conv_in."""
+    return 1 <= cin <= 4 and cout == 128 and H % 8 == 0 and W % 32 == 0 and H >= 8 and W >= 32
+
+
+def conv_cin_small_weights(weight):
+    """[128, Cin <= 4, 3, 3] fp32 -> [9 Cin, 128]: row tap * Cin + ci, column co."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    return weight.detach().float().permute(2, 3, 1, 0).reshape(9 * cin, cout).contiguous()
+
+
+def conv3x3_cin_small(x, wk, bias=None, stats_groups: int = 0):
+    """The encoder's conv_in on libgqhip (gqhip.h:conv3x3_cin_small_f32): 3x3 / stride 1 / pad 1, Cin <= 4 -> 128 channels of a
+    channels_last fp32 HIP image, fp32 FMAs in a fixed order, bias added; ``stats_groups`` = 32: returns (y, statistics of y)."""
+    if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32:
+        raise GqHipError("conv3x3_cin_small needs a dense channels_last fp32 HIP tensor")
+    B, C, H, W = x.shape
+    if not conv_cin_small_ok(C, wk.shape[1], H, W) or wk.shape[0] != 9 * C or stats_groups not in (0, 32):
+        raise GqHipError(f"conv3x3_cin_small: shape {tuple(x.shape)} is not tiled by the kernel")
+    with torch.cuda.device(x.device):
+        y = torch.empty((B, 128, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        ostats = torch.empty(GNSTAT_WORDS * B * 32, dtype=torch.int64, device=x.device) if stats_groups else None
+        _check(lib().conv3x3_cin_small_f32(x.data_ptr(), wk.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(ostats), B, H, W, C, 128,
+                                           32, _stream()), "conv3x3_cin_small_f32")
+    return (y, ostats) if stats_groups else y
 
 
 def f16_scales(stats, amp: float, u_scale: float):

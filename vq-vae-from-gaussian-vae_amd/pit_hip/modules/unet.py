@@ -243,6 +243,24 @@ def _conv_f32(conv: nn.Conv2d, x: torch.Tensor, gn=None) -> torch.Tensor:
     return _lib.conv3x3_f32(x, wk, conv.out_channels, bias=conv.bias, gn=gn)
 
 
+def _conv_in_small(conv: nn.Conv2d, x: torch.Tensor):
+    """The encoder's conv_in (unet.py:411-413, 3 -> 128 channels) -> (y, pending_bias).  On the channels_last path: libgqhip's
+    fixed-order fp32 kernel with the bias and the first GroupNorm's statistics in its epilogue (round 4; it was the last MIOpen
+    convolution of the bench shapes: 0.24 ms per call once MIOpen's CK solver runs, 4 ms for each of a process's first eight
+    calls).  Other shapes / layouts: ``_conv``."""
+    if (CONV_IN_SMALL and FUSED_GN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.dim() == 4
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and GN_GROUPS == 32):
+        from .. import _lib
+
+        if _lib.image_layout(x) == 1 and _lib.conv_cin_small_ok(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3]):
+            wk = _cached(conv, "cin_small_wk", _wkey(conv.weight), lambda: _lib.conv_cin_small_weights(conv.weight))
+            y, st = _lib.conv3x3_cin_small(x, wk, conv.bias, stats_groups=GN_GROUPS)
+            y._gn_stats = (st, GN_GROUPS)
+            return y, None
+    return _conv(conv, x)
+
+
 def _norm_act_conv_f32(norm: nn.GroupNorm, conv: nn.Conv2d, x: torch.Tensor, pre_bias=None) -> torch.Tensor:
     """conv(swish(norm(x + pre_bias))) for the encoder's conv_out (unet.py:432-436): GroupNorm + swish applied while the
     patch is staged, fp32 matrix cores, fixed summation order."""
@@ -494,6 +512,7 @@ WINOGRAD_ENCODER = True
 DIRECT_UPCONV = True
 FUSED_QKV = True         # attention: q, k, v as one GEMM with fused biases (channels_last)
 FUSED_ADD_STATS = True   # residual add also produces the next GroupNorm's statistics (channels_last only)
+CONV_IN_SMALL = True     # the encoder's conv_in (3 -> 128) on libgqhip's fixed-order fp32 kernel (+ bias + statistics), not MIOpen
 GN_GROUPS = 32     # unet.py:54-57: every Normalize is GroupNorm(32, C, eps=1e-6)
 DEFER_BIAS = True
 ATTN_F16X3 = True   # both attention GEMMs as fp16 x 3 library GEMMs (split of q, k, v and softmax + split in libgqhip kernels)
@@ -872,7 +891,7 @@ class Encoder(nn.Module):
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         x = _match_layout(x, self.conv_in)
-        h, pb = _conv(self.conv_in, x)
+        h, pb = _conv_in_small(self.conv_in, x)
         for lvl, level in enumerate(self.down):
             h, pb = level.run(h, pb), None
             if lvl != self.num_resolutions - 1:
