@@ -206,6 +206,12 @@ int gn_apply_f32(const float *x, const float *gamma, const float *beta, float *y
  * version counter (`param.data`): their weight-derived caches are rebuilt when a sum differs (pit_hip/modules/unet.py). */
 int gqhip_checksum_tensors(const void *table_dev, int64_t count, uint64_t *sums_dev, void *stream);
 
+/* Every entry point that FILLS GroupNorm statistics records zeroes them first (one small memset launch each).  A caller that hands
+ * out records which are already zero -- e.g. slices of one arena cleared by a single fill per forward, as pit_hip/modules/unet.py
+ * does -- says so with gqhip_stats_prezeroed(1) around those calls; (0) restores the default.  Thread-local.  (ABI 6; no reference
+ * counterpart.) */
+int gqhip_stats_prezeroed(int on);
+
 /* The encoder's conv_in (pit/modules/unet.py:411-413: 3 -> ch channels): a 3x3 / stride 1 / pad 1 convolution of a channels_last
  * image with Cin <= 4 input channels into Cout = 128 channels as fp32 FMAs in a FIXED order (tap-major, then input channel), + bias,
  * + the statistics of the result for the GroupNorm that follows (stats_out: B * 32 records, zeroed here; groups_out must be 32).

@@ -195,3 +195,37 @@ def test_encoder_runs_no_library_convolution_at_the_bench_shape():
     dz = float((z1 - z0).abs().max())
     print(f"encoder z with conv_in on libgqhip vs on MIOpen: |dz| {dz:.2e}; F.conv2d calls with the switch off: {len(calls)}")
     assert dz <= 2e-5
+
+
+def test_statistics_arena_changes_no_bit_and_survives_reentry():
+    """Round 4: the GroupNorm statistics records of a forward come out of one arena zeroed by a single fill (gqhip_stats_prezeroed)
+    instead of one memset launch per producing kernel.  Same bits with and without it, across repeated forwards (the arena is
+    re-zeroed per forward), a changed batch size (it grows), and a direct library call in between (flag back to 'not zeroed')."""
+    from pit_hip import _lib
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(1234)
+    enc = U.Encoder(**FULL).eval().to(DEV).to(memory_format=torch.channels_last)
+    dec = U.Decoder(**FULL).eval().to(DEV).to(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(9)
+    xs = [(torch.rand(b, 3, 256, 256, generator=g) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last) for b in (2, 3, 2)]
+    probe = torch.randn(2, 128, 16, 16, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for flag in (True, False, True):
+        U.STATS_ARENA = flag
+        try:
+            with torch.no_grad():
+                got = []
+                for x in xs:
+                    z = enc(x)
+                    st = _lib.gn_stats(probe, 32)                  # a direct call between forwards: its records are NOT pre-zeroed
+                    got.append((z.clone(), dec(z[:, :16].contiguous(memory_format=torch.channels_last)).clone(), _lib.gn_stats_values(st)))
+        finally:
+            U.STATS_ARENA = True
+        outs.setdefault(flag, []).append(got)
+    a, b = outs[True][0], outs[False][0]
+    for (z1, r1, s1), (z0, r0, s0) in zip(a, b):
+        assert torch.equal(z1, z0) and torch.equal(r1, r0) and torch.equal(s1, s0)
+    for (z1, r1, s1), (z2, r2, s2) in zip(outs[True][0], outs[True][1]):
+        assert torch.equal(z1, z2) and torch.equal(r1, r2)
+    assert enc.__dict__["_gq_stats_arena"].buf is not None and enc.__dict__["_gq_stats_arena"].used > 0

@@ -16,7 +16,22 @@
 
 using namespace gqhip;
 
+namespace {
+// Statistics records are zeroed by the entry point that fills them -- unless the caller has said that they already are
+// (gqhip_stats_prezeroed: the conv stack's modules carve all records of a forward out of one arena zeroed by ONE fill, instead of
+// ~60 separate 32-KB memset launches per step).  Thread-local: the flag belongs to the calling thread's sequence of calls.
+thread_local int g_stats_prezeroed = 0;
+inline hipError_t stats_zero(void *p, size_t bytes, hipStream_t st) {
+  return g_stats_prezeroed ? hipSuccess : hipMemsetAsync(p, 0, bytes, st);
+}
+}  // namespace
+
 extern "C" {
+
+int gqhip_stats_prezeroed(int on) {
+  g_stats_prezeroed = on != 0;
+  return GQHIP_OK;
+}
 
 int gn_silu_f32(const float *x, const float *gamma, const float *beta, const float *pre_bias_or_null, float *y,
                 int64_t B, int64_t C, int64_t HW, int64_t groups, double eps, int apply_silu, int layout,
@@ -29,7 +44,7 @@ int gn_silu_f32(const float *x, const float *gamma, const float *beta, const flo
   if (layout == GQHIP_LAYOUT_NHWC) {
     // thread <-> channel-quad mapping needs cpg % 4 == 0, (C/4) | 256, <= 64 groups
     if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
-    if (hipMemsetAsync(stats_ws, 0, sizeof(int64_t) * kStatWords * bg, st) != hipSuccess) return check_launch();
+    if (stats_zero(stats_ws, sizeof(int64_t) * kStatWords * bg, st) != hipSuccess) return check_launch();
     const int lanes = (int)(256 / (C / 4));
     int slabs = (int)((HW + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16));   // ~16 pixels per thread
     if (slabs > 1024) slabs = 1024;
@@ -47,7 +62,7 @@ int gn_silu_f32(const float *x, const float *gamma, const float *beta, const flo
     return check_launch();
   }
   if (layout != GQHIP_LAYOUT_NCHW || HW % 4 != 0) return GQHIP_ERR_INVALID_ARG;   // callers fall back to torch
-  if (hipMemsetAsync(stats_ws, 0, sizeof(int64_t) * kStatWords * bg, st) != hipSuccess) return check_launch();
+  if (stats_zero(stats_ws, sizeof(int64_t) * kStatWords * bg, st) != hipSuccess) return check_launch();
   // ~16 KiB of input per block keeps >= 2k blocks in flight at the big resolutions
   int slices = (int)((chunk + 4095) / 4096);
   if (slices > 256) slices = 256;
@@ -105,7 +120,7 @@ int add_bias_stats_f32(const float *a, const float *b, const float *bias_or_null
   const int64_t cpg = C / groups;
   if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(stats_out, 0, sizeof(int64_t) * kStatWords * B * groups, st) != hipSuccess) return check_launch();
+  if (stats_zero(stats_out, sizeof(int64_t) * kStatWords * B * groups, st) != hipSuccess) return check_launch();
   const int slabs = nhwc_slabs(C, HW);
   hipLaunchKernelGGL(add_bias_stats_nhwc_kernel, dim3((unsigned)(B * slabs)), dim3(256), 0, st, a, b, bias_or_null, y,
                      stats_out, (int)C, (long)HW, (int)cpg, slabs);
@@ -204,7 +219,7 @@ int gn_stats_f32(const float *x, const float *pre_bias_or_null, int64_t B, int64
   const int64_t cpg = C / groups;
   if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(stats_out, 0, sizeof(int64_t) * kStatWords * B * groups, st) != hipSuccess) return check_launch();
+  if (stats_zero(stats_out, sizeof(int64_t) * kStatWords * B * groups, st) != hipSuccess) return check_launch();
   const int slabs = nhwc_slabs(C, HW);
   hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3((unsigned)(B * slabs)), dim3(256), 0, st, x, pre_bias_or_null, stats_out,
                      (int)C, (long)HW, (int)cpg, slabs);
@@ -306,7 +321,7 @@ int conv3x3_gn_f16x3(const float *x, const float *gamma, const float *beta, cons
   if (B == 0) return GQHIP_OK;
   if (!x || !gamma || !beta || !stats_in || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
+  if (stats_out_or_null && stats_zero(stats_out_or_null, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
     return check_launch();
   Conv3GnParams gp{};
   Conv3Params &cp = gp.c;
@@ -342,7 +357,7 @@ int conv1x1_f16x3(const float *x, const float *pre_bias_or_null, const void *Wf,
   if (B == 0) return GQHIP_OK;
   if (!x || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
+  if (stats_out_or_null && stats_zero(stats_out_or_null, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
     return check_launch();
   Conv1Params gp{};
   Conv3Params &cp = gp.c;
@@ -368,7 +383,7 @@ int conv3x3s2_f16x3(const float *x, const void *Wf, const float *scales_dev_or_n
   if (B == 0) return GQHIP_OK;
   if (!x || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
+  if (stats_out_or_null && stats_zero(stats_out_or_null, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
     return check_launch();
   Conv3S2Params gp{};
   Conv3Params &cp = gp.c;
@@ -391,7 +406,7 @@ int upconv2x_f16x3(const float *x, const void *Wf, const float *scales_dev_or_nu
   if (B == 0) return GQHIP_OK;
   if (!x || !Wf || !y) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
+  if (stats_out_or_null && stats_zero(stats_out_or_null, sizeof(int64_t) * kStatWords * B * groups_out, st) != hipSuccess)
     return check_launch();
   Upconv2Params gp{};
   Conv3Params &cp = gp.c;
@@ -439,7 +454,7 @@ int conv3x3_cin_small_f32(const float *x, const float *wk, const float *bias_or_
   if (B == 0) return GQHIP_OK;
   if (!x || !wk || !y) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (stats_out_or_null && hipMemsetAsync(stats_out_or_null, 0, sizeof(int64_t) * kStatWords * B * 32, st) != hipSuccess)
+  if (stats_out_or_null && stats_zero(stats_out_or_null, sizeof(int64_t) * kStatWords * B * 32, st) != hipSuccess)
     return check_launch();
   ConvInParams cp{};
   cp.x = x; cp.wk = wk; cp.bias = bias_or_null; cp.y = y; cp.stats = stats_out_or_null; cp.H = (int)H; cp.W = (int)W;
@@ -533,7 +548,7 @@ int wino_out_res_nhwc_f32(const float *M, const float *res, const float *bias_or
   const int64_t cpg = C / groups;
   if (cpg % 4 != 0 || 256 % (C / 4) != 0 || groups > 64) return GQHIP_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(stats_out, 0, sizeof(int64_t) * kStatWords * B * groups, st) != hipSuccess) return check_launch();
+  if (stats_zero(stats_out, sizeof(int64_t) * kStatWords * B * groups, st) != hipSuccess) return check_launch();
   const long tpi = (long)((H / tile) * (W / tile)), tiles = (long)B * tpi;
   // F(4x4,3x3): two channels per thread (see the kernel) wherever a block still spans whole pixels
   const int vw = (tile == 4 && 256 % (C / 2) == 0) ? 2 : 4;

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "f16_scales_from_gn_stats": (ctypes.c_int, [_vp, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "upsample2x_nhwc_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "add_bias_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp]),
+    "gqhip_stats_prezeroed": (ctypes.c_int, [ctypes.c_int]),
     "gq_index_histogram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "gq_indices_to_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "gq_indices_from_u16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -353,6 +354,68 @@ def image_layout(x: torch.Tensor):
     return None
 
 
+class StatsArena:
+    """All GroupNorm statistics records of ONE forward of a module, carved out of one int64 buffer that a single fill zeroes at
+    the forward's start (gqhip.h:gqhip_stats_prezeroed) -- instead of one 32-KB memset launch in front of every kernel that leaves
+    statistics behind (~60 per encode + decode step).  Grows to the forward's demand; records that do not fit come from
+    torch.empty and are zeroed by the entry point as before."""
+
+    def __init__(self) -> None:
+        self.buf, self.used, self.want = None, 0, 0
+
+    def begin(self, device) -> None:
+        if self.buf is None or self.buf.device != device or self.buf.numel() < self.want:
+            self.buf = torch.zeros(max(self.want, 1), dtype=torch.int64, device=device)
+        elif self.used:
+            self.buf[: self.used].zero_()
+        self.used = self.want = 0
+
+    def take(self, nwords: int):
+        self.want += nwords
+        if self.buf is None or self.used + nwords > self.buf.numel():
+            return None
+        t = self.buf[self.used: self.used + nwords]
+        self.used += nwords
+        return t
+
+
+_ARENA = {"active": None, "flag": 0}
+
+
+class stats_arena:
+    """``with stats_arena(arena, device): ...`` -- the statistics records allocated inside come from ``arena``."""
+
+    def __init__(self, arena: StatsArena, device) -> None:
+        self.arena, self.device = arena, device
+
+    def __enter__(self):
+        self.prev = _ARENA["active"]
+        self.arena.begin(self.device)
+        _ARENA["active"] = self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        _ARENA["active"] = self.prev
+        _set_prezeroed(0)
+
+
+def _set_prezeroed(on: int) -> None:
+    if _ARENA["flag"] != on:
+        lib().gqhip_stats_prezeroed(on)
+        _ARENA["flag"] = on
+
+
+def _stats_records(nwords: int, device):
+    """An int64 tensor for ``nwords`` words of statistics records; tells the library whether it is already zero."""
+    a = _ARENA["active"]
+    t = a.take(nwords) if a is not None else None
+    if t is not None and t.device == device:
+        _set_prezeroed(1)
+        return t
+    _set_prezeroed(0)
+    return torch.empty(nwords, dtype=torch.int64, device=device)
+
+
 def gn_nhwc_ok(C: int, groups: int) -> bool:
     cpg = C // groups
     return C % groups == 0 and cpg % 4 == 0 and C % 4 == 0 and 256 % (C // 4) == 0 and groups <= 64
@@ -367,7 +430,7 @@ def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True, pre_bias
     HW = x.shape[2] * x.shape[3]
     # statistics scratch: a fresh (stream-ordered, caching-allocator) tensor per call -- a process-global buffer would be
     # shared by concurrent streams / models and baked into captured graphs
-    ws = torch.empty(GNSTAT_WORDS * B * groups, dtype=torch.int64, device=x.device)
+    ws = _stats_records(GNSTAT_WORDS * B * groups, x.device)
     y = torch.empty_like(x)  # preserves the memory format
     with torch.cuda.device(x.device):
         _check(lib().gn_silu_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), y.data_ptr(), B, C, HW,
@@ -396,7 +459,7 @@ def add_bias_stats(a, b, bias, groups: int):
     B, C = a.shape[0], a.shape[1]
     HW = a.shape[2] * a.shape[3]
     y = torch.empty_like(a)
-    stats = torch.empty(GNSTAT_WORDS * B * groups, dtype=torch.int64, device=a.device)
+    stats = _stats_records(GNSTAT_WORDS * B * groups, a.device)
     with torch.cuda.device(a.device):
         _check(lib().add_bias_stats_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, groups,
                                         stats.data_ptr(), _stream()), "add_bias_stats_f32")
@@ -433,7 +496,7 @@ def gn_stats(x, groups: int, pre_bias=None):
     if image_layout(x) != 1 or not x.is_cuda or x.dtype != torch.float32 or not gn_nhwc_ok(x.shape[1], groups):
         raise GqHipError("gn_stats needs a dense channels_last fp32 HIP tensor with a GroupNorm-compatible C")
     B, C = x.shape[0], x.shape[1]
-    stats = torch.empty(GNSTAT_WORDS * B * groups, dtype=torch.int64, device=x.device)
+    stats = _stats_records(GNSTAT_WORDS * B * groups, x.device)
     with torch.cuda.device(x.device):
         _check(lib().gn_stats_f32(x.data_ptr(), _ptr(pre_bias), B, C, x.shape[2] * x.shape[3], groups, stats.data_ptr(),
                                   _stream()), "gn_stats_f32")
@@ -516,7 +579,7 @@ def wino_conv3x3(x, U, gn=None, residual=None, bias=None, stats_groups: int = 0,
             if (residual is not None and (image_layout(residual) != 1 or tuple(residual.shape) != tuple(y.shape))) \
                     or not gn_nhwc_ok(cout, stats_groups):
                 raise GqHipError("fused Winograd tail needs a channels_last residual of the output shape and a GroupNorm-compatible C")
-            stats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device)
+            stats = _stats_records(GNSTAT_WORDS * B * stats_groups, x.device)
             _check(L.wino_out_res_nhwc_f32(M.data_ptr(), _ptr(residual), _ptr(bias), y.data_ptr(), stats.data_ptr(),
                                            B, H, W, cout, stats_groups, t, float(mscale), _stream()), "wino_out_res_nhwc_f32")
             return y, stats
@@ -633,7 +696,7 @@ def conv3x3_direct(x, wf, u_scale: float, x_bound: float, gn, residual=None, bia
     L = lib()
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
+        ostats = _stats_records(GNSTAT_WORDS * B * stats_groups, x.device) if stats_groups else None
         mscale = 1.0 / (v_scale * u_scale)
         gamma, beta, groups, eps, silu, stats, pre_bias = gn
         _check(L.conv3x3_gn_f16x3(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(pre_bias), stats.data_ptr(),
@@ -667,7 +730,7 @@ def conv1x1_direct(x, wf, u_scale: float, scale, residual=None, bias=None, stats
         sdev, mscale = None, float(post_scale) / (v_scale * u_scale)
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
+        ostats = _stats_records(GNSTAT_WORDS * B * stats_groups, x.device) if stats_groups else None
         _check(lib().conv1x1_f16x3(x.data_ptr(), _ptr(pre_bias), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), _ptr(residual),
                                    y.data_ptr(), _ptr(ostats), B, H * W, C, cout, max(stats_groups, 1), _stream()),
                "conv1x1_f16x3")
@@ -715,7 +778,7 @@ def conv3x3s2_direct(x, wf, u_scale: float, scale, bias=None, stats_groups: int 
         sdev, mscale = None, 1.0 / (v_scale * u_scale)
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
+        ostats = _stats_records(GNSTAT_WORDS * B * stats_groups, x.device) if stats_groups else None
         _check(lib().conv3x3s2_f16x3(x.data_ptr(), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), y.data_ptr(),
                                      _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1), _stream()), "conv3x3s2_f16x3")
     return (y, ostats) if stats_groups else y
@@ -755,7 +818,7 @@ def upconv2x_direct(x, wf, u_scale: float, scale, bias=None, stats_groups: int =
         sdev, mscale = None, 1.0 / (v_scale * u_scale)
     with torch.cuda.device(x.device):
         y = torch.empty((B, cout, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(GNSTAT_WORDS * B * stats_groups, dtype=torch.int64, device=x.device) if stats_groups else None
+        ostats = _stats_records(GNSTAT_WORDS * B * stats_groups, x.device) if stats_groups else None
         _check(lib().upconv2x_f16x3(x.data_ptr(), wf.data_ptr(), sdev, float(v_scale), float(mscale), _ptr(bias), y.data_ptr(),
                                     _ptr(ostats), B, H, W, C, cout, max(stats_groups, 1), _stream()), "upconv2x_f16x3")
     return (y, ostats) if stats_groups else y
@@ -857,7 +920,7 @@ def conv3x3_cin_small(x, wk, bias=None, stats_groups: int = 0):
         raise GqHipError(f"conv3x3_cin_small: shape {tuple(x.shape)} is not tiled by the kernel")
     with torch.cuda.device(x.device):
         y = torch.empty((B, 128, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        ostats = torch.empty(GNSTAT_WORDS * B * 32, dtype=torch.int64, device=x.device) if stats_groups else None
+        ostats = _stats_records(GNSTAT_WORDS * B * 32, x.device) if stats_groups else None
         _check(lib().conv3x3_cin_small_f32(x.data_ptr(), wk.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(ostats), B, H, W, C, 128,
                                            32, _stream()), "conv3x3_cin_small_f32")
     return (y, ostats) if stats_groups else y

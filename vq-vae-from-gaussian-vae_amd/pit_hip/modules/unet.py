@@ -408,11 +408,26 @@ class _WeightGuard:
         return any(m and v == bv for m, v, bv in zip(moved, self.versions, base_v))
 
 
-def _guarded(module: nn.Module, run, x: torch.Tensor):
+def _with_stats_arena(module: nn.Module, run, x: torch.Tensor):
+    """run(x) with every GroupNorm statistics record of the forward carved out of the module's arena (one fill per forward instead
+    of one small memset launch per producing kernel: _lib.StatsArena)."""
+    if not (STATS_ARENA and FUSED_GN and x.is_cuda and not torch.is_grad_enabled()):
+        return run(x)
+    from .. import _lib
+
+    arena = module.__dict__.get("_gq_stats_arena")
+    if arena is None:
+        arena = module.__dict__["_gq_stats_arena"] = _lib.StatsArena()
+    with _lib.stats_arena(arena, x.device):
+        return run(x)
+
+
+def _guarded(module: nn.Module, run0, x: torch.Tensor):
     """run(x) with the module's weight caches verified against the parameters' bytes (see _WeightGuard).  Costs one host wait per
     forward (for a copy queued at the forward's start: the host stays at most one module ahead of the device).  A caller that
     never writes parameters through ``.data`` and wants a fully asynchronous forward opts out per module:
     ``encoder.weight_guard = False`` (or process-wide: GQHIP_WEIGHT_GUARD=0)."""
+    run = lambda t: _with_stats_arena(module, run0, t)
     if not (WEIGHT_GUARD and getattr(module, "weight_guard", True) and x.is_cuda and not torch.is_grad_enabled()
             and not torch.cuda.is_current_stream_capturing()):
         return run(x)
@@ -512,6 +527,7 @@ WINOGRAD_ENCODER = True
 DIRECT_UPCONV = True
 FUSED_QKV = True         # attention: q, k, v as one GEMM with fused biases (channels_last)
 FUSED_ADD_STATS = True   # residual add also produces the next GroupNorm's statistics (channels_last only)
+STATS_ARENA = True       # the statistics records of a forward from one arena zeroed by one fill (not ~60 memset launches per step)
 CONV_IN_SMALL = True     # the encoder's conv_in (3 -> 128) on libgqhip's fixed-order fp32 kernel (+ bias + statistics), not MIOpen
 GN_GROUPS = 32     # unet.py:54-57: every Normalize is GroupNorm(32, C, eps=1e-6)
 DEFER_BIAS = True

@@ -58,7 +58,7 @@ def _randn_off_the_critical_path(shape, device):
     runs beside whatever the device is still doing (the encoder) instead of in front of the quantiser's first launch.  Same
     generator, same values (the Philox offset advances on the host in call order).  The main stream waits for the draw's event and
     the tensor is recorded on it, so the caching allocator keeps the memory until the main stream is done with it."""
-    if torch.cuda.is_current_stream_capturing():
+    if device.type != "cuda" or torch.cuda.is_current_stream_capturing():   # (a CPU tensor: _lib refuses it right after -- no CPU fallback)
         return torch.randn(shape, dtype=torch.float32, device=device)
     main = torch.cuda.current_stream(device)
     side = _SIDE_STREAMS.get(device)
