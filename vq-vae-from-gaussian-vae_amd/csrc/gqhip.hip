@@ -117,13 +117,15 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   // insert (12 VALU) runs once per GT tiles, and VALU issue is what those loops are short of (measured at config 2 with the
   // split-bf16 filter: GT 1 162 us, 2 157, 4 153; GT 8: filter -2 us, re-rank +14 us); the re-rank's fp32 pre-filter makes their
   // 16 GT codes cheap to go through.
+  // dim 4 keeps the packed split-bf16 filter: 65 536 codes are dense in 4-d -- 3.5 candidate groups per row inside the fp16
+  // margin and a quarter of the rows undecided (measured, profiles/r03) -- and its kernel is not MFMA-bound in the first place
+  pl.f16 = pl.bf16 && want_f16_filter() && pl.waves == 8 && dim != 4;
   pl.gt = pl.bf16 ? 4 : (dim <= 8 ? 4 : 2);
+  // (Measured in round 4 and not kept: groups of 8 tiles at dim 8, where the tracker's 12 VALU per group weigh twice what they do at
+  // dim 16 -- filter 78.9 -> 75.1 us, but the re-rank's 128-code candidates give it back: whole call 128.4 -> 130.2 us.)
   pl.tiles_per_split = (pl.tiles_per_split + pl.gt - 1) / pl.gt * pl.gt;   // a tile group never straddles two splits
   pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   pl.mixed = pl.bf16 && want_mixed_filter() && dim == 16 && pl.waves == 8 && pl.ct == 16 && pl.gt == 4;
-  // dim 4 keeps the packed split-bf16 filter: 65 536 codes are dense in 4-d -- 3.5 candidate groups per row inside the fp16
-  // margin and a quarter of the rows undecided (measured, profiles/r03) -- and its kernel is not MFMA-bound in the first place
-  pl.f16 = pl.bf16 && want_f16_filter() && pl.waves == 8 && pl.gt == 4 && dim != 4;
   if (pl.f16) pl.ct = dim == 32 ? 8 : 16;   // one 16-byte vector per MFMA, lane and tile: 16-tile chunks are 16 / 32 KiB
   if ((pl.mixed || pl.f16) && pl.nsplit > kMaxSplit / 2) {
     // the fp16 + fp8 filter leaves one record per lane half: 2 nsplit record sets for the re-rank (<= kMaxSplit)
@@ -255,13 +257,14 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
   const dim3 fblock((unsigned)(64 * pl.waves));
   ProfScope prof;
   if (pl.f16) {
-#define GQ_LAUNCH_F16(NV, R, C)                                                                                      \
+#define GQ_LAUNCH_F16G(NV, R, C, G)                                                                                  \
   do {                                                                                                             \
     if (prof.on)                                                                                                   \
-      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2>), grid, fblock, 0, st, prof.a, prof.b, 0, fp); \
+      hipExtLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, G, 8, 2>), grid, fblock, 0, st, prof.a, prof.b, 0, fp); \
     else                                                                                                           \
-      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, 4, 8, 2>), grid, fblock, 0, st, fp);                      \
+      hipLaunchKernelGGL((gq_filter_bf16_kernel<NV, R, C, G, 8, 2>), grid, fblock, 0, st, fp);                      \
   } while (0)
+#define GQ_LAUNCH_F16(NV, R, C) GQ_LAUNCH_F16G(NV, R, C, 4)
     switch (dim * 10 + pl.rt) {
       case 81: GQ_LAUNCH_F16(1, 1, 16); break;
       case 82: GQ_LAUNCH_F16(1, 2, 16); break;
@@ -272,6 +275,7 @@ int launch_filter_bf16(const Plan &pl, const FilterBfParams &fp, int dim, bool m
       default: return GQHIP_ERR_INVALID_ARG;
     }
 #undef GQ_LAUNCH_F16
+#undef GQ_LAUNCH_F16G
     return check_launch();
   }
 #define GQ_LAUNCH_BF1(NV, R, C, G, W)                                                                       \

@@ -50,27 +50,6 @@ def _kl_bits(mu: torch.Tensor, var: torch.Tensor, logvar: torch.Tensor) -> torch
     return 1.4426 * 0.5 * (torch.pow(mu, 2) + var - 1.0 - logvar)
 
 
-_SIDE_STREAMS = {}
-
-
-def _randn_off_the_critical_path(shape, device):
-    """One torch.randn draw for zhat_noquant (gaussian.py:121 draws it in eval too) on a side stream: it depends on nothing, so it
-    runs beside whatever the device is still doing (the encoder) instead of in front of the quantiser's first launch.  Same
-    generator, same values (the Philox offset advances on the host in call order).  The main stream waits for the draw's event and
-    the tensor is recorded on it, so the caching allocator keeps the memory until the main stream is done with it."""
-    if device.type != "cuda" or torch.cuda.is_current_stream_capturing():   # (a CPU tensor: _lib refuses it right after -- no CPU fallback)
-        return torch.randn(shape, dtype=torch.float32, device=device)
-    main = torch.cuda.current_stream(device)
-    side = _SIDE_STREAMS.get(device)
-    if side is None:
-        side = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    with torch.cuda.stream(side):
-        noise = torch.randn(shape, dtype=torch.float32, device=device)
-    main.wait_stream(side)
-    noise.record_stream(main)
-    return noise
-
-
 class _GaussianQuantBase(nn.Module):
     def _setup(self, n_samples: int, dim: int, seed: int, beta: float, backend: str,
                logvar_range: Sequence[float], tolerance: float, lam_factor: float, lam_range) -> None:
@@ -144,7 +123,7 @@ class GaussianQuantRegularizer(_GaussianQuantBase):
             if not z.is_contiguous() and z.is_contiguous(memory_format=torch.channels_last):
                 zmem = z.permute(0, 2, 3, 1).reshape(b, h * w, c2)   # a view of the same memory
                 # one draw of the size of mu (advances the generator like gaussian.py:121)
-                noise = _randn_off_the_critical_path((b, h * w, c2 // 2), z.device)
+                noise = torch.randn((b, h * w, c2 // 2), dtype=torch.float32, device=z.device)
                 ind, zhat, noq = _lib.gq_quantize_z(zmem, self.prior_samples, self.group, "blc", _lib.GQHIP_GROUP_STRIDED,
                                                     self.logvar_range, self.beta, self._ws, noise=noise)
                 as_bchw = lambda t: t.view(b, h, w, -1).permute(0, 3, 1, 2)   # logical [B, C, h, w], NHWC memory
@@ -152,7 +131,7 @@ class GaussianQuantRegularizer(_GaussianQuantBase):
         else:
             b, l, c2 = z.shape
             shape_n = (b, l, c2 // 2)
-        noise = _randn_off_the_critical_path(shape_n, z.device)
+        noise = torch.randn(shape_n, dtype=torch.float32, device=z.device)
         indices, zhat, zhat_noquant = _lib.gq_quantize_z(z, self.prior_samples, self.group, self.format,
                                                          _lib.GQHIP_GROUP_STRIDED, self.logvar_range, self.beta,
                                                          self._ws, noise=noise)
