@@ -229,3 +229,72 @@ def test_statistics_arena_changes_no_bit_and_survives_reentry():
     for (z1, r1, s1), (z2, r2, s2) in zip(outs[True][0], outs[True][1]):
         assert torch.equal(z1, z2) and torch.equal(r1, r2)
     assert enc.__dict__["_gq_stats_arena"].buf is not None and enc.__dict__["_gq_stats_arena"].used > 0
+
+
+# ------------------------------------------------------------------------------------------ g16: the other quantiser shapes, trained-like z
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_g16_groupings_at_the_trained_operating_point_vs_reference_golden(channels_last):
+    """BASELINE configs[3] at realistic sigma: the trained-operating-point z of g15 through GaussianQuantRegularizer group 8 / 4
+    (strided channels, K = 2 / 4: pit/quantization/gaussian.py:122-123) and GaussianQuantRegularizer2 dim 16 / 8 (contiguous channels:
+    :273-287) on the device, against indices captured from the reference on CPU (tests/golden/make_golden_r4b.py).  Same gate as
+    every same-z golden: identical, or the reference's own top-2 gap below the libm difference of exp / log."""
+    from bench import GATES
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer, GaussianQuantRegularizer2
+
+    d = np.load(os.path.join(G, "g16_groupings_trained_like.npz"))
+    z = torch.from_numpy(d["z_enc"]).to(DEV)
+    if channels_last:
+        z = z.contiguous(memory_format=torch.channels_last)
+    for group in (8, 4):
+        reg = GaussianQuantRegularizer("bchw", 65536, group=group, backend="hip").eval().to(DEV)
+        zhat, info = reg(z)
+        got, want, gap = _rows(info["indices"].cpu().numpy()), _rows(d[f"gq_group{group}_indices"]), d[f"gq_group{group}_gap"]
+        diff = got != want
+        print(f"g16 GQ group {group} (channels_last={channels_last}): {int(diff.sum())} of {want.size} differ; smallest golden gap {float(gap.min()):.1e}")
+        assert diff.sum() == 0 or np.all(gap[diff] < GATES["same_z_gap"]), (group, int(diff.sum()), gap[diff])
+        assert torch.equal(reg.dequant(info["indices"]), zhat)
+    for dim in (16, 8):
+        reg2 = GaussianQuantRegularizer2(dim, 65536, backend="hip").eval().to(DEV)
+        _, info2 = reg2(z)
+        got, want, gap = _rows(info2["indices"].cpu().numpy()), _rows(d[f"gq2_dim{dim}_indices"]), d[f"gq2_dim{dim}_gap"]
+        diff = got != want
+        print(f"g16 GQ2 dim {dim} (channels_last={channels_last}): {int(diff.sum())} of {want.size} differ")
+        assert diff.sum() == 0 or np.all(gap[diff] < GATES["same_z_gap"]), (dim, int(diff.sum()), gap[diff])
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_g16_vq_behind_checkpoint_like_weights_vs_reference_golden(channels_last):
+    """BASELINE configs[4]'s quantiser behind realistic weights: the reference Encoder (double_z False) with checkpoint-like weights and
+    a calibrated conv_out -> VQQuantizer (vq.py:58-73) on CPU, against the GPU encoder + vq_argmin_f32."""
+    from bench import GATES
+    from pit_hip.models.autoencoder import AutoencodingEngine
+
+    d = np.load(os.path.join(G, "g16_vq_trained_like.npz"))
+    single = dict(FULL, double_z=False)
+    torch.manual_seed(1234)
+    vae = AutoencodingEngine(encoder_config={"target": "pit.modules.unet.Encoder", "params": single},
+                             decoder_config={"target": "pit.modules.unet.Decoder", "params": single},
+                             regularizer_config={"target": "pit.quantization.vq.VQQuantizer",
+                                                 "params": {"format": "bchw", "n": 65536, "dim": 16}}).eval()
+    checkpoint_like_(vae.encoder, 5)
+    apply_conv_out_calibration_(vae.encoder.conv_out, torch.from_numpy(d["conv_out_scale"]), torch.from_numpy(d["conv_out_shift"]))
+    g = torch.Generator().manual_seed(7)
+    vae.regularization.embedding.weight.data.copy_(torch.randn(65536, 16, generator=g))
+    vae = vae.to(DEV)
+    gx = torch.Generator().manual_seed(5256)
+    x = (torch.rand(1, 3, 256, 256, generator=gx) * 2 - 1).to(DEV)
+    if channels_last:
+        vae = vae.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        z_enc = vae.encode(x, unregularized=True)[0]
+        zq, ind = vae.quant(x)
+        _, info_g = vae.regularization(torch.from_numpy(d["z_enc"]).to(DEV))
+    dz = float((z_enc.float().cpu() - torch.from_numpy(d["z_enc"])).abs().max())
+    want, gap = _rows(d["indices"]), d["gap"]
+    diff = _rows(ind.cpu().numpy()) != want
+    diff_g = _rows(info_g["indices"].cpu().numpy()) != want
+    print(f"g16 vq (channels_last={channels_last}): |dz| {dz:.2e}, {int(diff.sum())} of 1024 differ end to end, {int(diff_g.sum())} on the golden z")
+    assert dz <= GATES["z_enc_max_abs"]
+    assert diff.sum() <= GATES["indices_differing_per_1024"] and np.all(gap[diff] < GATES["near_tie_gap"])
+    assert diff_g.sum() == 0 or np.all(gap[diff_g] < GATES["same_z_gap"])
