@@ -698,14 +698,14 @@ def main():
                             "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": prov}
             peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
             roofline["whole_call"] = {
-                "what": "algorithmic flops / time of the WHOLE quantiser call (prep + filter + re-rank + tail + the module's "
-                        "torch ops), i.e. what a caller gets",
+                "what": "algorithmic flops / time of the WHOLE quantiser call (prep + filter + re-rank: three launches, + the "
+                        "module's torch ops), i.e. what a caller gets",
                 "in_step_ms": stages["quantiser"], "achieved": round(whole, 2), "frac": round(whole / peak, 4),
                 "back_to_back_us": round(call_us, 1), "back_to_back_achieved": round(whole_b2b, 2),
                 "back_to_back_frac": round(whole_b2b / peak, 4)}
-            # HBM traffic of the WHOLE call: the four launches' PMC bytes summed (same committed passes as `traffic`)
+            # HBM traffic of the WHOLE call: the three launches' PMC bytes summed (same committed passes as `traffic`)
             parts = {}
-            for kn in ("gq_prep_kernel", kname, "gq_rerank_kernel", "gq_tail_kernel"):
+            for kn in ("gq_prep_kernel", kname, "gq_rerank_kernel"):      # the call's three launches
                 tb, _ = pmc_traffic(kn)
                 parts[kn] = tb
             alg_bytes = rows * (2 * dim * 4 + 8 + dim * 4) + 4 * dim * N_CODES     # rows in / index + zhat out + codebook once
@@ -713,8 +713,10 @@ def main():
                 tot = sum(parts.values())
                 roofline["whole_call_traffic"] = {"bytes": tot, "per_kernel": parts, "algorithmic_bytes": alg_bytes,
                                                   "ratio": round(tot / alg_bytes, 2),
-                                                  "note": "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, summed over the call's four "
-                                                          "launches; algorithmic = SURVEY 8(d)'s fused figure"}
+                                                  "note": "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, summed over the call's three "
+                                                          "launches (prep, filter, re-rank); algorithmic = SURVEY 8(d)'s fused figure; the "
+                                                          "x2 on FETCH_SIZE is calibrated for wide streaming reads only -- the re-rank's "
+                                                          "fetches are gathers"}
             else:
                 roofline["whole_call_traffic"] = None
             roofline.update({"launches": launches, "avg_launch_us": round(avg_ms * 1e3, 2),

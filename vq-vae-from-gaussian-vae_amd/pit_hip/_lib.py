@@ -8,6 +8,7 @@ tensor is not on a HIP device the call raises.
 from __future__ import annotations
 
 import ctypes
+import threading
 import math
 import os
 import subprocess
@@ -379,7 +380,12 @@ class StatsArena:
         return t
 
 
-_ARENA = {"active": None, "flag": 0}
+class _ArenaState(threading.local):      # per thread, like the library's flag (gqhip_stats_prezeroed is thread-local)
+    def __init__(self) -> None:
+        self.state = {"active": None, "flag": 0}
+
+
+_ARENA_TLS = _ArenaState()
 
 
 class stats_arena:
@@ -389,25 +395,25 @@ class stats_arena:
         self.arena, self.device = arena, device
 
     def __enter__(self):
-        self.prev = _ARENA["active"]
+        self.prev = _ARENA_TLS.state["active"]
         self.arena.begin(self.device)
-        _ARENA["active"] = self.arena
+        _ARENA_TLS.state["active"] = self.arena
         return self.arena
 
     def __exit__(self, *exc):
-        _ARENA["active"] = self.prev
+        _ARENA_TLS.state["active"] = self.prev
         _set_prezeroed(0)
 
 
 def _set_prezeroed(on: int) -> None:
-    if _ARENA["flag"] != on:
+    if _ARENA_TLS.state["flag"] != on:
         lib().gqhip_stats_prezeroed(on)
-        _ARENA["flag"] = on
+        _ARENA_TLS.state["flag"] = on
 
 
 def _stats_records(nwords: int, device):
     """An int64 tensor for ``nwords`` words of statistics records; tells the library whether it is already zero."""
-    a = _ARENA["active"]
+    a = _ARENA_TLS.state["active"]
     t = a.take(nwords) if a is not None else None
     if t is not None and t.device == device:
         _set_prezeroed(1)
