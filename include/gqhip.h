@@ -114,9 +114,9 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
  * logsd_or_null: log(sd) as the caller computed it; NULL -> the kernel uses
  *           float(log(double(sd))) (correctly rounded).
  * dim: any 1..64 (4, 8, 16, 32 run on the MFMA filter; others exhaustive).
- * Four launches on `stream` for the MFMA dims: prep (operand images, bound sums,
- * max|cb|) -> filter -> exact re-rank -> tail (undecided rows; returns at once
- * when there are none). */
+ * Three launches on `stream` for the MFMA dims: prep (operand images, bound sums,
+ * max|cb|) -> filter -> exact re-rank (rows the filter leaves undecided are
+ * finished inside it by a block-wide scan of their record sets). */
 int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null,
                   const float *cb, int64_t *idx, float *zhat_or_null,
                   int64_t dim, int64_t rows, int64_t n, double beta,

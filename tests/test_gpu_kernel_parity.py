@@ -211,8 +211,8 @@ def test_reference_smoke_loop_shape_max_size(filter_kind):
     lsd = np.log(sd.numpy()[sel].astype(np.float64)).astype(np.float32)
     oi, _ = O.argmax_rows(mu.numpy()[sel], sd.numpy()[sel], noise.numpy(), 1.0, logstd=lsd)
     assert np.array_equal(idx.cpu().numpy()[sel], oi)
-    # abs(randn) sigmas (tiny ones included): ~3 % of the rows need the fp64 second stage behind the fp32 filter;
-    # the split-bf16 filter's wider margin sends more of these ill-conditioned rows there (still exact)
+    # abs(randn) sigmas (tiny ones included): ~3 % of the rows are left undecided by the fp32 filter (finished by the in-block fp64 scan);
+    # the wider margins of the 16-bit filters leave more of these ill-conditioned rows undecided (still exact)
     assert fb < (rows // 10 if filter_kind == "fp32" else rows // 2), f"fallback rows {fb}"
     # compat op on the first 64 rows: same arg-max wherever the top-2 gap is not a rounding tie
     out = torch.zeros(64, n, device=dev)

@@ -1,5 +1,5 @@
 """-m gpu: randomized / adversarial parity sweep of the fused arg-max against the oracle.
-Stresses the exactness machinery (fp32 margin, candidate tracking, fp64 second stage, partial
+Stresses the exactness machinery (rounding margins, candidate records, in-block fp64 scan of undecided rows, partial
 tiles, code splits) with heavy-tailed sigmas, large means, odd sizes and several betas."""
 import os
 

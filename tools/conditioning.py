@@ -1,4 +1,4 @@
-"""Quantiser call time, second-stage rows and candidates per row for three kinds of encoder output (random z,
+"""Quantiser call time, undecided rows and candidates per row for three kinds of encoder output (random z,
 trained-model-like, tiny z of a random-init encoder) with both filter kernels."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,5 +35,5 @@ for name, z in (("randn z", torch.randn(16, 32, 32, 32, generator=g)),
         fb, rr = _lib.debug_counters(ws)
         _lib.debug_enable(False)
         t = timed(lambda: _lib.gq_quantize_z(z, cb, 16, "bchw", _lib.GQHIP_GROUP_STRIDED, (-30.0, 20.0), 1.0, ws=ws))
-        print(f"{name:32s} filter={filt:5s}: {t:.3f} ms, second-stage rows {fb}, candidates/row {rr/16384:.3f}")
+        print(f"{name:32s} filter={filt:5s}: {t:.3f} ms, undecided rows (in-block scan) {fb}, candidates/row {rr/16384:.3f}")
 _lib.set_filter("auto")

@@ -53,7 +53,7 @@ _lib.gq_quantize_z(zz, cb, 16, "bchw", 0, ws=ws)
 torch.cuda.synchronize()
 fb, rr = _lib.debug_counters(ws)
 _lib.debug_enable(False)
-print(f"gq_quantize_z bs16 256^2 (prep+split+filter+rerank+second stage): {t:.3f} ms; second-stage rows {fb}, candidates/row {rr / 16384:.3f}")
+print(f"gq_quantize_z bs16 256^2 (prep + filter + re-rank): {t:.3f} ms; undecided rows (in-block scan) {fb}, candidates/row {rr / 16384:.3f}")
 idx, _ = _lib.gq_quantize_z(zz, cb, 16, "bchw", 0, ws=ws)
 t = timed(lambda: _lib.gq_dequant(idx, cb, 16, "bchw", 0))
 print(f"gq_dequant bs16: {t * 1e3:.1f} us")

@@ -18,4 +18,4 @@ for filt in ("auto", "fp32"):
     for _ in range(5):
         _lib.gq_argmax(mu, sd, noise, 1.0, ws=ws)
     torch.cuda.synchronize()
-    print(f"smoke-loop shape ({rows} rows, sd=|randn|) filter={filt}: {(time.perf_counter()-t0)/5*1e3:.2f} ms, second-stage rows {fb} ({100*fb/rows:.1f} %), candidates/row {rr/rows:.2f}")
+    print(f"smoke-loop shape ({rows} rows, sd=|randn|) filter={filt}: {(time.perf_counter()-t0)/5*1e3:.2f} ms, undecided rows (in-block scan) {fb} ({100*fb/rows:.1f} %), candidates/row {rr/rows:.2f}")

@@ -42,7 +42,7 @@ struct FilterBfParams {
 };
 
 // round-to-nearest-even fp32 -> bf16 (as the upper 16 bits); finite inputs (non-finite rows / codebooks never
-// reach a decision through the filter: the re-rank routes them to the second stage by their bound).
+// reach a decision through the filter: their bound is not finite and the re-rank scans every code for them).
 __device__ __forceinline__ unsigned bf16_rne(float f) {
   const unsigned x = __float_as_uint(f);
   return (x + 0x7fffu + ((x >> 16) & 1u)) >> 16;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     int j1 = i1[rt] * 2 + h, j2 = i2[rt] * 2 + h, j3 = i3[rt] * 2 + h;   // half-group ids
     if constexpr (MIXED || F16) {
       // One record per LANE HALF (the re-rank sees 2 nsplit "splits"): the wider margin of these filters makes "a fourth
-      // group of one record within the margin" -- an undecided row: ~12 us of fp64 second stage for a lone row -- about
+      // group of one record within the margin" -- an undecided row: a block-wide scan of its record sets in the re-rank -- about
       // as likely as not per call with merged records (1 row in 16 384 at config 2); half the codes per record makes it
       // ~8x rarer, and the merge below is not needed.
       const int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;

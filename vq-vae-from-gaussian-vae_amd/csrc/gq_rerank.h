@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256, DIM >= 32 ? 2 : 4) void gq_rerank_kernel(const
 
 // Exhaustive exact arg-max of rows list[first], list[first + stride], ... (list == NULL: the rows themselves): one
 // block per row, every code scored in the reference's operation order.  Depends on nothing but the row operands and
-// the codebook, so it is also what the tail kernel falls back to when a grid barrier fails.
+// the codebook (dims without an MFMA filter run on it).
 template <int MODE>
 __device__ __forceinline__ void exhaustive_rows(const RerankParams &p, const int *list, int count, int first, int stride) {
   __shared__ double sh_s[256];
