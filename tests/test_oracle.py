@@ -63,6 +63,18 @@ def test_g3_module_boundary_known_answers(name):
     assert np.array_equal(O.gq1_dequant(ind, cb, 16), zhat)  # dequant round trip
 
 
+@pytest.mark.parametrize("name", ["g15_e2e_trained_like", "g17_e2e_nonsquare_trained_like"])
+def test_trained_operating_point_goldens_pin_the_oracle(name):
+    """The end-to-end goldens of round 4 (reference Encoder -> GaussianQuantRegularizer -> Decoder on CPU, checkpoint-like weights,
+    z at ~17.8 bits per group; g17: three 192x320 images): the oracle's module forward on the golden z gives the reference's
+    indices (pit/quantization/gaussian.py:62-81,142-150), and the stored top-2 gaps are the oracle's."""
+    d = load(name + ".npz")
+    cb = O.codebook(65536, 16, 42)
+    zhat, ind = O.gq1_forward(d["z_enc"], cb, 16)
+    assert np.array_equal(ind, d["indices"])
+    assert float(d["gap"].min()) > 0.0 and d["gap"].size == d["indices"].size
+
+
 def test_g4_layouts():
     cb4, cb8 = O.codebook(2048, 4, 42), O.codebook(2048, 8, 42)
     for name, cb, group in (("g4_gq1_group4", cb4, 4), ("g4_gq1_group8", cb8, 8)):
