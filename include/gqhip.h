@@ -83,7 +83,9 @@ int gqhip_get_filter(void);
 
 /* Diagnostics: launch plan and workspace layout of the fused arg-max for a shape.  out8 = { byte offset of the
  * candidate records, code splits, tiles per candidate group, tiles per split, filter kernel the plan selects (0 fp32 MFMA, 1 split-bf16, 2 fp16 + fp8, 3 fp16 main product: the default at dims 8 / 16 / 32), coefficient of the
- * filter error bound (E_f = coeff * 2^-24 * T), row tiles per wave, waves per filter block }. */
+ * filter error bound (E_f = coeff * 2^-24 * T), row tiles per wave, waves per filter block }.
+ * The records are 16 bytes per (row, record set): { fp32 m1; fp16 gaps m1 - m2..m4, rounded towards zero; three 16-bit
+ * half-group ids relative to the set's split } (csrc/gq_common.h:Rec); "code splits" counts record sets. */
 int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8);
 
 

@@ -97,3 +97,39 @@ def test_f16_bound_restatement_matches_the_study_on_trained_like_rows():
     assert t1 < 0.6 and t3 < 0.6
     worst_case = 2.0 * (M.K_F16 * M.U * r["T_old"] + r["E_abs"])          # what Ea + Eb would be under the worst-case T alone
     assert np.median(r["Ea"] + r["Eb"]) < 0.25 * np.median(worst_case)
+
+
+def _rec_gap(m1, mk):
+    """numpy restatement of csrc/gq_common.h:rec_gap -- fp32 difference, x (1 - 2^-22) in fp32, fp16 towards zero; -inf -> +inf."""
+    m1, mk = np.asarray(m1, np.float32), np.asarray(mk, np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        g = ((m1 - mk).astype(np.float32) * np.float32(0.99999976158142090)).astype(np.float32)
+        h = g.astype(np.float16)                                          # round to nearest ...
+        up = h.astype(np.float32) > g                                     # ... then one step back where that went up
+        h = np.where(up, np.nextafter(h, np.float16(0.0)), h).astype(np.float16)
+    h = np.where(np.isfinite(g) & ~np.isfinite(h), np.float16(65504.0), h)   # finite never rounds to inf towards zero
+    return np.where(mk > -np.inf, h, np.float16(np.inf))
+
+
+def test_record_gap_encoding_never_reads_below_the_filters_value():
+    """The candidate records carry m2..m4 as fp16 gaps below m1 (16-byte records).  Whatever the pair, the value the re-rank
+    reconstructs, fp64(m1) - fp64(gap), is >= mk (a group is never missed) and above it by at most the gap's fp16 resolution."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    m1 = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n)).astype(np.float32)
+    gaps = [rng.random(n) * 10.0 ** rng.integers(-9, 6, n),                    # anything from far below an ulp to overflow
+            M._tie_values(rng, (n,), -20, 14).astype(np.float64) * rng.choice([1.0, 1 + 2.0 ** -10, 1 - 2.0 ** -11], n),   # fp16 ties / exact values
+            np.abs(m1) * 2.0 ** -24 * rng.integers(0, 4, n),                   # a few fp32 ulps of m1
+            np.zeros(n)]
+    for gtrue in gaps:
+        mk = (m1.astype(np.float64) - np.abs(gtrue)).astype(np.float32)
+        mk = np.minimum(mk, m1)
+        h = _rec_gap(m1, mk)
+        rec = m1.astype(np.float64) - h.astype(np.float64)
+        real_gap = m1.astype(np.float64) - mk.astype(np.float64)
+        assert (rec >= mk.astype(np.float64)).all()
+        fits = real_gap <= 65504.0                                             # larger gaps read as 65504 (still above mk)
+        assert ((rec - mk)[fits] <= (real_gap * 2.0 ** -10 + 2.0 ** -24 + real_gap * 2.0 ** -21)[fits]).all()
+        assert (h.astype(np.float64)[real_gap > 65600.0] == 65504.0).all()
+    none = _rec_gap(m1, np.full(n, -np.inf, np.float32))
+    assert np.isinf(none).all() and ((m1.astype(np.float64) - none.astype(np.float64)) == -np.inf).all()

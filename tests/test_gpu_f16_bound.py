@@ -24,14 +24,17 @@ def filter_kind(request):
 
 
 def _records_within_bound(ws, rows, n, dim, A, B, rs, cb, beta, mode):
-    """max over (split, row) of |m1 - max_group f| / max_group E(j), E(j) = k u T_j + E_abs (the charged coefficient)."""
+    """max over (set, row) of |m1 - max_group f| / max_group E(j), E(j) = k u T_j + E_abs (the charged coefficient).  The second
+    and third values of a record travel as fp16 gaps below m1, rounded towards zero (csrc/gq_common.h:Rec): what the re-rank
+    reconstructs must never be BELOW the filter's value -- checked here against the group's true maximum minus the same bound --
+    and not above it by more than the gap's fp16 resolution."""
     from pit_hip import _lib
 
     pl = _lib.debug_plan(rows, n, dim)
     assert pl["bf16"] == 3, pl
     m, ids = _lib.debug_records(ws, rows, n, dim)
-    m1 = m[..., 0].cpu().numpy().astype(np.float64)
-    id1 = ids[..., 0].cpu().numpy()
+    m = m.cpu().numpy().astype(np.float64)
+    ids = ids.cpu().numpy()
     r = M.analyse(A, B, rs, cb, beta, mode)
     E = M.K_F16 * M.U * r["T_j"] + r["E_abs"][:, None]
     gt = pl["gt"]
@@ -39,16 +42,27 @@ def _records_within_bound(ws, rows, n, dim, A, B, rs, cb, beta, mode):
     worst = 0.0
     ar = np.arange(rows)
     for s in range(pl["nsplit"]):
-        ok_rec = np.isfinite(m1[s]) & (m1[s] > -np.inf)
-        gid = id1[s]
-        tile = (gid >> 1)[:, None] * gt + (q >> 4)[None, :]
-        code = tile * 32 + (q & 3)[None, :] + 8 * ((q & 15) >> 2)[None, :] + 4 * (gid & 1)[:, None]
-        inside = code < n
-        cc = np.minimum(code, n - 1)
-        fg = np.where(inside, r["f"][ar[:, None], cc], -np.inf).max(1)
-        Eg = np.where(inside, E[ar[:, None], cc], 0.0).max(1)
-        ratio = np.abs(m1[s] - fg) / np.maximum(Eg, 1e-300)
-        worst = max(worst, float(ratio[ok_rec & np.isfinite(fg)].max(initial=0.0)))
+        for k in range(3):
+            mk = m[s, :, k]
+            ok_rec = np.isfinite(mk)
+            gid = ids[s, :, k]
+            tile = (gid >> 1)[:, None] * gt + (q >> 4)[None, :]
+            code = tile * 32 + (q & 3)[None, :] + 8 * ((q & 15) >> 2)[None, :] + 4 * (gid & 1)[:, None]
+            inside = code < n
+            cc = np.minimum(code, n - 1)
+            fg = np.where(inside, r["f"][ar[:, None], cc], -np.inf).max(1)
+            Eg = np.where(inside, E[ar[:, None], cc], 0.0).max(1)
+            sel = ok_rec & np.isfinite(fg)
+            if k == 0:
+                ratio = np.abs(mk - fg) / np.maximum(Eg, 1e-300)
+                worst = max(worst, float(ratio[sel].max(initial=0.0)))
+            else:
+                gap = m[s, :, 0] - mk
+                low = (fg - mk) / np.maximum(Eg, 1e-300)                   # <= 1: never below the filter's own value - bound
+                assert float(low[sel].max(initial=0.0)) <= 1.0, (s, k, float(low[sel].max()))
+                over = mk - fg - Eg - gap * 2.0 ** -9 - 2.0 ** -22 * np.abs(m[s, :, 0]) - 2.0 ** -24     # gap: fp16, 2^-24 floor
+                assert float(over[sel].max(initial=-1.0)) <= 0.0, (s, k, float(over[sel].max()))
+                assert (gap[ok_rec] >= 0).all()
     return worst
 
 

@@ -318,3 +318,53 @@ def test_g16_vq_behind_checkpoint_like_weights_vs_reference_golden(channels_last
     assert dz <= GATES["z_enc_max_abs"]
     assert diff.sum() <= GATES["indices_differing_per_1024"] and np.all(gap[diff] < GATES["near_tie_gap"])
     assert diff_g.sum() == 0 or np.all(gap[diff_g] < GATES["same_z_gap"])
+
+
+# ------------------------------------------------------------------------------------------ 16-bit split-relative ids in the records
+_BIG_N_SCRIPT = r"""
+import os, sys, json
+import numpy as np, torch
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "vq-vae-from-gaussian-vae_amd"))
+from pit_hip import _lib
+from oracle import gq_oracle as O
+dim, n, rows, filt = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+_lib.set_filter(filt)
+g = torch.Generator().manual_seed(dim + n)
+mu = 0.9 * torch.randn(rows, dim, generator=g)
+sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(rows, dim, generator=g)))
+cb = torch.randn(n, dim, generator=g)
+mu[: rows // 2] = cb[-(rows // 2):]      # winners in the LAST groups of the codebook: rows sitting on those codes, small sigma
+sd[: rows // 2] = 0.02
+dev = torch.device("cuda:0")
+ws = _lib.Workspace()
+idx, _ = _lib.gq_argmax(mu.to(dev), sd.to(dev), cb.to(dev), 1.0, ws=ws)
+torch.cuda.synchronize()
+pl = _lib.debug_plan(rows, n, dim)
+sel = np.r_[0:8, rows - 8:rows]
+ref, _ = O.argmax_rows(mu.numpy()[sel], sd.numpy()[sel], cb.numpy(), 1.0)
+got = idx.cpu().numpy()[sel]
+print(json.dumps({"plan": pl, "equal": bool(np.array_equal(got, ref)), "max_index": int(got.max()), "n": n}))
+"""
+
+
+@pytest.mark.parametrize("dim,n,filt,sets", [(4, 4_400_000, "auto", 2), (8, 4_400_000, "auto", 4), (16, 2_300_000, "fp32", 2)])
+def test_codebooks_beyond_the_16_bit_id_range_of_one_split_get_more_splits(dim, n, filt, sets):
+    """The candidate records hold half-group ids relative to their split in 16 bits (csrc/gq_common.h:Rec): one split may cover at
+    most 2^20 GT codes.  GQHIP_NSPLIT=1 asks for ONE split over a codebook larger than that (4.4 M codes at GT 4, 2.3 M at GT 2):
+    the plan must raise the split count, the ids of the last groups (global id > 65535) must come back right, the indices are the
+    oracle's.  (Own process: the environment switch is read once per process.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GQHIP_NSPLIT="1")
+    out = subprocess.run([sys.executable, "-c", _BIG_N_SCRIPT, root, str(dim), str(n), "512", filt], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    pl = res["plan"]
+    print(res)
+    assert pl["nsplit"] == sets and 2 * pl["tiles_per_split"] // pl["gt"] <= 65536
+    assert res["equal"] and res["max_index"] > n - 4096

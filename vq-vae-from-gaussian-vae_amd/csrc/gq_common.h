@@ -17,16 +17,51 @@ constexpr int kMaxDim = 64;
 // float32(log(sqrt(2*pi))): torch casts the python scalar to the tensor dtype.
 __device__ __host__ constexpr float half_log_2pi() { return 0.91893853320467274178f; }
 
-// One candidate record per (row, code split), produced by the filter kernel.
-//   m1 >= m2 >= m3 >= m4 : the four largest half-group maxima of the filter score
-//   id1, id2, id3        : half-group ids ((tile / GT) * 2 + half) of m1, m2, m3; a half-group
-//                          is the GT x 16 codes one lane half sees in GT consecutive tiles
+// One candidate record per (row, record set), produced by the filter kernel: 16 bytes (round 4; 32 before -- the records are the
+// largest stream between the filter and the re-rank: 2 x 8.4 MB less HBM traffic per call at config 2).
+//   m1 >= m2 >= m3 >= m4 : the four largest half-group maxima of the filter score.  m1 is stored as it is; m2..m4 as the GAPS
+//                          m1 - mk in fp16, rounded TOWARDS ZERO after the fp32 difference was scaled by (1 - 2^-22) (it may have
+//                          been rounded up): the value the re-rank reconstructs, m1 - gap, is never BELOW the filter's mk, so a
+//                          group is never missed -- at worst one more is looked at.  Gaps below 2^-24 read as 0, above 65504 as
+//                          65504, "no group" (mk = -inf) as +inf.
+//   id1, id2, id3        : half-group ids of m1, m2, m3 RELATIVE to the record set's split: ((tile - t_begin) / GT) * 2 + half; a
+//                          half-group is the GT x 16 codes one lane half sees in GT consecutive tiles.  16 bits: the plan keeps
+//                          2 * tiles_per_split / GT <= 65536 (gqhip.hip:make_plan).
 // The fourth value only tells the re-rank whether a fourth group could matter (then the row is undecided).
-struct __attribute__((aligned(32))) Rec {
-  float m1, m2, m3, m4;
-  int id1, id2, id3;
-  int pad;
+struct __attribute__((aligned(16))) Rec {
+  float m1;
+  unsigned short d2, d3, d4;
+  unsigned short id1, id2, id3;
 };
+static_assert(sizeof(Rec) == 16, "one 16-byte store / load per record");
+
+__device__ __forceinline__ unsigned short rec_gap(float m1, float mk) {
+  if (!(mk > -__builtin_inff())) return (unsigned short)0x7c00u;          // no group (or NaN): +inf
+  const float g = (m1 - mk) * 0.99999976158142090f;                       // (1 - 2^-22)
+  return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(g, 0.0f)) & 0xffffu);
+}
+// base2 = 2 * (t_begin / GT): the first half-group id of the record set's split
+__device__ __forceinline__ Rec make_rec(float m1, float m2, float m3, float m4, int j1, int j2, int j3, int base2) {
+  const float NEG_INF = -__builtin_inff();
+  Rec r;
+  r.m1 = m1;
+  r.d2 = rec_gap(m1, m2); r.d3 = rec_gap(m1, m3); r.d4 = rec_gap(m1, m4);
+  r.id1 = (unsigned short)(m1 > NEG_INF ? j1 - base2 : 0);
+  r.id2 = (unsigned short)(m2 > NEG_INF ? j2 - base2 : 0);
+  r.id3 = (unsigned short)(m3 > NEG_INF ? j3 - base2 : 0);
+  return r;
+}
+__device__ __forceinline__ Rec empty_rec() {
+  Rec r;
+  r.m1 = -__builtin_inff();
+  r.d2 = r.d3 = r.d4 = (unsigned short)0x7c00u;
+  r.id1 = r.id2 = r.id3 = 0;
+  return r;
+}
+// the reconstructed k-th value (k = 2, 3, 4): exact in fp64 whenever the gap is not below an fp32 ulp of m1 (then it reads m1)
+__device__ __forceinline__ double rec_value(float m1, unsigned short gap) {
+  return (double)m1 - (double)(float)__builtin_bit_cast(_Float16, gap);
+}
 
 // Workspace header (first 4 KiB of the caller's workspace).  Everything in it is (re)written by the kernels of ONE
 // call: gq_prep_kernel resets the counters and writes the max|cb| partials, the re-rank reduces them per wave.

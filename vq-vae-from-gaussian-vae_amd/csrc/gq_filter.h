@@ -368,10 +368,7 @@ __device__ __forceinline__ void filter_block(const FilterParams &p, const int vb
     const int pos = rowblk * (128 * RT) + (wave * RT + rt) * 32 + c;
     if (h == 0 && pos < nrows) {
       const int row = pos;
-      Rec r;
-      r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.m4 = a4; r.id1 = j1; r.id2 = j2; r.id3 = j3;
-      r.pad = 0;
-      p.rec[(long)split * p.rows + row] = r;
+      p.rec[(long)split * p.rows + row] = make_rec(a1, a2v, a3, a4, j1, j2, j3, 2 * (t_begin / GT));
     }
   }
 }

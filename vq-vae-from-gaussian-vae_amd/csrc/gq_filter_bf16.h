@@ -433,10 +433,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
       const int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;
       if (row < p.rows) {
         const float rs = p.rowscale[row];      // back to true units: the row's coefficients were normalised by 2^-e_r
-        Rec r;
-        r.m1 = a1 * rs; r.m2 = a2v * rs; r.m3 = a3 * rs; r.m4 = a4 * rs; r.id1 = j1; r.id2 = j2; r.id3 = j3;
-        r.pad = 0;
-        p.rec[(long)(split * 2 + h) * p.rows + row] = r;
+        p.rec[(long)(split * 2 + h) * p.rows + row] = make_rec(a1 * rs, a2v * rs, a3 * rs, a4 * rs, j1, j2, j3, 2 * (t_begin / GT));
       }
       continue;
     }
@@ -461,10 +458,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void gq_filter_bf16
     }
     const int row = rowblk * (32 * WAVES * RT) + (wave * RT + rt) * 32 + c;
     if (h == 0 && row < p.rows) {
-      Rec r;
-      r.m1 = a1; r.m2 = a2v; r.m3 = a3; r.m4 = a4; r.id1 = j1; r.id2 = j2; r.id3 = j3;
-      r.pad = 0;
-      p.rec[(long)split * p.rows + row] = r;
+      p.rec[(long)split * p.rows + row] = make_rec(a1, a2v, a3, a4, j1, j2, j3, 2 * (t_begin / GT));
     }
   }
 #ifdef GQHIP_CLOCK_STAMPS

@@ -371,8 +371,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   Rec r[NSI];
 #pragma unroll
   for (int k = 0; k < NSI; ++k) {
-    r[k].m1 = r[k].m2 = r[k].m3 = r[k].m4 = NEG_INF;
-    r[k].id1 = r[k].id2 = r[k].id3 = 0;
+    r[k] = empty_rec();
     const int s = k * GROUP + sub;
     if (s < p.nsplit) r[k] = p.rec[(long)s * p.rows + row];
   }
@@ -436,15 +435,19 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
   unsigned long long sets_in = 0ull;          // record sets with any group within the margin
 #pragma unroll
   for (int k = 0; k < NSI; ++k) {
-    const bool c1 = (double)r[k].m1 >= thr, c2 = (double)r[k].m2 >= thr, c3 = (double)r[k].m3 >= thr;
-    const bool c4 = (double)r[k].m4 >= thr;
+    // m2..m4 as the record holds them: m1 - gap, never below the filter's value (gq_common.h:Rec)
+    const bool c1 = (double)r[k].m1 >= thr, c2 = rec_value(r[k].m1, r[k].d2) >= thr, c3 = rec_value(r[k].m1, r[k].d3) >= thr;
+    const bool c4 = rec_value(r[k].m1, r[k].d4) >= thr;
     const unsigned long long b1 = group_bits(c1), b2 = group_bits(c2), b3 = group_bits(c3);
     fourth = fourth || group_bits(c4) != 0ull;   // a fourth group of some set could matter: the candidates are incomplete
     sets_in |= b1 << (k * GROUP);
     const int n1 = __popcll(b1), n2 = __popcll(b2);
-    if (c1) cand[slot][total + __popcll(b1 & lt)] = r[k].id1;
-    if (c2) cand[slot][total + n1 + __popcll(b2 & lt)] = r[k].id2;
-    if (c3) cand[slot][total + n1 + n2 + __popcll(b3 & lt)] = r[k].id3;
+    // ids are relative to the set's split: + 2 * (first tile of the split / GT)
+    const int sset = k * GROUP + sub;
+    const int base2 = 2 * (((p.rec_halves == 2 ? sset >> 1 : sset) * p.tiles_per_split) / GT);
+    if (c1) cand[slot][total + __popcll(b1 & lt)] = base2 + (int)r[k].id1;
+    if (c2) cand[slot][total + n1 + __popcll(b2 & lt)] = base2 + (int)r[k].id2;
+    if (c3) cand[slot][total + n1 + n2 + __popcll(b3 & lt)] = base2 + (int)r[k].id3;
     total += n1 + n2 + __popcll(b3);
   }
   const bool undecided = bad || fourth;       // group-uniform

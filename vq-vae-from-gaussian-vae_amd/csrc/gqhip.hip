@@ -133,6 +133,20 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
     pl.tiles_per_split = ((pl.tiles_total + s3 - 1) / s3 + pl.gt - 1) / pl.gt * pl.gt;
     pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
   }
+  // The records carry half-group ids RELATIVE to their split in 16 bits (gq_common.h:Rec): 2 * tiles_per_split / GT <= 65536, i.e.
+  // at most 2^20 GT codes per split.  More splits where that is not so (n > 2^22 at the bench's 8..16 splits); codebooks beyond what
+  // the split cap allows (n > 2^26 GT / 2: 134 M codes at GT 4) leave the MFMA path for the exhaustive kernel.
+  const int64_t max_tps = 32768LL * pl.gt;
+  if (pl.mfma && pl.tiles_per_split > max_tps) {
+    const int cap = (pl.mixed || pl.f16) ? kMaxSplit / 2 : kMaxSplit;
+    const int64_t need = (pl.tiles_total + max_tps - 1) / max_tps;
+    if (need > cap) {
+      pl.mfma = pl.bf16 = pl.f16 = pl.mixed = false;
+    } else {
+      pl.tiles_per_split = (int)(((pl.tiles_total + need - 1) / need + pl.gt - 1) / pl.gt * pl.gt);
+      pl.nsplit = (pl.tiles_total + pl.tiles_per_split - 1) / pl.tiles_per_split;
+    }
+  }
   return pl;
 }
 

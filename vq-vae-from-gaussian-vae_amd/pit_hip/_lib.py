@@ -1056,10 +1056,19 @@ def debug_plan(rows: int, n: int, dim: int) -> dict:
 
 
 def debug_records(ws: Workspace, rows: int, n: int, dim: int):
-    """Candidate records the filter left in the workspace: (m [nsplit, rows, 4] fp32, ids [nsplit, rows, 3] int32)."""
+    """Candidate records the filter left in the workspace, decoded from their 16-byte form (csrc/gq_common.h:Rec):
+    (m [sets, rows, 4] fp32: m1 and the re-rank's view m1 - gap of m2..m4; ids [sets, rows, 3] int32: GLOBAL half-group ids)."""
     pl = debug_plan(rows, n, dim)
-    raw = ws.buf[pl["rec_offset"]: pl["rec_offset"] + pl["nsplit"] * rows * 32].view(torch.int32).reshape(pl["nsplit"], rows, 8)
-    return raw[..., :4].contiguous().view(torch.float32), raw[..., 4:7].contiguous()
+    sets = pl["nsplit"]
+    raw = ws.buf[pl["rec_offset"]: pl["rec_offset"] + sets * rows * 16].reshape(sets, rows, 16)
+    m1 = raw[..., 0:4].contiguous().view(torch.float32)                                   # [sets, rows, 1]
+    gaps = raw[..., 4:10].contiguous().view(torch.float16).to(torch.float64)               # [sets, rows, 3]
+    m = torch.cat([m1.to(torch.float64), m1.to(torch.float64) - gaps], dim=-1).to(torch.float32)
+    local = raw[..., 10:16].contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+    halves = 2 if pl["bf16"] in (2, 3) else 1                                              # one set per (split, lane half)
+    split = torch.arange(sets, device=raw.device, dtype=torch.int32) // halves
+    base2 = 2 * ((split * pl["tiles_per_split"]) // pl["gt"])
+    return m, local + base2[:, None, None]
 
 
 def debug_counters(ws: Workspace) -> Tuple[int, int]:
