@@ -286,25 +286,39 @@ __device__ __forceinline__ void finish_row_by_scan(const RerankParams &p, long r
     const int t0 = split * p.tiles_per_split;
     const int t1 = min(t0 + p.tiles_per_split, p.tiles_total);
     const int items = (t1 - t0) * cpt;
-    for (int it = tid; it < items; it += 256) {
-      const int tile = t0 + it / cpt, c = it % cpt;
-      const int code = tile * kTileCodes + (p.rec_halves == 2 ? (c & 3) + 8 * (c >> 2) + 4 * h : c);
-      if (code >= p.n) continue;
-      float n[DIM];
-      const f32x4 *q = reinterpret_cast<const f32x4 *>(p.cb + (long)code * DIM);
+    // U codes per thread and pass, their rows loaded BEFORE the first expansion: the scan is a chain of L2 latencies (one 4 DIM-byte
+    // row per thread in flight and ~0.7 us each: 270 us per 65 536 codes at dim 16 with the plain loop), so the loads in flight are
+    // what sets its speed
+    constexpr int U = DIM <= 8 ? 8 : (DIM == 16 ? 3 : 4);
+    for (int it0 = tid; it0 < items; it0 += 256 * U) {
+      float n[U][DIM];
+      int code[U];
+      bool ok[U];
 #pragma unroll
-      for (int k = 0; k < DIM / 4; ++k) {
-        const f32x4 v = q[k];
-        n[4 * k] = v.x; n[4 * k + 1] = v.y; n[4 * k + 2] = v.z; n[4 * k + 3] = v.w;
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + 256 * u;
+        const int itc = it < items ? it : it0;            // (clamped: a load that is not used)
+        const int tile = t0 + itc / cpt, c = itc % cpt;
+        code[u] = tile * kTileCodes + (p.rec_halves == 2 ? (c & 3) + 8 * (c >> 2) + 4 * h : c);
+        ok[u] = it < items && code[u] < p.n;
+        const f32x4 *q = reinterpret_cast<const f32x4 *>(p.cb + (long)(code[u] < p.n ? code[u] : p.n - 1) * DIM);
+#pragma unroll
+        for (int k = 0; k < DIM / 4; ++k) {
+          const f32x4 v = q[k];
+          n[u][4 * k] = v.x; n[u][4 * k + 1] = v.y; n[u][4 * k + 2] = v.z; n[u][4 * k + 3] = v.w;
+        }
       }
-      float f = 0.0f;
 #pragma unroll
-      for (int i = 0; i < DIM; ++i) f = __builtin_fmaf(__builtin_fmaf(cA[i], n[i], cB[i]), n[i], f);
-      if (keep_all || !(f < thr)) {                     // a NaN value passes
-        double sc;
-        if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(n, ops, p.beta);
-        else sc = vq_neg_dist(n, ops, DIM);
-        if (!have || better_d(sc, code, best_s, best_i)) { best_s = sc; best_i = code; have = true; }
+      for (int u = 0; u < U; ++u) {
+        float f = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) f = __builtin_fmaf(__builtin_fmaf(cA[i], n[u][i], cB[i]), n[u][i], f);
+        if (ok[u] && (keep_all || !(f < thr))) {          // a NaN value passes
+          double sc;
+          if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(n[u], ops, p.beta);
+          else sc = vq_neg_dist(n[u], ops, DIM);
+          if (!have || better_d(sc, code[u], best_s, best_i)) { best_s = sc; best_i = code[u]; have = true; }
+        }
       }
     }
   }
