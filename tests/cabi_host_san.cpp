@@ -13,7 +13,8 @@ int main() {
   if (gqhip_abi_version() != GQHIP_ABI_VERSION) { std::printf("FAIL abi\n"); return 1; }
   long plans = 0;
   const int64_t rows_v[] = {1, 2, 31, 32, 33, 127, 128, 1000, 1024, 4096, 8191, 8192, 16384, 65536, 262144, 1048576, 0x3fffffff};
-  const int64_t n_v[] = {1, 2, 31, 32, 33, 64, 1000, 4096, 65536, 65537, 1 << 20, 0x3fffffff};
+  const int64_t n_v[] = {1, 2, 31, 32, 33, 64, 1000, 4096, 65536, 65537, 1 << 20, (1 << 21) + 1, 1 << 22, (1 << 22) + 33, 1 << 23, (1 << 26) - 7,
+                         (1 << 27) + 5, 1 << 28, 0x3fffffff};
   const int64_t dim_v[] = {1, 3, 4, 7, 8, 16, 24, 32, 33, 64};
   for (int kind = 0; kind <= 3; ++kind) {
     if (gqhip_set_filter(kind) != GQHIP_OK || gqhip_get_filter() != kind) { std::printf("FAIL set_filter %d\n", kind); return 1; }
@@ -26,6 +27,16 @@ int main() {
           std::memset(out8, 0, sizeof(out8));
           if (gqhip_debug_plan(rows, n, dim, out8) != GQHIP_OK) { std::printf("FAIL debug_plan\n"); return 1; }
           if (out8[1] < 0 || out8[1] > 64 || out8[0] < 0 || out8[0] > b) { std::printf("FAIL plan fields\n"); return 1; }
+          if (out8[1] > 0) {
+            // the records hold 16-bit half-group ids relative to their split (csrc/gq_common.h:Rec), and the splits cover the codebook
+            const int64_t gt = out8[2], tps = out8[3], tiles = (n + 31) / 32;
+            const int64_t halves = (out8[4] == 2 || out8[4] == 3) ? 2 : 1;
+            if (gt < 1 || tps % gt != 0 || 2 * (tps / gt) > 65536 || (out8[1] / halves) * tps < tiles) {
+              std::printf("FAIL id range / coverage: rows %lld n %lld dim %lld: sets %lld gt %lld tps %lld\n", (long long)rows, (long long)n,
+                          (long long)dim, (long long)out8[1], (long long)gt, (long long)tps);
+              return 1;
+            }
+          }
           ++plans;
         }
   }
