@@ -113,7 +113,7 @@ class GaussianQuantRegularizer(_GaussianQuantBase):
 
     def _forward_fused(self, z):
         """Eval branch (gaussian.py:120-160) as ONE call: chunk / clamp / exp, the group permutes, zhat_noquant, the
-        rows x n score matrix, arg-max and gather all happen inside libgqhip's four launches.  A channels_last z
+        rows x n score matrix, arg-max and gather all happen inside libgqhip's three launches.  A channels_last z
         (what the NHWC conv stack hands over) is read, and zhat / indices / zhat_noquant are written, in that memory
         layout directly: NHWC memory of [B, C, h, w] IS the "blc" layout with L = h * w, so nothing is transposed."""
         z = z.float()
