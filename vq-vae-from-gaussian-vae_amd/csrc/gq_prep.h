@@ -92,6 +92,12 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     p.hdr->reranked = 0ull;
   }
 
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 1024)   // diagnostic build (tools/abl_prep.sh): the code blocks do nothing
+  if ((int)blockIdx.x >= p.row_blocks) return;
+#endif
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 2048)   // diagnostic build: the row blocks do nothing
+  if ((int)blockIdx.x < p.row_blocks) return;
+#endif
   if ((int)blockIdx.x >= p.row_blocks) {
     // ------------------------------------------------------------------ codebook image + max |cb|
     const int cbk = blockIdx.x - p.row_blocks;
@@ -270,8 +276,13 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
       lv = lv < p.lv_min ? p.lv_min : lv;
       lv = lv > p.lv_max ? p.lv_max : lv;
       const float half = 0.5f * lv;
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 4096)   // diagnostic build: fp32 exp / log (results differ; only the time is read)
+      s = __expf(half);
+      ls = __logf(s);
+#else
       s = (float)exp((double)half);
       ls = (float)log((double)s);
+#endif
       if (p.zhat_noquant) {
 #pragma clang fp contract(off)
         const float e = p.noise[oo] * s;
@@ -281,7 +292,11 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
       m = p.mu[row * DIM + g];
       if constexpr (MODE == kModeGQ) {
         s = p.sd[row * DIM + g];
+#if defined(GQHIP_ABL) && (GQHIP_ABL & 4096)
+        ls = p.lsd ? p.lsd[row * DIM + g] : __logf(s);
+#else
         ls = p.lsd ? p.lsd[row * DIM + g] : (float)log((double)s);
+#endif
       }
     }
   }
