@@ -368,3 +368,43 @@ def test_codebooks_beyond_the_16_bit_id_range_of_one_split_get_more_splits(dim, 
     print(res)
     assert pl["nsplit"] == sets and 2 * pl["tiles_per_split"] // pl["gt"] <= 65536
     assert res["equal"] and res["max_index"] > n - 4096
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_g18_the_bench_configuration_against_the_reference(channels_last):
+    """BASELINE configs[1] itself (bs 16, 256x256, codebook 2^16 x dim 16) with checkpoint-like weights at the trained operating
+    point, against the reference's CPU run (tests/golden/make_golden_r4d.py): all 16 384 indices (gates of bench.GATES: differing ones only
+    at near-ties of the reference's own score, at most 2 per image), the reference's per-image PSNR (eval.py:165-169) through the
+    one-launch step record, and the first moments of every reconstruction."""
+    from bench import GATES
+    from pit_hip.eval_dist import StepRecord
+
+    d = np.load(os.path.join(G, "g18_e2e_16x256_trained_like.npz"))
+    vae = _trained_like_engine(d).to(DEV)
+    gx = torch.Generator().manual_seed(4258)
+    x = (torch.rand(16, 3, 256, 256, generator=gx) * 2 - 1).to(DEV)
+    if channels_last:
+        vae = vae.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        z_enc = vae.encode(x, unregularized=True)[0]
+        z, ind = vae.quant(x)
+        rec = vae.dequant(ind)
+    zm = d["z_moments"]
+    assert abs(float(z_enc.abs().max()) - zm[0]) <= 2 * GATES["z_enc_max_abs"] and abs(float(z_enc[:, :16].std()) - zm[1]) < 1e-4
+    want, gap = _rows(d["indices"].astype(np.int64)), d["gap"]
+    got = _rows(ind.cpu().numpy())
+    diff = got != want
+    per_image = diff.reshape(16, 1024).sum(1)
+    print(f"g18 bench configuration (channels_last={channels_last}): {int(diff.sum())} of 16384 indices differ"
+          f"{' at gaps ' + str(gap[diff]) if diff.any() else ''}; smallest golden gap {float(gap.min()):.2e}")
+    assert per_image.max() <= GATES["indices_differing_per_1024"] and np.all(gap[diff] < GATES["near_tie_gap"]), (per_image, gap[diff])
+    same = ~diff.reshape(16, 1024).any(1)
+    lay = StepRecord(16, 1024, n_metrics=1)
+    _, met = lay.unpack(lay.pack_with_psnr(ind, x, rec))
+    psnr = met[:, 0].cpu().numpy()
+    mom = np.stack([rec.mean(dim=(1, 2, 3)).cpu().numpy(), rec.std(dim=(1, 2, 3)).cpu().numpy(), rec.abs().amax(dim=(1, 2, 3)).cpu().numpy()], 1)
+    print(f"   PSNR max |d| {np.abs(psnr - d['psnr'])[same].max():.2e} dB; moments max rel {np.abs(mom / d['x_rec_moments'] - 1)[same].max():.2e}")
+    # measured: 2.5e-5 dB, 7.5e-6 relative (fp32 reconstructions of the same tokens through two implementations of the decoder)
+    assert np.abs(psnr - d["psnr"])[same].max() <= 2e-4
+    assert np.abs(mom[same, 1:] / d["x_rec_moments"][same, 1:] - 1).max() <= 1e-4 and np.abs(mom[same, 0] - d["x_rec_moments"][same, 0]).max() <= 1e-4
