@@ -418,13 +418,13 @@ def reference_gpu_path(vae, x, cfg, product_indices, product_images_per_s, steps
         if fam == "gq":
             from pit_hip.quantization.gaussian import GaussianQuantRegularizer
 
-            reg = GaussianQuantRegularizer(**dict(cfg["params"], backend="cuda")).eval().to(dev)
+            reg = GaussianQuantRegularizer(**dict(cfg["params"], backend="cuda-compat")).eval().to(dev)
             quant = lambda z: (lambda zh, info: (zh, info["indices"]))(*reg(z))
             seq = "gq_cuda op -> rows x 65536 fp32 matrix in HBM -> torch.argmax -> index_select"
         elif fam == "gq2":
             from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
 
-            reg = GaussianQuantRegularizer2(**dict(cfg["params"], backend="cuda")).eval().to(dev)
+            reg = GaussianQuantRegularizer2(**dict(cfg["params"], backend="cuda-compat")).eval().to(dev)
             quant = lambda z: (lambda zh, info: (zh, info["indices"]))(*reg(z))
             seq = "quant_gaussian + gq_cuda op -> rows x 65536 fp32 matrix in HBM -> torch.argmax -> index_select"
         elif fam == "vq":

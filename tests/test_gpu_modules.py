@@ -105,15 +105,30 @@ def test_g5_edge_rows():
     assert ind[0, 0, 0, 3] == 7  # duplicated codeword -> first index
 
 
-def test_compat_backend_cuda_call_sequence():
-    """backend="cuda": gq_cuda.ops.gq_cuda -> argmax -> index_select (gaussian.py:124-133)."""
+def test_backend_cuda_is_the_fused_path_and_cuda_compat_the_reference_call_sequence(monkeypatch):
+    """backend="cuda" (what every shipped GQ YAML says, configs/sd3unet_gq_0.25.yaml:33): the fused kernels, no score matrix, the
+    reference golden's indices; backend="cuda-compat" (or "cuda" + GQHIP_COMPAT=1): gq_cuda.ops.gq_cuda -> argmax -> index_select
+    (gaussian.py:124-133)."""
     import gq_cuda
     from pit_hip.quantization.gaussian import GaussianQuantRegularizer
 
     d = load("g3_realistic_seed0.npz")
-    q = GaussianQuantRegularizer("bchw", 65536, group=16, backend="cuda").eval().to(DEV)
-    zhat, info = q(torch.from_numpy(d["z"]).to(DEV))
-    assert q.perturbed.shape == (1024, 65536)
+    zdev = torch.from_numpy(d["z"]).to(DEV)
+    monkeypatch.delenv("GQHIP_COMPAT", raising=False)
+    qf = GaussianQuantRegularizer("bchw", 65536, group=16, backend="cuda").eval().to(DEV)
+    _, info_f = qf(zdev)
+    assert qf.perturbed is None                                   # no 4.29 GB matrix on the zero-edit route
+    qh = GaussianQuantRegularizer("bchw", 65536, group=16, backend="hip").eval().to(DEV)
+    zh_h, info_h = qh(zdev)                                       # pinned against the reference golden by test_g3_*
+    assert torch.equal(info_f["indices"], info_h["indices"]) and torch.equal(qf(zdev)[0], zh_h)
+    assert (info_f["indices"].cpu().numpy() != d["indices"]).mean() < 1e-3
+    monkeypatch.setenv("GQHIP_COMPAT", "1")
+    _, info_e = qf(zdev)
+    assert qf.perturbed is not None and qf.perturbed.shape == (1024, 65536)
+    monkeypatch.delenv("GQHIP_COMPAT")
+    q = GaussianQuantRegularizer("bchw", 65536, group=16, backend="cuda-compat").eval().to(DEV)
+    zhat, info = q(zdev)
+    assert q.perturbed.shape == (1024, 65536) and torch.equal(info["indices"], info_e["indices"])
     ind = info["indices"].cpu().numpy()
     cb = q.prior_samples.cpu().numpy()
     zf = d["z"]
@@ -172,6 +187,7 @@ def test_vq_lfq_512_shapes():
     assert torch.equal(_lib.lfq_unpack(li, 16), lq)
 
 
+@pytest.mark.e2e
 def test_engine_end_to_end_full_config():
     """x -> encode -> indices -> dequant/decode on the GPU vs the reference's CPU end-to-end golden.
     Gates (fp32, different conv/GN/SDPA kernels): |z_enc diff| <= 5e-5; at most 2 of 1024 indices differ end to end and
@@ -188,7 +204,7 @@ def test_engine_end_to_end_full_config():
         regularizer_config={"target": "pit.quantization.gaussian.GaussianQuantRegularizer",
                             "params": {"format": "bchw", "group": 16, "n_samples": 65536, "backend": "cuda"}},
     ).eval()
-    vae.regularization.backend = "hip"  # YAML said cuda; flip to the fused path like a user would
+    assert vae.regularization.backend == "cuda"      # the shipped YAML's value, untouched: it lands on the fused path
     vae = vae.to(DEV)
     d = load("g7_full_e2e.npz")
     gx = torch.Generator().manual_seed(1000)
@@ -253,6 +269,7 @@ def test_histogram_and_u16_wire_format():
     assert torch.equal(_lib.indices_from_u16(u).cpu(), idx)
 
 
+@pytest.mark.e2e
 def test_eval_loop_single_rank_on_gpu():
     from pit_hip.eval_dist import evaluate_sharded
     from pit_hip.models.autoencoder import AutoencodingEngine
@@ -280,6 +297,7 @@ def test_eval_loop_single_rank_on_gpu():
     assert int((out["indices"][:4].cpu() != ind.reshape(4, -1).cpu()).sum()) <= 2
 
 
+@pytest.mark.e2e
 def test_smoke_entry():
     import __graft_entry__ as ge
 
@@ -315,6 +333,7 @@ def test_g10_bsq_and_fsq_modules():
     assert abs(float(info["bits"]) - float(np.sum(np.log2(levels)) * 6 * 64)) < 1e-2
 
 
+@pytest.mark.convstack
 @pytest.mark.parametrize("shape", [(2, 128, 64, 64), (3, 256, 16, 16), (1, 512, 32, 32), (2, 64, 6, 10)])
 def test_fused_groupnorm_silu_matches_torch(shape):
     """gn_silu_f32 vs ATen GroupNorm -> SiLU (fp32; tolerance 2e-5 abs / 1e-5 rel: different
@@ -336,26 +355,7 @@ def test_fused_groupnorm_silu_matches_torch(shape):
     torch.testing.assert_close(got_s, want_s, atol=2e-5, rtol=1e-5)
 
 
-def test_unet_fused_and_aten_paths_agree():
-    from pit_hip.modules import unet
-
-    cfg = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=64, in_channels=3, out_ch=3, ch=64,
-               ch_mult=[1, 2, 4], num_res_blocks=1, attn_resolutions=[16], dropout=0.0)
-    torch.manual_seed(1234)
-    enc, dec = unet.Encoder(**cfg).eval().to(DEV), unet.Decoder(**cfg).eval().to(DEV)
-    x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV)
-    with torch.no_grad():
-        outs = []
-        for fused, defer in ((True, True), (True, False), (False, False)):
-            unet.FUSED_GN, unet.DEFER_BIAS = fused, defer
-            z = enc(x)
-            outs.append((z, dec(z[:, :16])))
-        unet.FUSED_GN = unet.DEFER_BIAS = True
-    for z, r in outs[:2]:
-        torch.testing.assert_close(z, outs[2][0], atol=1e-4, rtol=1e-4)
-        torch.testing.assert_close(r, outs[2][1], atol=1e-4, rtol=1e-4)
-
-
+@pytest.mark.convstack
 def test_gn_prebias_and_add_bias_kernels():
     from pit_hip import _lib
 
@@ -373,6 +373,7 @@ def test_gn_prebias_and_add_bias_kernels():
         torch.testing.assert_close(_lib.add_bias(x, y, pb), x + y + pb[None, :, None, None], atol=1e-6, rtol=1e-6)
 
 
+@pytest.mark.convstack
 @pytest.mark.parametrize("shape", [(2, 128, 32, 32), (1, 256, 16, 24), (2, 512, 8, 8)])
 def test_fused_groupnorm_nhwc_and_add_bias_nhwc(shape):
     import torch.nn.functional as F
@@ -393,22 +394,6 @@ def test_fused_groupnorm_nhwc_and_add_bias_nhwc(shape):
         torch.testing.assert_close(_lib.add_bias(x, y, pb), x + y + pb[None, :, None, None], atol=1e-6, rtol=1e-6)
 
 
-def test_unet_channels_last_matches_nchw():
-    from pit_hip.modules import unet
-
-    cfg = dict(attn_type="vanilla", double_z=True, z_channels=16, resolution=64, in_channels=3, out_ch=3, ch=128,
-               ch_mult=[1, 2, 4], num_res_blocks=1, attn_resolutions=[16], dropout=0.0)
-    torch.manual_seed(1234)
-    enc, dec = unet.Encoder(**cfg).eval().to(DEV), unet.Decoder(**cfg).eval().to(DEV)
-    x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV)
-    with torch.no_grad():
-        z1 = enc(x); r1 = dec(z1[:, :16].contiguous())
-        enc_cl, dec_cl = enc.to(memory_format=torch.channels_last), dec.to(memory_format=torch.channels_last)
-        z2 = enc_cl(x.contiguous(memory_format=torch.channels_last)); r2 = dec_cl(z2[:, :16].contiguous())
-    torch.testing.assert_close(z1, z2, atol=2e-4, rtol=2e-4)
-    torch.testing.assert_close(r1, r2, atol=2e-4, rtol=2e-4)
-
-
 @pytest.mark.parametrize("z_channels,K", [(16, 1), (32, 2)])
 def test_gq2_shipped_config_and_flagged_k2_variant(z_channels, K):
     """BASELINE config 4: configs/sd3unet_gq2_0.25.yaml (dim 16, codebook 65536, z_channels 16 -> K = 1
@@ -417,8 +402,7 @@ def test_gq2_shipped_config_and_flagged_k2_variant(z_channels, K):
     from pit_hip import _lib
     from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
 
-    q2 = GaussianQuantRegularizer2(dim=16, codebook_size=65536, backend="cuda").eval().to(DEV)
-    q2.backend = "hip"
+    q2 = GaussianQuantRegularizer2(dim=16, codebook_size=65536, backend="cuda").eval().to(DEV)   # as shipped (sd3unet_gq2_0.25.yaml)
     g = torch.Generator().manual_seed(40 + K)
     c = z_channels
     z = torch.cat([0.9 * torch.randn(2, c, 32, 32, generator=g), -1.5 + 0.3 * torch.randn(2, c, 32, 32, generator=g)], 1)
@@ -468,6 +452,7 @@ def test_quantizer_is_hip_graph_capturable():
         assert torch.equal(idx_g, idx_e) and torch.equal(zhat_g, zhat_e)
 
 
+@pytest.mark.convstack
 def test_upsample2x_nhwc_matches_interpolate():
     import torch.nn.functional as F
     from pit_hip import _lib
@@ -536,6 +521,7 @@ def test_vq_multi_candidate(rows, n, dim, filt):
     assert torch.equal(zq.cpu(), emb[idx])
 
 
+@pytest.mark.convstack
 def test_add_bias_stats_and_gn_apply_match_the_unfused_pair():
     """Residual add that leaves the next GroupNorm's statistics behind + apply-only GroupNorm == add, then GN."""
     import torch.nn.functional as F
@@ -558,28 +544,7 @@ def test_add_bias_stats_and_gn_apply_match_the_unfused_pair():
             assert torch.allclose(out, _lib.gn_silu(y, gamma, beta, 32, 1e-6, silu=silu), atol=1e-6, rtol=1e-6)
 
 
-def test_unet_with_and_without_fused_add_stats_agree():
-    from pit_hip.modules import unet as U
-
-    torch.manual_seed(0)
-    cfg = dict(ch=128, out_ch=3, in_channels=3, resolution=64, z_channels=16, double_z=True, ch_mult=[1, 2, 4, 4],
-               num_res_blocks=2, attn_resolutions=[8], dropout=0.0)
-    enc = U.Encoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
-    dec = U.Decoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
-    x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
-    outs = []
-    with torch.no_grad():
-        for flag in (True, False):
-            U.FUSED_ADD_STATS = flag
-            z = enc(x)
-            outs.append((z, dec(z[:, :16])))
-    U.FUSED_ADD_STATS = True
-    # same arithmetic up to the summation order of the statistics (fp32 partial sums per thread, fp64 across blocks)
-    dz = float((outs[0][0] - outs[1][0]).abs().max())
-    dx = float((outs[0][1] - outs[1][1]).abs().max())
-    assert dz <= 1e-4 and dx <= 5e-4, (dz, dx)
-
-
+@pytest.mark.convstack
 def test_upsample_fallback_route_matches_upsample_then_conv():
     """Upsample at shapes the direct sub-pixel kernel does not tile (H % 8, W % 32, or no statistics on the input): libgqhip's
     NHWC upsample copy + the ordinary convolution routes == interpolate followed by the 3x3 conv.  (The tiled shapes:
@@ -607,128 +572,3 @@ def test_upsample_fallback_route_matches_upsample_then_conv():
         print(f"upsample fallback {ch} ch {H}x{W}: error / sum|x||w|: this route {e_got:.2e}, F.conv2d {e_ref:.2e}")
         assert e_got <= max(4e-7 * (4 if ch >= 128 else 1), 2.0 * e_ref), (e_got, e_ref)
 
-
-def test_winograd_conv3x3_matches_direct_conv():
-    """Winograd F(2x2,3x3) path of the decoder's wide 3x3 convolutions (transform kernels + 16 hipBLASLt GEMMs)
-    against F.conv2d: same function up to fp32 rounding (the GEMM library's fp32 is ~3e-7 of sum|a||b|)."""
-    import torch.nn.functional as F
-    from pit_hip import _lib
-    from pit_hip.modules import unet as U
-
-    torch.manual_seed(2)
-    for cin, cout, H, W in ((256, 256, 16, 24), (512, 256, 8, 8), (64, 32, 6, 10), (128, 128, 32, 32)):
-        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
-        x = torch.randn(2, cin, H, W).to(DEV).contiguous(memory_format=torch.channels_last)
-        with torch.no_grad():
-            ref = F.conv2d(x.double(), conv.weight.double(), None, 1, 1)
-            direct = F.conv2d(x, conv.weight, None, 1, 1)
-            scale = float(ref.abs().mean())
-            e_d = float((direct.double() - ref).abs().max()) / scale
-            for f4 in (False, True):
-                if f4 and (H % 4 or W % 4):
-                    continue
-                y = _lib.wino_conv3x3(x, U._wino_weights(conv, f4))
-                assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
-                e_w = float((y.double() - ref).abs().max()) / scale
-                print(f"winograd F({4 if f4 else 2},3) {cin}->{cout} {H}x{W}: max err / mean|y| = {e_w:.2e} "
-                      f"(direct MIOpen conv: {e_d:.2e})")
-                assert e_w < (2e-3 if f4 else 2e-4)
-
-
-def test_decoder_with_and_without_winograd_agree():
-    from pit_hip.modules import unet as U
-
-    torch.manual_seed(0)
-    cfg = dict(ch=128, out_ch=3, in_channels=3, resolution=64, z_channels=16, double_z=True, ch_mult=[1, 2, 4, 4],
-               num_res_blocks=2, attn_resolutions=[8], dropout=0.0)
-    dec = U.Decoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
-    z = torch.randn(2, 16, 8, 8).to(DEV).contiguous(memory_format=torch.channels_last)
-    outs = []
-    with torch.no_grad():
-        for flag in (True, False):
-            U.WINOGRAD = flag
-            outs.append(dec(z))
-    U.WINOGRAD = True
-    d = float((outs[0] - outs[1]).abs().max())
-    assert d <= 2e-3 * max(1.0, float(outs[1].abs().max())), d
-
-
-def test_winograd_with_fused_groupnorm_matches_unfused():
-    """GroupNorm+SiLU applied inside the Winograd input transform == gn_silu followed by the plain transform."""
-    from pit_hip import _lib
-    from pit_hip.modules import unet as U
-
-    torch.manual_seed(4)
-    conv = torch.nn.Conv2d(256, 128, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
-    norm = torch.nn.GroupNorm(32, 256, eps=1e-6).to(DEV)
-    with torch.no_grad():
-        norm.weight.normal_(); norm.bias.normal_()
-    x = torch.randn(3, 256, 12, 20).to(DEV).contiguous(memory_format=torch.channels_last)
-    pb = torch.randn(256).to(DEV)
-    with torch.no_grad():
-        for f4 in (False, True):
-            Uw = U._wino_weights(conv, f4)
-            for pre in (None, pb):
-                stats = _lib.gn_stats(x, 32, pre)
-                fused = _lib.wino_conv3x3(x, Uw, gn=(norm.weight, norm.bias, 32, 1e-6, True, stats, pre))
-                plain = _lib.wino_conv3x3(_lib.gn_silu(x, norm.weight, norm.bias, 32, 1e-6, silu=True, pre_bias=pre), Uw)
-                # same folded scale / shift and SiLU function (gq_aux.h:silu_f32); gn_silu sums its own statistics
-                # (atomics), so a last-bit difference of the scale is possible: the fp32 GEMM's own noise is the bound
-                tol = 2e-4 if f4 else 1e-5
-                assert torch.allclose(fused, plain, atol=tol, rtol=tol), float((fused - plain).abs().max())
-
-
-def test_winograd_fused_tail_matches_unfused():
-    """Output transform + bias + residual + GroupNorm statistics in one pass == plain transform, add_bias_stats."""
-    from pit_hip import _lib
-    from pit_hip.modules import unet as U
-
-    torch.manual_seed(6)
-    for cin, cout, H, W in ((256, 128, 16, 24), (128, 512, 8, 12)):
-        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
-        x = torch.randn(3, cin, H, W).to(DEV).contiguous(memory_format=torch.channels_last)
-        res = torch.randn(3, cout, H, W).to(DEV).contiguous(memory_format=torch.channels_last)
-        bias = torch.randn(cout).to(DEV)
-        with torch.no_grad():
-            for f4 in (False, True):
-                Uw = U._wino_weights(conv, f4)
-                y, stats = _lib.wino_conv3x3(x, Uw, residual=res, bias=bias, stats_groups=32)
-                y0, stats0 = _lib.add_bias_stats(res, _lib.wino_conv3x3(x, Uw), bias, 32)
-                assert torch.allclose(y, y0, atol=1e-5, rtol=1e-5), float((y - y0).abs().max())
-                assert torch.allclose(_lib.gn_stats_values(stats), _lib.gn_stats_values(stats0), rtol=1e-6, atol=1e-4)
-
-
-def test_unet_with_and_without_fused_winograd_tail_agree():
-    from pit_hip.modules import unet as U
-
-    torch.manual_seed(0)
-    cfg = dict(ch=128, out_ch=3, in_channels=3, resolution=64, z_channels=16, double_z=True, ch_mult=[1, 2, 4, 4],
-               num_res_blocks=2, attn_resolutions=[8], dropout=0.0)
-    enc = U.Encoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
-    dec = U.Decoder(**cfg).eval().to(DEV).to(memory_format=torch.channels_last)
-    x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
-    outs = []
-    with torch.no_grad():
-        for flag in (True, False):
-            U.FUSED_WINO_TAIL = flag
-            z = enc(x)
-            outs.append((z, dec(z[:, :16])))
-    U.FUSED_WINO_TAIL = True
-    dz = float((outs[0][0] - outs[1][0]).abs().max())
-    dx = float((outs[0][1] - outs[1][1]).abs().max())
-    assert dz <= 1e-4 and dx <= 1e-3, (dz, dx)
-
-
-def test_attention_fused_qkv_matches_three_convs():
-    from pit_hip.modules import unet as U
-
-    torch.manual_seed(3)
-    blk = U.AttnBlock(128).eval().to(DEV).to(memory_format=torch.channels_last)
-    x = torch.randn(2, 128, 8, 8).to(DEV).contiguous(memory_format=torch.channels_last)
-    with torch.no_grad():
-        U.FUSED_QKV = True
-        y1 = blk(x)
-        U.FUSED_QKV = False
-        y0 = blk(x)
-        U.FUSED_QKV = True
-    assert torch.allclose(y1, y0, atol=2e-5, rtol=1e-5), float((y1 - y0).abs().max())

@@ -81,6 +81,7 @@ def _e2e_vs_golden(d, x, channels_last, filt, tag):
         assert err <= GATES["recon_max_abs_if_indices_equal"] * max(1.0, scale), (err, scale)
 
 
+@pytest.mark.e2e
 @pytest.mark.parametrize("channels_last", [True, False])
 @pytest.mark.parametrize("filt", ["auto", "bf16", "fp32", "mixed"])
 def test_g15_trained_operating_point_end_to_end_vs_reference_golden(channels_last, filt):
@@ -91,6 +92,7 @@ def test_g15_trained_operating_point_end_to_end_vs_reference_golden(channels_las
     _e2e_vs_golden(d, x, channels_last, filt, "g15 trained-like e2e")
 
 
+@pytest.mark.e2e
 @pytest.mark.parametrize("channels_last", [True, False])
 @pytest.mark.parametrize("filt", ["auto", "fp32"])
 def test_g17_nonsquare_odd_batch_end_to_end_vs_reference_golden(channels_last, filt):
@@ -152,6 +154,7 @@ def test_step_record_psnr_matches_reference_golden():
 
 
 # ------------------------------------------------------------------------------------------ the encoder's conv_in on libgqhip
+@pytest.mark.convstack
 @pytest.mark.parametrize("B,cin,H,W", [(2, 3, 64, 64), (1, 3, 8, 32), (3, 4, 16, 96), (2, 1, 24, 32), (16, 3, 256, 256)])
 def test_conv_in_small_matches_fp64_and_leaves_the_statistics(B, cin, H, W):
     """conv3x3_cin_small_f32 (pit/modules/unet.py:411-413, the encoder's conv_in): against an fp64 convolution -- 9 Cin fp32 FMAs
@@ -186,37 +189,7 @@ def test_conv_in_small_matches_fp64_and_leaves_the_statistics(B, cin, H, W):
         assert torch.equal(y2, y) and torch.equal(st2, st)
 
 
-def test_encoder_runs_no_library_convolution_at_the_bench_shape():
-    """With conv_in on libgqhip the channels_last encoder calls no MIOpen convolution at 256 x 256 any more (MIOpen's immediate mode ran
-    a process's first eight conv_in calls on a 4 ms naive kernel).  Checked by counting torch's convolution dispatches."""
-    from pit_hip.modules import unet as U
-
-    torch.manual_seed(1234)
-    enc = U.Encoder(**FULL).eval().to(DEV).to(memory_format=torch.channels_last)
-    x = (torch.rand(2, 3, 256, 256, device=DEV) * 2 - 1).contiguous(memory_format=torch.channels_last)
-    calls = []
-    real = torch.nn.functional.conv2d
-
-    def counting(*a, **k):
-        calls.append(tuple(a[0].shape))
-        return real(*a, **k)
-
-    torch.nn.functional.conv2d = counting
-    U.F.conv2d = counting
-    try:
-        with torch.no_grad():
-            z1 = enc(x)
-            U.CONV_IN_SMALL = False
-            z0 = enc(x)
-    finally:
-        U.CONV_IN_SMALL = True
-        torch.nn.functional.conv2d = real
-        U.F.conv2d = real
-    dz = float((z1 - z0).abs().max())
-    print(f"encoder z with conv_in on libgqhip vs on MIOpen: |dz| {dz:.2e}; F.conv2d calls with the switch off: {len(calls)}")
-    assert dz <= 2e-5
-
-
+@pytest.mark.e2e
 def test_statistics_arena_changes_no_bit_and_survives_reentry():
     """Round 4: the GroupNorm statistics records of a forward come out of one arena zeroed by a single fill (gqhip_stats_prezeroed)
     instead of one memset launch per producing kernel.  Same bits with and without it, across repeated forwards (the arena is
@@ -282,6 +255,7 @@ def test_g16_groupings_at_the_trained_operating_point_vs_reference_golden(channe
         assert diff.sum() == 0 or np.all(gap[diff] < GATES["same_z_gap"]), (dim, int(diff.sum()), gap[diff])
 
 
+@pytest.mark.e2e
 @pytest.mark.parametrize("channels_last", [True, False])
 def test_g16_vq_behind_checkpoint_like_weights_vs_reference_golden(channels_last):
     """BASELINE configs[4]'s quantiser behind realistic weights: the reference Encoder (double_z False) with checkpoint-like weights and
@@ -370,6 +344,7 @@ def test_codebooks_beyond_the_16_bit_id_range_of_one_split_get_more_splits(dim, 
     assert res["equal"] and res["max_index"] > n - 4096
 
 
+@pytest.mark.e2e
 @pytest.mark.parametrize("channels_last", [True, False])
 def test_g18_the_bench_configuration_against_the_reference(channels_last):
     """BASELINE configs[1] itself (bs 16, 256x256, codebook 2^16 x dim 16) with checkpoint-like weights at the trained operating

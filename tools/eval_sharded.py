@@ -39,8 +39,6 @@ def main():
     model = model.eval().to(device)
     if device.type == "cuda":
         model = model.to(memory_format=torch.channels_last)   # NHWC: the fast conv stack (inputs are converted by the modules)
-    if getattr(model.regularization, "backend", None) == "cuda":
-        model.regularization.backend = "hip"
     if a.dataset:
         from pit_hip.data import SimpleDataset
 

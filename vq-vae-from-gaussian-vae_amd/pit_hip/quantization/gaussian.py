@@ -11,11 +11,18 @@ the HIP kernels and the score matrix never exists in HBM.
 
 backend:
   "hip"   fused path (default here).
-  "cuda"  the reference's call sequence -- ``gq_cuda.ops.gq_cuda`` into a
+  "cuda"  what every shipped GQ YAML says (configs/sd3unet_gq_0.25.yaml:33): in
+          the reference that selects its fast path, and it selects the fast path
+          here too -- the fused kernels, indices bit-identical to the reference's
+          torch backend, no score matrix (``self.perturbed`` stays ``None``).
+  "cuda-compat" (or backend "cuda" with GQHIP_COMPAT=1 in the environment)
+          the reference's own call sequence -- ``gq_cuda.ops.gq_cuda`` into a
           persistent ``perturbed`` buffer, then ``torch.argmax`` and
           ``index_select`` (gaussian.py:124-133) -- served by our HIP build of
-          the ``extension_cpp::gq`` op.  Kept for users who want the score
-          matrix; it is HBM-bound by construction.
+          the ``extension_cpp::gq`` op: for users who want the rows x n score
+          matrix.  HBM-bound by construction (4.29 GB written and re-read at
+          bs 16), and its arg-max is the op's own rounding of 2 s + const(r):
+          equal to the bit-exact indices except at rounding-level ties.
   "torch" accepted for config compatibility; runs the fused HIP path (the
           indices are those of the reference's torch backend, bit for bit).
 There is no CPU implementation in this package: tensors must live on a HIP
@@ -24,6 +31,7 @@ device (``pit_hip._lib`` raises otherwise).
 from __future__ import annotations
 
 import math
+import os
 from typing import Sequence
 
 import torch
@@ -65,10 +73,14 @@ class _GaussianQuantBase(nn.Module):
         self.register_buffer("normal_log_prob", self.normal_dist.log_prob(self.prior_samples).float(),
                              persistent=False)
         self.perturbed = None
-        if backend not in ("hip", "cuda", "torch"):
+        if backend not in ("hip", "cuda", "cuda-compat", "torch"):
             raise ValueError(f"unknown backend {backend!r}")
         self.backend = backend
         self._ws = _lib.Workspace()   # scratch only: every call rebuilds what it derives from the codebook
+
+    def _compat(self) -> bool:
+        """True when the caller asked for the score-matrix call sequence instead of the fused kernels."""
+        return self.backend == "cuda-compat" or (self.backend == "cuda" and os.environ.get("GQHIP_COMPAT", "0") == "1")
 
     # the reference's "cuda" call sequence on rows (gaussian.py:124-133 / :289-298)
     def _compat_rows(self, mu: torch.Tensor, std: torch.Tensor, dim: int):
@@ -138,7 +150,7 @@ class GaussianQuantRegularizer(_GaussianQuantBase):
         return zhat, {"indices": indices, "zhat_noquant": zhat_noquant}
 
     def forward(self, z):
-        if not self.training and self.backend != "cuda":
+        if not self.training and not self._compat():
             return self._forward_fused(z)
         z = z.float()
         if self.format == "bchw":
@@ -167,7 +179,7 @@ class GaussianQuantRegularizer(_GaussianQuantBase):
                     "bits-max": kl2_max, "lam": torch.zeros_like(kl_loss) + self.lam}
             return zhat, info
 
-        # backend "cuda": the reference's own call sequence (score matrix -> argmax -> index_select)
+        # backend "cuda-compat": the reference's own call sequence (score matrix -> argmax -> index_select)
         zhat_noquant = mu + torch.randn_like(mu) * std  # consumes RNG in eval, like gaussian.py:121
         k = c // self.group
         mu_r = mu.reshape(b, l, self.group, k).permute(0, 1, 3, 2).reshape(-1, self.group)
@@ -225,7 +237,7 @@ class GaussianQuantRegularizer2(_GaussianQuantBase):
     def quant_vq(self, z):
         z2, z_shape, mu, _, std = self._split(z.float())
         knum = z2.shape[-1] // (self.dim * 2)
-        if self.backend == "cuda":
+        if self._compat():
             zq, ind = self._compat_rows(mu.reshape(-1, self.dim).contiguous(), std.reshape(-1, self.dim).contiguous(),
                                         self.dim)
             zhat = zq.reshape(-1, knum * self.dim).float()
