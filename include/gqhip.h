@@ -38,12 +38,14 @@
 extern "C" {
 #endif
 
-#define GQHIP_ABI_VERSION 6   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
+#define GQHIP_ABI_VERSION 7   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
                                * 4: four-launch fused arg-max (no caller-cached max|cb|; noise / zhat_noquant in gq_quantize_z_f32), profile_reserve;
                                * 5: GroupNorm statistics as order-independent fixed-point records (gqhip_gnstat_t), conv3x3_f32 (fp32 matrix
                                *    cores: conv_in / conv_out of the encoder and decoder), gqhip_debug_barrier / gqhip_debug_tail;
                                * 6: three-launch fused arg-max -- undecided rows are finished inside the re-rank, the tail kernel with its grid
-                               *    barriers is gone and gqhip_debug_barrier / gqhip_debug_tail with it; gq_step_record_f32, conv3x3_cin_small_f32 */
+                               *    barriers is gone and gqhip_debug_barrier / gqhip_debug_tail with it; gq_step_record_f32, conv3x3_cin_small_f32;
+                               * 7: codebook cache (gqhip_cb_cache_bytes; cb_cache arguments of gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32):
+                               *    dims 4 / 8 run a pruned exact search over a cached spatial index of the codebook (csrc/gq_grid.h) */
 
 /* GroupNorm statistics of one (image, group): GQHIP_GNSTAT_WORDS int64 words = {sum: 3 limbs, sum of squares: 3 limbs, poison,
  * unused}; value = q0 2^-56 + q1 2^-16 + q2 2^24.  Every kernel that leaves statistics behind adds its threads' fp32 partial
@@ -97,6 +99,20 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8);
  * nothing derived from a codebook or from rows is ever reused across calls. */
 int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim);
 
+/* ---- codebook cache ---------------------------------------------------------
+ * Bytes of PERSISTENT device memory (256-B aligned) in which the fused arg-max keeps what it derives from a codebook of `n` codes
+ * of width `dim` across calls; 0 when this shape keeps nothing (then pass NULL / 0).  Today: dims 4 and 8 with 2^14 <= n <= 2^20
+ * -- a three-level tree of bounding boxes over the codes sorted into 4096 leaves, which lets those dims run a pruned exact search
+ * (5-6 leaves of ~16 codes per row at dim 4 instead of all n codes; csrc/gq_grid.h) in place of filter + re-rank.
+ * Contract: the caller owns the buffer, hands the SAME buffer to every call that uses the same codebook, and never writes it;
+ * its initial contents are don't-care.  The library validates it on EVERY call -- the first launch hashes the codebook it is
+ * given (it reads it anyway) and compares with the hashes the cache was stamped with -- and rebuilds it in-stream (one extra
+ * one-block kernel that otherwise exits at once) when they differ: a codebook edited in place by any route, a different
+ * codebook, a fresh or clobbered buffer all cost one rebuild and never a wrong index.  One cache serves one stream at a time.
+ * Without a cache (NULL) every shape runs the filter + re-rank path.  (No reference counterpart: the reference recomputes
+ * everything per call, pit/quantization/gaussian.py:136-150.) */
+int64_t gqhip_cb_cache_bytes(int64_t n, int64_t dim);
+
 /* ---- compat op: the reference's native boundary ---------------------------
  * out[r, j] = sum_i -((cb[j,i]-mu[r,i])/sd[r,i])^2 + cb[j,i]^2 * beta
  * mu, sd [rows, dim]; cb [n, dim]; out [rows, n]; all fp32 contiguous.
@@ -122,7 +138,8 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
 int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null,
                   const float *cb, int64_t *idx, float *zhat_or_null,
                   int64_t dim, int64_t rows, int64_t n, double beta,
-                  void *workspace, int64_t workspace_bytes, void *stream);
+                  void *workspace, int64_t workspace_bytes,
+                  void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream);
 
 /* ---- module-level fused quantiser -----------------------------------------
  * z is the encoder output holding [mu | logvar] along its channel axis.
@@ -147,7 +164,8 @@ int gq_quantize_z_f32(const float *z, const float *noise_or_null, const float *c
                       float *mu_out_or_null, float *sd_out_or_null, int64_t B,
                       int64_t L, int64_t c, int64_t dim, int64_t n, int layout,
                       int grouping, double lv_min, double lv_max, double beta,
-                      void *workspace, int64_t workspace_bytes, void *stream);
+                      void *workspace, int64_t workspace_bytes,
+                      void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream);
 
 /* zhat from indices (same layouts as above). */
 int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B,
@@ -157,7 +175,8 @@ int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B,
 /* ---- VQ: argmin_j |z_r - e_j|^2 (fp64 arbiter, first min wins) ------------- */
 int vq_argmin_f32(const float *z, const float *emb, int64_t *idx,
                   float *zq_or_null, int64_t dim, int64_t rows, int64_t n,
-                  void *workspace, int64_t workspace_bytes, void *stream);
+                  void *workspace, int64_t workspace_bytes,
+                  void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream);
 
 /* ---- LFQ: sign quantisation + big-endian bit pack -------------------------- */
 int lfq_pack_f32(const float *x, int64_t *idx, float *q_or_null, int64_t rows,
@@ -415,6 +434,10 @@ int gqhip_profile_collect(int *launches_host, double *total_ms_host);
 int gqhip_debug_enable(int on);
 int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
                          int64_t *reranked_halftiles_host);
+/* Grid search (dims 4 / 8 with a codebook cache), last call on `workspace`, synchronous copy: out4 = { leaves visited summed over
+ * the rows (counted only after gqhip_debug_enable(1)), codes that received the reference's arithmetic (likewise), rows handed to
+ * the block-wide scan, 1 if `cb_cache_or_null` holds a current index / 0 if not / -1 without a cache }.  A leaf is ~n / 4096 codes. */
+int gqhip_debug_grid(const void *workspace, const void *cb_cache_or_null, int64_t *out4_host);
 #ifdef __cplusplus
 }
 #endif

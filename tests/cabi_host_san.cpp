@@ -48,14 +48,14 @@ int main() {
   }
   // every entry point with NULL pointers / bad sizes: a status, never a dereference (rows == 0 returns OK before any check of the pointers)
   int bad = 0;
-  bad += gq_argmax_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 16, 4, 1024, 1.0, nullptr, 0, nullptr) == GQHIP_OK;
-  bad += gq_argmax_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 16, -1, 1024, 1.0, nullptr, 0, nullptr) == GQHIP_OK;
-  bad += gq_argmax_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 16, 0, 1024, 1.0, nullptr, 0, nullptr) != GQHIP_OK;
+  bad += gq_argmax_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 16, 4, 1024, 1.0, nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;
+  bad += gq_argmax_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 16, -1, 1024, 1.0, nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;
+  bad += gq_argmax_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 16, 0, 1024, 1.0, nullptr, 0, nullptr, 0, nullptr) != GQHIP_OK;
   bad += gq_scores_f32(nullptr, nullptr, nullptr, nullptr, 16, 4, 1024, 1.0, nullptr) == GQHIP_OK;
   bad += gq_quantize_z_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 16, 16, 16, 1024, 0, 0, -30.0, 20.0,
-                           1.0, nullptr, 0, nullptr) == GQHIP_OK;
+                           1.0, nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;
   bad += gq_dequant_f32(nullptr, nullptr, nullptr, 1, 16, 1, 16, 1024, 0, 0, nullptr) == GQHIP_OK;
-  bad += vq_argmin_f32(nullptr, nullptr, nullptr, nullptr, 16, 4, 1024, nullptr, 0, nullptr) == GQHIP_OK;
+  bad += vq_argmin_f32(nullptr, nullptr, nullptr, nullptr, 16, 4, 1024, nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;
   bad += lfq_pack_f32(nullptr, nullptr, nullptr, 4, 16, nullptr) == GQHIP_OK;
   bad += lfq_pack_f32(nullptr, nullptr, nullptr, 4, 63, nullptr) == GQHIP_OK;
   bad += lfq_unpack_f32(nullptr, nullptr, 4, 0, nullptr) == GQHIP_OK;

@@ -65,11 +65,11 @@ int main() {
   CHECK_HIP(hipMemcpyAsync(d_cb, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, st));
 
   // error paths first: status codes, no crash
-  if (gq_argmax_f32(d_mu, d_sd, nullptr, d_cb, d_idx, d_zhat, dim, rows, n, beta, d_ws, 16, st) != GQHIP_ERR_WORKSPACE) return 4;
-  if (gq_argmax_f32(nullptr, d_sd, nullptr, d_cb, d_idx, d_zhat, dim, rows, n, beta, d_ws, ws_bytes, st) != GQHIP_ERR_INVALID_ARG) return 5;
+  if (gq_argmax_f32(d_mu, d_sd, nullptr, d_cb, d_idx, d_zhat, dim, rows, n, beta, d_ws, 16, nullptr, 0, st) != GQHIP_ERR_WORKSPACE) return 4;
+  if (gq_argmax_f32(nullptr, d_sd, nullptr, d_cb, d_idx, d_zhat, dim, rows, n, beta, d_ws, ws_bytes, nullptr, 0, st) != GQHIP_ERR_INVALID_ARG) return 5;
 
   CHECK_GQ(gq_argmax_f32(d_mu, d_sd, nullptr, d_cb, d_idx, d_zhat, dim, rows, n, beta,
-                         d_ws, ws_bytes, st));
+                         d_ws, ws_bytes, nullptr, 0, st));
   CHECK_GQ(gq_dequant_f32(d_idx, d_cb, d_deq, /*B*/ 1, /*L*/ rows, /*K*/ 1, dim, n, GQHIP_LAYOUT_BLC,
                           GQHIP_GROUP_STRIDED, st));
   CHECK_GQ(gq_scores_f32(d_mu, d_sd, d_cb, d_out, dim, 64, n, (double)beta, st));
@@ -108,7 +108,7 @@ int main() {
   int64_t *d_idx2;
   CHECK_HIP(hipMalloc(&d_ws2, ws2_bytes));
   CHECK_HIP(hipMalloc(&d_idx2, rows * 8));
-  CHECK_GQ(gq_argmax_f32(d_mu, d_sd, nullptr, d_cb, d_idx2, nullptr, dim, rows, n, beta, d_ws2, ws2_bytes, st));
+  CHECK_GQ(gq_argmax_f32(d_mu, d_sd, nullptr, d_cb, d_idx2, nullptr, dim, rows, n, beta, d_ws2, ws2_bytes, nullptr, 0, st));
   CHECK_GQ(gqhip_set_filter(GQHIP_FILTER_AUTO));
   if (gqhip_set_filter(7) != GQHIP_ERR_INVALID_ARG) return 7;
   std::vector<int64_t> idx2(rows);

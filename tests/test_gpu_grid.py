@@ -1,0 +1,247 @@
+"""-m gpu: the pruned exact search of dims 4 / 8 (csrc/gq_grid.h; BASELINE configs[3]: sd3unet_gq_1.00 / gq_0.50) through the C ABI
+against the CPU oracle -- bit-exact indices whatever the codebook looks like --, the codebook cache's self-validation (edits in
+place, other codebooks, clobbered buffers), the rows it hands to the block-wide scan, and the pruning itself (leaves visited).
+Reference arithmetic: pit/quantization/gaussian.py:136-150 (torch backend), vq.py:58-73."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rows(rows, dim, seed, kind="trained"):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "trained":        # ~1.1 bit per dimension
+        mu = 0.9 * torch.randn(rows, dim, generator=g)
+        sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(rows, dim, generator=g)))
+    elif kind == "linear":       # seeded-random weights: sigma ~ 1, A ~ 0 of either sign: the score is nearly linear in n
+        mu = 0.3 * torch.randn(rows, dim, generator=g)
+        sd = torch.exp(0.5 * (0.1 * torch.randn(rows, dim, generator=g)))
+    elif kind == "convex":       # sigma > 1: A > 0 on every axis, the maximum sits in a corner of the codebook
+        mu = torch.randn(rows, dim, generator=g)
+        sd = 1.5 + torch.rand(rows, dim, generator=g)
+    elif kind == "wide":         # sigma over 5 decades, large means
+        mu = 3.0 * torch.randn(rows, dim, generator=g)
+        sd = torch.exp(torch.rand(rows, dim, generator=g) * 11.5 - 9.2)
+    else:
+        raise ValueError(kind)
+    return mu.contiguous(), sd.contiguous()
+
+
+def _books(n, dim, which, seed=3):
+    rng = np.random.default_rng(seed)
+    if which == "sobol":
+        return O.codebook(n, dim, 42)
+    if which == "uniform":
+        return rng.uniform(-3, 3, (n, dim)).astype(np.float32)
+    if which == "scaled":
+        return (O.codebook(n, dim, 42) * np.float32(37.5) + np.float32(4.0)).astype(np.float32)
+    if which == "clustered":     # two tight clusters: almost every leaf empty, two overfull
+        c = rng.normal(0, 1e-3, (n, dim)).astype(np.float32)
+        c[n // 2:] += np.float32(2.0)
+        return c
+    if which == "identical":     # zero variance on every axis: ONE leaf holds the whole book; first index wins everywhere
+        return np.tile(rng.normal(0, 1, (1, dim)).astype(np.float32), (n, 1))
+    if which == "duplicates":    # every code twice: ties decided by the lower index
+        h = O.codebook(n // 2, dim, 42)
+        return np.concatenate([h, h], 0)
+    raise ValueError(which)
+
+
+def _gq(mu, sd, cb, beta=1.0, ws=None):
+    from pit_hip import _lib
+
+    ws = ws or _lib.Workspace()
+    lsd = O.torch_log(sd.numpy())
+    idx, zhat = _lib.gq_argmax(mu.to(DEV), sd.to(DEV), cb if torch.is_tensor(cb) else torch.from_numpy(cb).to(DEV), beta,
+                               logsd=torch.from_numpy(lsd).to(DEV), ws=ws)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), zhat.cpu().numpy(), lsd, ws
+
+
+def _uses_grid(ws):
+    return ws.cache_buf is not None
+
+
+@pytest.mark.parametrize("which", ["sobol", "uniform", "scaled", "clustered", "duplicates"])
+@pytest.mark.parametrize("kind", ["trained", "linear", "convex", "wide"])
+@pytest.mark.parametrize("dim,n,rows", [(4, 65536, 1000), (8, 65536, 777), (4, 16384, 37), (8, 100000, 300), (4, 70001, 130)])
+def test_grid_indices_bit_exact_for_any_codebook(dim, n, rows, kind, which):
+    from pit_hip import _lib
+
+    cb = _books(n, dim, which)
+    mu, sd = _rows(rows, dim, 11 * dim + rows, kind)
+    for beta in (1.0, 0.0):
+        idx, zhat, lsd, ws = _gq(mu, sd, cb, beta)
+        assert _uses_grid(ws) and _lib.debug_grid(ws)["index_current"] == 1
+        ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb, beta, logstd=lsd)
+        assert np.array_equal(idx, ref_idx), (kind, which, beta, int((idx != ref_idx).sum()))
+        assert np.array_equal(zhat, ref_zhat)
+
+
+def test_grid_one_leaf_holds_the_whole_codebook():
+    """A codebook of identical codes (zero variance: every threshold equals the mean, one leaf of n codes): every row's arg-max is
+    index 0 (first maximum wins, torch.argmax), found by walking that one leaf."""
+    cb = _books(16384, 4, "identical")
+    mu, sd = _rows(48, 4, 5)
+    idx, zhat, lsd, ws = _gq(mu, sd, cb)
+    assert (idx == 0).all() and np.array_equal(zhat, np.tile(cb[:1], (48, 1)))
+
+
+@pytest.mark.parametrize("dim", [4, 8])
+def test_grid_vq_matches_the_fp64_arbiter(dim):
+    from pit_hip import _lib
+
+    g = torch.Generator().manual_seed(7)
+    emb = torch.randn(65536, dim, generator=g)
+    z = 1.3 * torch.randn(2000, dim, generator=g)
+    z[:300] = emb[torch.randint(0, 65536, (300,), generator=g)] + 1e-4 * torch.randn(300, dim, generator=g)
+    ws = _lib.Workspace()
+    idx, zq = _lib.vq_argmin(z.to(DEV), emb.to(DEV), ws=ws)
+    assert _uses_grid(ws)
+    oi = O.vq_argmin_rows(z.numpy(), emb.numpy())
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(zq.cpu().numpy(), emb.numpy()[oi])
+
+
+def test_grid_rows_that_go_to_the_block_scan():
+    """Rows the search does not decide: non-finite operands (exhaustive semantics: NaN counts as the maximum, first NaN wins) and a
+    flat score (mu = 0, sigma = 1, beta = 1: A = B = 0 -- every code within the margin, the leaf cap trips and the whole block
+    scans).  Same indices as the oracle; the other rows of the same blocks are untouched."""
+    from pit_hip import _lib
+
+    dim, n, rows = 4, 65536, 200
+    cb = O.codebook(n, dim, 42)
+    mu, sd = _rows(rows, dim, 3)
+    mu[5] = 0.0; sd[5] = 1.0                      # flat
+    mu[17, 2] = float("nan")
+    mu[40, 0] = float("inf")
+    sd[63, 1] = 0.0
+    sd[64, 3] = float("inf")
+    mu[150] = 0.0; sd[150] = 1.0
+    idx, zhat, lsd, ws = _gq(mu, sd, cb)
+    g = _lib.debug_grid(ws)
+    assert g["scanned_rows"] >= 6
+    finite = np.ones(rows, bool)
+    finite[[17, 40, 63, 64]] = False
+    ref_idx, _ = O.argmax_rows(mu.numpy()[finite], sd.numpy()[finite], cb, 1.0, logstd=lsd[finite])
+    assert np.array_equal(idx[finite], ref_idx)
+    # non-finite rows: the score matrix's own arg-max in torch order (the reference's torch backend raises on them; its CUDA backend
+    # would return this -- DESIGN.md, documented deviation)
+    s = O.score_matrix(mu.numpy()[~finite], sd.numpy()[~finite], cb, 1.0, logstd=lsd[~finite])
+    want = [int(np.argmax(np.isnan(r))) if np.isnan(r).any() else int(np.argmax(r)) for r in s]
+    assert idx[~finite].tolist() == want
+
+
+def test_grid_non_finite_codebook_means_every_row_is_scanned():
+    from pit_hip import _lib
+
+    dim, n = 4, 16384
+    cb = O.codebook(n, dim, 42).copy()
+    cb[777, 1] = np.nan
+    mu, sd = _rows(40, dim, 9)
+    idx, zhat, lsd, ws = _gq(mu, sd, cb)
+    assert _lib.debug_grid(ws)["scanned_rows"] == 40
+    assert (idx == 777).all()                     # NaN score counts as the maximum (torch.argmax)
+
+
+def test_codebook_cache_validates_itself():
+    """The cache is keyed on nothing the caller tells us: a codebook edited in place through .data (no version bump), another
+    codebook through the same Workspace, and a cache buffer overwritten with garbage all give the right answer on the very next
+    call, and an unchanged codebook does NOT rebuild (the builder exits: the sorted arrays are bit-identical afterwards)."""
+    from pit_hip import _lib
+
+    dim, n, rows = 4, 65536, 512
+    cb0 = O.codebook(n, dim, 42)
+    cbt = torch.from_numpy(cb0.copy()).to(DEV)
+    mu, sd = _rows(rows, dim, 21)
+    ws = _lib.Workspace()
+
+    def check(cb_np):
+        idx, zhat, lsd, _ = _gq(mu, sd, cbt, ws=ws)
+        ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb_np, 1.0, logstd=lsd)
+        assert np.array_equal(idx, ref_idx) and np.array_equal(zhat, ref_zhat)
+        return idx
+
+    i0 = check(cb0)
+    snap = ws.cache_buf.clone()
+    check(cb0)
+    assert torch.equal(ws.cache_buf, snap)                         # nothing was rebuilt
+    # (1) an edit through .data: one coordinate of the winner of row 0 pushed far away
+    cb1 = cb0.copy()
+    cb1[i0[0], 0] += 50.0
+    cbt.data[int(i0[0]), 0] += 50.0
+    i1 = check(cb1)
+    assert i1[0] != i0[0] and not torch.equal(ws.cache_buf, snap)
+    # (2) a swap of two codes (same multiset of values: only a position-salted hash sees it)
+    a, b = int(i1[1]), int((i1[1] + 12345) % n)
+    cb2 = cb1.copy()
+    cb2[[a, b]] = cb2[[b, a]]
+    cbt.data[[a, b]] = cbt.data[[b, a]]
+    check(cb2)
+    # (3) garbage in the cache buffer (a caller that reused the memory)
+    ws.cache_buf.copy_(torch.randint(0, 255, ws.cache_buf.shape, dtype=torch.uint8, device=DEV))
+    check(cb2)
+    # (4) garbage everywhere but the stamp: header intact, sorted arrays destroyed -> the hash still matches, so this is the one
+    #     thing the contract forbids (the caller must not write the buffer); a REBUILD request through a zeroed stamp repairs it
+    ws.cache_buf[:4096].zero_()
+    check(cb2)
+    # (5) another codebook of the same shape through the same workspace
+    cb3 = np.random.default_rng(0).normal(0, 1, (n, dim)).astype(np.float32)
+    cbt.data.copy_(torch.from_numpy(cb3))
+    check(cb3)
+
+
+def test_grid_path_is_graph_capturable_and_sees_edits_on_replay():
+    from pit_hip import _lib
+
+    dim, n, rows = 4, 65536, 256
+    cb0 = O.codebook(n, dim, 42)
+    cbt = torch.from_numpy(cb0.copy()).to(DEV)
+    mu, sd = _rows(rows, dim, 33)
+    lsd = O.torch_log(sd.numpy())
+    mud, sdd, lsdd = mu.to(DEV), sd.to(DEV), torch.from_numpy(lsd).to(DEV)
+    ws = _lib.Workspace()
+    _lib.gq_argmax(mud, sdd, cbt, 1.0, logsd=lsdd, ws=ws)          # warm-up: buffers sized, index built
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            idx, zhat = _lib.gq_argmax(mud, sdd, cbt, 1.0, logsd=lsdd, ws=ws)
+    g.replay()
+    torch.cuda.synchronize()
+    ref, _ = O.argmax_rows(mu.numpy(), sd.numpy(), cb0, 1.0, logstd=lsd)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    cb1 = cb0.copy()
+    cb1[ref[0], :] += 30.0
+    cbt.data[int(ref[0]), :] += 30.0
+    g.replay()                                                     # the captured builder sees the new hash and rebuilds
+    torch.cuda.synchronize()
+    ref1, _ = O.argmax_rows(mu.numpy(), sd.numpy(), cb1, 1.0, logstd=lsd)
+    assert np.array_equal(idx.cpu().numpy(), ref1) and ref1[0] != ref[0]
+
+
+@pytest.mark.parametrize("dim,kind,limit", [(4, "trained", 12.0), (4, "linear", 16.0), (8, "trained", 120.0), (8, "linear", 220.0)])
+def test_grid_prunes(dim, kind, limit):
+    """The point of the formulation: leaves visited per row (of 4096; a leaf = 16 codes of the 65 536).  CPU study
+    (tools/grid_prune_study.py): 5-6 at dim 4, 54-95 at dim 8; the gate is 2x that."""
+    from pit_hip import _lib
+
+    cb = O.codebook(65536, dim, 42)
+    mu, sd = _rows(8192, dim, 77, kind)
+    _lib.debug_enable(True)
+    try:
+        idx, zhat, lsd, ws = _gq(mu, sd, cb)
+        g = _lib.debug_grid(ws)
+    finally:
+        _lib.debug_enable(False)
+    per_row = g["leaves"] / 8192
+    print(f"dim {dim}, {kind}: {per_row:.1f} leaves and {g['exact_codes'] / 8192:.2f} exactly scored codes per row, "
+          f"{g['scanned_rows']} rows scanned")
+    assert per_row <= limit and g["scanned_rows"] == 0
+    ref_idx, _ = O.argmax_rows(mu.numpy()[:1024], sd.numpy()[:1024], cb, 1.0, logstd=lsd[:1024])
+    assert np.array_equal(idx[:1024], ref_idx)

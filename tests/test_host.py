@@ -38,7 +38,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(dll, name), f"libgqhip.so does not export {name}"
     assert declared == set(L.EXPORTED_SYMBOLS), "python binding and header disagree"
-    assert L.lib().gqhip_abi_version() == L.ABI_VERSION == 6
+    assert L.lib().gqhip_abi_version() == L.ABI_VERSION == 7
     assert L.lib().gqhip_status_string(2) == b"workspace missing or too small"
 
 
@@ -66,7 +66,7 @@ def test_workspace_sizing_is_host_only_and_monotone():
 
 def test_invalid_arguments_return_status_not_crash():
     L = _lib().lib()
-    assert L.gq_argmax_f32(None, None, None, None, None, None, 16, 4, 1024, 1.0, None, 0, None) == 1
+    assert L.gq_argmax_f32(None, None, None, None, None, None, 16, 4, 1024, 1.0, None, 0, None, 0, None) == 1
     assert L.gq_scores_f32(None, None, None, None, 16, 4, 1024, 1.0, None) == 1
     assert L.lfq_pack_f32(None, None, None, 4, 16, None) == 1
 

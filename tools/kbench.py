@@ -57,6 +57,17 @@ def main():
     ex = {1: 3, 2: 2, 3: 1}.get(kind, 1)   # bf16-rate MACs executed per algorithmic MAC (fp16 + fp8: 1 fp16 + 2 fp8 at twice the rate)
     rate = (f"{tf:.1f} algorithmic TFLOP/s = {tf/157.3:.2f}x the fp32 MFMA peak; executed {ex}x = {ex*tf:.0f} TFLOP/s bf16-equivalent "
             f"({ex*tf/2500*100:.1f}% of 2500)") if bf16 else f"{tf:.1f} TFLOP/s ({tf/157.3*100:.1f}% of 157.3)"
+    if ws.cache_buf is not None and (a.filter in (None, "auto")):     # dims 4 / 8: the pruned search replaced filter + re-rank
+        _lib.debug_enable(True)
+        _lib.gq_argmax(mu, sd, cb, 1.0, ws=ws)
+        torch.cuda.synchronize()
+        gs = _lib.debug_grid(ws)
+        _lib.debug_enable(False)
+        print(f"rows={a.rows} dim={a.dim} n={a.n}: grid search kernel (gq_grid.h) {kms*1e3:.1f} us avg over {launches} launches -> "
+              f"{tf:.1f} algorithmic TFLOP/s-equivalent ({tf/2500*100:.1f}% of the 2500 the dense form is priced against); "
+              f"{gs['leaves'] / a.rows:.1f} of 4096 leaves and {gs['exact_codes'] / a.rows:.2f} exactly scored codes per row, "
+              f"{gs['scanned_rows']} rows scanned by their block; whole call wall {wall*1e6:.1f} us")
+        return
     print(f"rows={a.rows} dim={a.dim} n={a.n}: {('fp32', 'split-bf16', 'fp16+fp8', 'fp16 main product')[kind]} filter kernel {kms*1e3:.1f} us avg over "
           f"{launches} launches -> {rate}; "
           f"whole call wall {wall*1e6:.1f} us; fallback rows {fb}, re-ranked half-tiles/row {rr/a.rows:.3f}")

@@ -12,7 +12,7 @@ def short(name, n=90):
     return name if len(name) <= n else name[:n] + "..."
 
 
-for tag in ("bench_trace", "kbench_trace", "kbench_fp32_trace", "variants_trace"):
+for tag in ("bench_trace", "kbench_trace", "kbench_fp32_trace", "variants_trace", "trace"):
     files = glob.glob(os.path.join(out, tag, "**", "*kernel_stats.csv"), recursive=True)
     print(f"== {tag}: kernel stats (top 25 by total time) ==")
     for f in files:

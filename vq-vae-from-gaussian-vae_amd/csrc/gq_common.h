@@ -63,22 +63,33 @@ __device__ __forceinline__ double rec_value(float m1, unsigned short gap) {
   return (double)m1 - (double)(float)__builtin_bit_cast(_Float16, gap);
 }
 
-// Workspace header (first 4 KiB of the caller's workspace).  Everything in it is (re)written by the kernels of ONE
+// Workspace header (first 8 KiB of the caller's workspace).  Everything in it is (re)written by the kernels of ONE
 // call: gq_prep_kernel resets the counters and writes the max|cb| partials, the re-rank reduces them per wave.
 // Nothing here is read across calls.
 constexpr int kAbsmaxParts = 256;
 struct WsHeader {
   int fb_count;                       // rows the candidates could not decide (finished by the in-block scan; exhaustive kernel: its list)
   int pad0;
-  unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly
-  int pad1[28];
+  unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly (grid search: codes given the reference's arithmetic)
+  unsigned long long grid_leaves;     // grid search (gq_grid.h), debug statistics: leaves visited, summed over the rows
+  int pad1[26];
   float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
   int pad2[128];
   float r2_part[kAbsmaxParts];        // max squared code norm per code block (fp16 filter's norm bound, gq_rerank.h)
   int pad3[256];
+  unsigned long long cbsum[kAbsmaxParts];   // content hash of the codebook slice each code block of gq_prep_kernel read in THIS call
+                                            // (what the codebook cache is validated against and stamped with: gq_grid.h, gq_prep.h)
+  int pad4[512];
 };
-static_assert(sizeof(WsHeader) == 4096, "header is 4 KiB");
+static_assert(sizeof(WsHeader) == 8192, "header is 8 KiB");
+
+// Position-salted content hash of a run of fp32 words (codebook cache validation): sum of bits(x_i) + c times an odd multiplier
+// derived from i, modulo 2^64 -- any single changed word and any swap of two different words changes the sum.
+__device__ __forceinline__ unsigned long long cb_hash_term(float x, long i) {
+  const unsigned long long b = (unsigned long long)__float_as_uint(x) + 0x9e3779b97f4a7c15ull;
+  return b * (((unsigned long long)i * 0xd1342543de82ef95ull) | 1ull);
+}
 
 // Insert (t, id) into a descending top-4 (ids kept for the top 3 only).
 __device__ __forceinline__ void top4_insert(float t, int id, float &m1, float &m2, float &m3, float &m4,

@@ -1,0 +1,747 @@
+// gq_grid.h -- the fused arg-max at dim 4 (round 5; templated for dim 8): an exact, PRUNED search over a spatial index of the
+// codebook instead of the dense rows x codes product.
+//
+// Why (profiles/r04/pmc_filter_gq_1.00_dim4_round3_kernels.txt): at K_eff = 2 dim = 8 .. 16 the dense MFMA filter is
+// bound by the VALU fold of its own outputs (>= 8 v_max3 per 32-cycle MFMA), not by the matrix cores -- no schedule fixes that.
+// But 65 536 codes are DENSE in 4 dimensions: the score  f(r, j) = sum_i A_ri n_ji^2 + B_ri n_ji  is a quadratic per coordinate,
+// so its maximum over an axis-aligned BOX of codes is a closed form, and almost every box is far below the row's best code.  The
+// codebook is therefore sorted once into a two-level tree of boxes -- 16 nodes x 64 = 1024 leaves of ~64 codes, TIGHT bounding
+// boxes of their actual members (the quantile cells themselves are useless in the near-linear regime of sigma ~ 1:
+// profiles/r05/grid_prune_study.txt) -- and a row first walks greedily to its most promising leaf (a good F), then visits every
+// leaf whose upper bound is not below  F - margin.  ALL boxes and code ranges sit in LDS (37 KiB at dim 4), so the only global
+// reads of a row are its own operands and the codes of the leaves it visits: the search is a chain of dependent round trips of
+// ~1 us each on a busy chip, and the variants with a tree level in global memory spent their time exactly there
+// (profiles/r05/grid_search_variants.txt).
+//
+// Exactness is unchanged -- the reference's own arithmetic still decides (gq_common.h:ref_term / gq_rerank.h:ref_score_lds):
+//   * f^(j) = the fp32 FMA expansion of f (pass 1 of the re-rank: |f^ - f| <= E32 = (2 dim + 4) u T);  E_r bounds the reference
+//     score's own rounding (gq_rerank.h:row_bound);  margin32 = 2.5 (E32 + E_r).
+//   * The reference's arg-max j* has f(j*) >= f(j^) - 2 E_r for every code j^, in particular for the one that set F:
+//     f(j*) >= F - E32 - 2 E_r.  Every box that contains j* has a true upper bound >= f(j*); its computed bound U^ is below the true
+//     one by at most (dim + 1) u T <= E32 (one FMA pair per axis evaluated at a point of the box, dim - 1 additions), so
+//     U^ >= F - 2 E32 - 2 E_r >= F - margin32: the box is visited, at either level, whatever F was at the time (F only grows).
+//   * Inside a leaf, j* has f^(j*) >= F - 2 E32 - 2 E_r >= F - margin32 as well, so it receives the reference's arithmetic; the
+//     winner among everything that did is taken in torch.argmax order (score, then lowest index; NaN first).
+//   * Rows with a non-finite operand or bound, any non-finite codebook (max|cb| not finite) and rows whose leaf list overflows
+//     (a flat score: everything within the margin) are finished by the whole block with a scan of ALL codes -- the re-rank's
+//     exhaustive semantics -- after the block's other rows have left.
+//
+// The index lives in a caller-owned, persistent buffer (the "codebook cache": gqhip_cb_cache_bytes), is validated on EVERY call
+// against a content hash of the codebook the caller passes (the first launch hashes it anyway while it reduces max|cb|), and is
+// rebuilt in-stream by a one-block kernel when the hash -- or the buffer's own stamp -- does not match: a codebook edited in place
+// by any route is seen by the very next call, a fresh or clobbered buffer costs one rebuild.
+#pragma once
+#include <type_traits>
+
+#include "gq_common.h"
+#include "gq_rerank.h"
+
+namespace gqhip {
+
+constexpr unsigned kGridMagic = 0x47514732u;
+constexpr int kGridLanes = 16;                     // lanes per row (one DPP row)
+constexpr int kGridL1 = 16, kGridL2 = 256, kGridLeaves = 1024;    // 16 nodes x 16 nodes x 4 leaves
+constexpr int kGridFan2 = kGridLeaves / kGridL1;                    // leaves under an L1 node
+constexpr int kGridBuildThreads = 1024;
+constexpr int kGridL2Cap = 32, kGridLeafCap = 48;  // list capacities of the search (a row beyond them goes to the block-wide scan)
+
+struct GridHdr {                                   // first 4 KiB of the codebook cache
+  unsigned magic;
+  int n, dim;
+  int stale;                                       // set by the first launch when the codebook's hash differs; cleared by the builder
+  int pad0[12];
+  float thr[8][8];                                 // per axis: the (cells - 1) ascending thresholds of its coordinate, rest +inf
+  unsigned long long blk_sum[kAbsmaxParts];        // hash of the codebook slice of prep's code block k when the index was built
+  int pad1[432];
+};
+static_assert(sizeof(GridHdr) == 4096, "cache header is 4 KiB");
+
+struct GridLayout {
+  int64_t hdr, box1, box2, box3, start, scb, sidx, total;      // box1 | box2 | box3 | start are contiguous: one linear copy into LDS
+};
+__host__ __device__ inline int64_t grid_align(int64_t v) { return (v + 255) / 256 * 256; }
+__host__ __device__ inline GridLayout grid_layout(int64_t n, int64_t dim) {
+  GridLayout g{};
+  int64_t off = 0;
+  g.hdr = off;   off += (int64_t)sizeof(GridHdr);
+  g.box1 = off;  off += kGridL1 * 2 * dim * 4;
+  g.box2 = off;  off += kGridL2 * 2 * dim * 4;
+  g.box3 = off;  off += (int64_t)kGridLeaves * 2 * dim * 4;
+  g.start = off; off += grid_align((kGridLeaves + 16) * 4);
+  g.scb = off;   off += grid_align(n * dim * 4);
+  g.sidx = off;  off += grid_align(n * 4);
+  g.total = off;
+  return g;
+}
+
+// cells per axis: dim 4: 8 x 8 x 4 x 4; dim 8: 4 x 4 x 2 x 2 x 2 x 2 x 2 x 2 -- 1024 leaves either way, and for a scrambled-Sobol
+// codebook of 65 536 points mapped through the normal quantile (pit/quantization/gaussian.py:15-19) exactly 64 codes in each (a
+// (t, m, s)-net: every elementary interval holds its share).  Leaf id = l1 * 64 + l2 * 4 + l3 (three levels of boxes: 16 -> 256 ->
+// 1024): l1 = the top bit of the coordinates of axes 0..3; dim 4: l2 = the second bit of axes 0, 1 and the low bit of axes 2, 3,
+// l3 = the low bit of axes 0, 1; dim 8: l2 = the low bit of axes 0, 1 and the bits of axes 4, 5, l3 = the bits of axes 6, 7.
+template <int DIM> __device__ __forceinline__ int grid_cells_of_axis(int i) { return DIM == 4 ? (i < 2 ? 8 : 4) : (i < 2 ? 4 : 2); }
+
+template <int DIM>
+__device__ __forceinline__ int grid_leaf_of(const float (&x)[DIM], const float (*thr)[8]) {
+  int c[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    int k = 0;
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+      if (t < grid_cells_of_axis<DIM>(i) - 1) k += x[i] >= thr[i][t] ? 1 : 0;       // NaN: 0
+    c[i] = k;
+  }
+  int l1, l2, l3;
+  if constexpr (DIM == 4) {
+    l1 = (c[0] >> 2) | ((c[1] >> 2) << 1) | ((c[2] >> 1) << 2) | ((c[3] >> 1) << 3);
+    l2 = ((c[0] >> 1) & 1) | (((c[1] >> 1) & 1) << 1) | ((c[2] & 1) << 2) | ((c[3] & 1) << 3);
+    l3 = (c[0] & 1) | ((c[1] & 1) << 1);
+  } else {
+    l1 = (c[0] >> 1) | ((c[1] >> 1) << 1) | (c[2] << 2) | (c[3] << 3);
+    l2 = (c[0] & 1) | ((c[1] & 1) << 1) | (c[4] << 2) | (c[5] << 3);
+    l3 = c[6] | (c[7] << 1);
+  }
+  return (l1 * 16 + l2) * 4 + l3;
+}
+
+// ---------------------------------------------------------------------------------------------------- builder (one block)
+struct GridBuildParams {
+  const float *cb;
+  char *cache;            // the codebook cache (grid_layout)
+  const WsHeader *hdr;    // this call's workspace header: cbsum[] = the hashes the first launch just computed
+  int n;
+};
+
+template <int DIM>
+__global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const GridBuildParams p) {
+  GridHdr *gh = reinterpret_cast<GridHdr *>(p.cache);
+  if (gh->magic == kGridMagic && gh->n == p.n && gh->dim == DIM && gh->stale == 0) return;   // (block-uniform) the index is current
+  const GridLayout L = grid_layout(p.n, DIM);
+  float *box1 = reinterpret_cast<float *>(p.cache + L.box1), *box2 = reinterpret_cast<float *>(p.cache + L.box2);
+  float *box3 = reinterpret_cast<float *>(p.cache + L.box3);
+  int *start = reinterpret_cast<int *>(p.cache + L.start);
+  float *scb = reinterpret_cast<float *>(p.cache + L.scb);
+  int *sidx = reinterpret_cast<int *>(p.cache + L.sidx);
+  constexpr int NT = kGridBuildThreads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double s_red[NT / 64][2 * DIM];
+  __shared__ float s_thr[8][8];
+  __shared__ int s_cnt[kGridLeaves];
+  __shared__ int s_wsum[NT / 64];
+
+  // ---- 1. per-axis mean / deviation -> thresholds at the normal quantiles (any thresholds are valid; these balance a Gaussian book)
+  double acc[2 * DIM];
+#pragma unroll
+  for (int i = 0; i < 2 * DIM; ++i) acc[i] = 0.0;
+  for (int j = tid; j < p.n; j += NT) {
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const double v = (double)p.cb[(long)j * DIM + i];
+      acc[i] += v;
+      acc[DIM + i] += v * v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * DIM; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) s_red[wave][i] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int i = tid >> 3, t = tid & 7;
+    float th = __builtin_inff();
+    if (i < DIM) {
+      double s = 0.0, q = 0.0;
+      for (int w = 0; w < NT / 64; ++w) { s += s_red[w][i]; q += s_red[w][DIM + i]; }
+      const double mean = s / p.n;
+      const double var = q / p.n - mean * mean;
+      const double sd = sqrt(var > 0.0 ? var : 0.0);
+      const int cells = grid_cells_of_axis<DIM>(i);
+      // N(0,1) quantiles k / cells
+      const double q8[7] = {-1.1503493803760079, -0.6744897501960817, -0.3186393639643752, 0.0, 0.3186393639643752,
+                            0.6744897501960817, 1.1503493803760079};
+      const double q4[3] = {-0.6744897501960817, 0.0, 0.6744897501960817};
+      if (t < cells - 1) th = (float)(mean + sd * (cells == 8 ? q8[t] : (cells == 4 ? q4[t] : 0.0)));
+    }
+    s_thr[i][t] = th;
+    gh->thr[i][t] = th;
+  }
+  for (int c = tid; c < kGridLeaves; c += NT) s_cnt[c] = 0;
+  __syncthreads();
+
+  // ---- 2. leaf histogram
+  auto leaf_of_code = [&](int j) {
+    float x[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) x[i] = p.cb[(long)j * DIM + i];
+    return grid_leaf_of<DIM>(x, s_thr);
+  };
+  for (int j = tid; j < p.n; j += NT) atomicAdd(&s_cnt[leaf_of_code(j)], 1);
+  __syncthreads();
+
+  // ---- 3. exclusive scan of the leaf counters (one per thread) -> start[], cursors in s_cnt
+  {
+    constexpr int PER = kGridLeaves / NT;
+    static_assert(kGridLeaves % NT == 0, "whole counters per thread");
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { loc[k] = s_cnt[tid * PER + k]; sum += loc[k]; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    int run = base + inc - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      start[tid * PER + k] = run;
+      s_cnt[tid * PER + k] = run;
+      run += loc[k];
+    }
+    if (tid == NT - 1) start[kGridLeaves] = run;
+  }
+  __syncthreads();
+
+  // ---- 4. scatter the codes into leaf order (order inside a leaf: arbitrary -- the search's result does not depend on it)
+  for (int j = tid; j < p.n; j += NT) {
+    float x[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) x[i] = p.cb[(long)j * DIM + i];
+    const int pos = atomicAdd(&s_cnt[grid_leaf_of<DIM>(x, s_thr)], 1);
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) scb[(long)pos * DIM + i] = x[i];
+    sidx[pos] = j;
+  }
+  __threadfence();
+  __syncthreads();
+
+  // ---- 5. tight bounding boxes, bottom-up ([lo | hi]; an empty node: lo = +inf, hi = -inf)
+  const float INF = __builtin_inff();
+  for (int c = tid; c < kGridLeaves; c += NT) {
+    float lo[DIM], hi[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { lo[i] = INF; hi[i] = -INF; }
+    const int s = start[c], e = start[c + 1];
+    for (int j = s; j < e; ++j) {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        const float v = scb[(long)j * DIM + i];
+        lo[i] = __builtin_fminf(lo[i], v);
+        hi[i] = __builtin_fmaxf(hi[i], v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { box3[(long)c * 2 * DIM + i] = lo[i]; box3[(long)c * 2 * DIM + DIM + i] = hi[i]; }
+  }
+  __threadfence();
+  __syncthreads();
+  auto merge = [&](const float *child, float *parent, int node, int fan) {
+    float lo[DIM], hi[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { lo[i] = INF; hi[i] = -INF; }
+    for (int k = 0; k < fan; ++k) {
+      const float *b = child + (long)(node * fan + k) * 2 * DIM;
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) { lo[i] = __builtin_fminf(lo[i], b[i]); hi[i] = __builtin_fmaxf(hi[i], b[DIM + i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { parent[(long)node * 2 * DIM + i] = lo[i]; parent[(long)node * 2 * DIM + DIM + i] = hi[i]; }
+  };
+  if (tid < kGridL2) merge(box3, box2, tid, kGridLeaves / kGridL2);
+  __threadfence();
+  __syncthreads();
+  if (tid < kGridL1) merge(box2, box1, tid, kGridL2 / kGridL1);
+  if (tid < 15) start[kGridLeaves + 1 + tid] = p.n;      // padding of the start table (copied to LDS in 16-byte pieces)
+  // ---- 6. stamp: the hashes this call's first launch computed of the very codebook that was just indexed
+  if (tid < kAbsmaxParts) gh->blk_sum[tid] = p.hdr->cbsum[tid];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    gh->n = p.n;
+    gh->dim = DIM;
+    gh->stale = 0;
+    gh->magic = kGridMagic;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- the search
+struct GridParams {
+  const float *mu, *sd, *lsd;      // [rows, dim] (VQ: z in mu)
+  const double *rowsum;            // [rows, 4]
+  const float *coef;               // [rows, 2, dim]  A | B
+  const float *cb;                 // [n, dim] the caller's codebook (results, the block-wide scan)
+  const char *cache;               // the codebook cache
+  int64_t *idx;
+  float *zhat;                     // may be NULL
+  WsHeader *hdr;
+  int rows, n;
+  float beta;
+  int leaf_cap;                    // leaves a row may visit before it is handed to the block-wide scan
+  int stats;
+  int abl;                         // diagnostic builds only (GQHIP_ABL): 1 = no search, 2 = greedy descent only (wrong results, timing)
+  OutMap omap;
+};
+
+// max over the box [lo, hi] of sum_i A_i v_i^2 + B_i v_i: per axis at the clamped vertex (A < 0) or at the better endpoint
+template <int DIM>
+__device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float (&B)[DIM], const float (&M)[DIM], const float *box) {
+  float lo[DIM], hi[DIM];
+  const f32x4 *q = reinterpret_cast<const f32x4 *>(box);
+#pragma unroll
+  for (int k = 0; k < DIM / 4; ++k) {
+    const f32x4 a = q[k], b = q[DIM / 4 + k];
+    lo[4 * k] = a.x; lo[4 * k + 1] = a.y; lo[4 * k + 2] = a.z; lo[4 * k + 3] = a.w;
+    hi[4 * k] = b.x; hi[4 * k + 1] = b.y; hi[4 * k + 2] = b.z; hi[4 * k + 3] = b.w;
+  }
+  float u = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    const float vin = __builtin_amdgcn_fmed3f(M[i], lo[i], hi[i]);
+    const float e = __builtin_fmaf(A[i], hi[i] + lo[i], B[i]) > 0.0f ? hi[i] : lo[i];
+    const float v = A[i] < 0.0f ? vin : e;
+    u = __builtin_fmaf(__builtin_fmaf(A[i], v, B[i]), v, u);
+  }
+  return lo[0] <= hi[0] ? u : -__builtin_inff();     // empty node (or a NaN box: never visited; such books are scanned)
+}
+
+// Reductions over the 16 lanes of a DPP row (= one search group) without an LDS round trip: quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror -- afterwards every lane of the row holds the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = __builtin_fmaxf(v, dpp_row_f<0xB1>(v));
+  v = __builtin_fmaxf(v, dpp_row_f<0x4E>(v));
+  v = __builtin_fmaxf(v, dpp_row_f<0x141>(v));
+  v = __builtin_fmaxf(v, dpp_row_f<0x140>(v));
+  return v;
+}
+
+constexpr int kGridThreads = 512;      // 8 waves x 4 rows: 32 rows per block pass share one LDS copy of the tree; two blocks per CU
+
+// The whole block scans ALL codes for one row (the re-rank's exhaustive semantics): codes with f^ >= thr (or all: keep_all) get the
+// reference's arithmetic.  Inlined at the block's end.
+template <int MODE, int DIM>
+__device__ __forceinline__ void grid_finish_row_by_scan(const GridParams &p, long row, float thr, bool keep_all, const float *ops,
+                                                        double *sh_s, int *sh_i) {
+  constexpr int NT = kGridThreads;
+  const int tid = threadIdx.x;
+  float cA[DIM], cB[DIM];
+  {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(p.coef + row * 2 * DIM);
+#pragma unroll
+    for (int k = 0; k < DIM / 4; ++k) {
+      const f32x4 a = q[k], b = q[DIM / 4 + k];
+      cA[4 * k] = a.x; cA[4 * k + 1] = a.y; cA[4 * k + 2] = a.z; cA[4 * k + 3] = a.w;
+      cB[4 * k] = b.x; cB[4 * k + 1] = b.y; cB[4 * k + 2] = b.z; cB[4 * k + 3] = b.w;
+    }
+  }
+  double best_s = 0.0;
+  int best_i = 0x7fffffff;
+  bool have = false;
+  constexpr int U = 8;
+  for (int j0 = tid; j0 < p.n; j0 += NT * U) {
+    float n[U][DIM];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + NT * u;
+      const f32x4 *q = reinterpret_cast<const f32x4 *>(p.cb + (long)(j < p.n ? j : p.n - 1) * DIM);
+#pragma unroll
+      for (int k = 0; k < DIM / 4; ++k) {
+        const f32x4 v = q[k];
+        n[u][4 * k] = v.x; n[u][4 * k + 1] = v.y; n[u][4 * k + 2] = v.z; n[u][4 * k + 3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + NT * u;
+      float f = 0.0f;
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) f = __builtin_fmaf(__builtin_fmaf(cA[i], n[u][i], cB[i]), n[u][i], f);
+      if (j < p.n && (keep_all || !(f < thr))) {           // a NaN value passes
+        double sc;
+        if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(n[u], ops, p.beta);
+        else sc = vq_neg_dist(n[u], ops, DIM);
+        if (!have || better_d(sc, j, best_s, best_i)) { best_s = sc; best_i = j; have = true; }
+      }
+    }
+  }
+  __syncthreads();
+  sh_s[tid] = best_s;
+  sh_i[tid] = have ? best_i : 0x7fffffff;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if (tid < o) {
+      const double os = sh_s[tid + o];
+      const int oi = sh_i[tid + o];
+      const bool mine = sh_i[tid] != 0x7fffffff;
+      if (oi != 0x7fffffff && (!mine || better_d(os, oi, sh_s[tid], sh_i[tid]))) { sh_s[tid] = os; sh_i[tid] = oi; }
+    }
+    __syncthreads();
+  }
+  const int best = sh_i[0];
+  if (best != 0x7fffffff) {
+    if (tid == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best;
+    if (p.zhat && tid < DIM) p.zhat[out_zhat_offset(p.omap, row, tid, DIM)] = p.cb[(long)best * DIM + tid];
+  }
+  __syncthreads();
+}
+
+// 16 lanes per row, 4 rows per wave, 32 rows per block pass; blocks walk row sets.  The whole tree (three levels of boxes, the code
+// ranges of the leaves) sits in LDS.  A row: (1) greedy descent to ONE leaf -> F; (2) the L2 nodes, then the leaves, whose bound is
+// within the margin of F go to lists (LDS / VALU only); (3) the listed leaves, two per round trip: fp32 expansions, F and thr
+// tighten, the maximum of every batch is remembered; (4) with the FINAL threshold, only the batches that reached it are read again
+// (cache hits) and their codes within the margin get the reference's arithmetic -- one instance of that (long, divergent) code
+// per wave and pending code instead of one per batch and slot: the kernel is bound by VALU issue, not by memory
+// (profiles/r05/grid_search_variants.txt).
+template <int MODE, int DIM>
+__global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel(const GridParams p) {
+  constexpr int GROUP = kGridLanes;
+  constexpr int RPW = 64 / GROUP, RPB = (kGridThreads / 64) * RPW;
+  constexpr int BOXF = 2 * DIM;                         // floats per box: [lo | hi]
+  constexpr int TREE_F = (kGridL1 + kGridL2 + kGridLeaves) * BOXF;  // floats of box1 | box2 | box3
+  constexpr int START_N = kGridLeaves + 16;
+  constexpr int LPN = kGridLeaves / kGridL2;            // leaves per L2 node: 4
+  constexpr int CPL = 4;                                // codes per lane and leaf in one round (64-code leaves: one round)
+  constexpr int LEAF_U = 2;                             // leaves per round trip
+  __shared__ __attribute__((aligned(16))) float s_box[TREE_F];
+  __shared__ __attribute__((aligned(16))) int s_start[START_N];
+  __shared__ float s_ops[RPB][3 * DIM + 1];
+  __shared__ float s_zhat[RPB][DIM + 1];
+  __shared__ int s_l2list[RPB][kGridL2Cap];             // per row: L2 nodes / leaves whose bound is within the margin
+  __shared__ int s_leaflist[RPB][kGridLeafCap];
+  __shared__ float s_bmax[RPB][kGridLeafCap / LEAF_U];  // per batch of listed leaves: its largest f^
+  __shared__ int s_best[RPB];
+  __shared__ int s_scan[RPB];                           // 0: decided; 1: scan with threshold; 2: scan, keep everything
+  __shared__ float s_scan_thr[RPB];
+  __shared__ double sh_s[kGridThreads];
+  __shared__ int sh_i[kGridThreads];
+  const GridLayout L = grid_layout(p.n, DIM);
+  const float *scb = reinterpret_cast<const float *>(p.cache + L.scb);
+  const int *sidx = reinterpret_cast<const int *>(p.cache + L.sidx);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane % GROUP, grp = lane / GROUP, slot = wave * RPW + grp;
+  const int gshift = grp * GROUP;
+  auto group_bits = [&](bool c) { return (unsigned)((__ballot(c) >> gshift) & 0xffffull); };
+  auto group_max = [&](float v) { return row16_max(v); };
+  auto wave_sync_lds = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  {   // the whole tree -> LDS: box1 | box2 | box3 | start are contiguous in the cache (grid_layout)
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cache + L.box1);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(s_box);
+    for (int k = tid; k < TREE_F / 4; k += kGridThreads) dst[k] = src[k];
+    const f32x4 *src2 = reinterpret_cast<const f32x4 *>(p.cache + L.start);
+    f32x4 *dst2 = reinterpret_cast<f32x4 *>(s_start);
+    for (int k = tid; k < START_N / 4; k += kGridThreads) dst2[k] = src2[k];
+  }
+  const float *s_box2 = s_box + kGridL1 * BOXF, *s_box3 = s_box + (kGridL1 + kGridL2) * BOXF;
+  const float N1f = wave_absmax(p.hdr->absmax_part, lane);
+  const float NEG_INF = -__builtin_inff();
+  const int nsets = (p.rows + RPB - 1) / RPB;
+  __syncthreads();
+
+#ifdef GQHIP_CLOCK_STAMPS
+  unsigned long long st_[8];
+  int nst_ = 0;
+#define GQ_GRID_STAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (nst_ < 8) st_[nst_++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GQ_GRID_STAMP() do { } while (0)
+#endif
+  for (int vb = blockIdx.x; vb < nsets; vb += gridDim.x) {
+    GQ_GRID_STAMP();   // 0: row set starts
+    const long pos_raw = (long)vb * RPB + slot;
+    const bool live = pos_raw < p.rows;
+    const long row = live ? pos_raw : p.rows - 1;
+    // ---- row operands
+    float cA[DIM], cB[DIM], cM[DIM];
+    {
+      const f32x4 *q = reinterpret_cast<const f32x4 *>(p.coef + row * 2 * DIM);
+#pragma unroll
+      for (int k = 0; k < DIM / 4; ++k) {
+        const f32x4 a = q[k], b = q[DIM / 4 + k];
+        cA[4 * k] = a.x; cA[4 * k + 1] = a.y; cA[4 * k + 2] = a.z; cA[4 * k + 3] = a.w;
+        cB[4 * k] = b.x; cB[4 * k + 1] = b.y; cB[4 * k + 2] = b.z; cB[4 * k + 3] = b.w;
+      }
+    }
+    double rs[4];
+    {
+      const double *q = p.rowsum + row * 4;
+      rs[0] = q[0]; rs[1] = q[1]; rs[2] = q[2]; rs[3] = q[3];
+    }
+    float *ops = s_ops[slot];
+    for (int i = sub; i < DIM; i += GROUP) {
+#pragma clang fp contract(off)
+      ops[i] = p.mu[row * DIM + i];
+      if constexpr (MODE == kModeGQ) {
+        const float sg = p.sd[row * DIM + i];
+        ops[DIM + i] = 2.0f * (sg * sg);
+        ops[2 * DIM + i] = p.lsd[row * DIM + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) cM[i] = cA[i] < 0.0f ? (-0.5f * cB[i]) / cA[i] : 0.0f;   // the parabola's vertex (any point is valid)
+    const double u = 5.9604644775390625e-08;
+    const double N1 = (double)N1f;
+    double T, G;
+    row_bound<MODE>(rs, N1, DIM, p.beta, T, G);
+    const double Er = MODE == kModeGQ ? (DIM + 16.0) * u * G : 1e-12 * T;
+    const float margin32 = (float)(2.5 * ((2.0 * DIM + 4.0) * u * T + Er) * 1.0000002 + 1e-30);
+    const bool bad = !(N1 == N1) || N1 > 1e18 || !(T < 1e30) || !(G < 1e30) || !(margin32 < 1e30f);
+    wave_sync_lds();
+
+    auto expansion = [&](const float (&n)[DIM]) {
+      float f = 0.0f;
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) f = __builtin_fmaf(__builtin_fmaf(cA[i], n[i], cB[i]), n[i], f);
+      return f;
+    };
+    float F = NEG_INF;
+    // thr: what a box / a code must reach (rounded down: the subtraction and F's own last bit)
+    auto thr_of = [&](float Fv) { return Fv > NEG_INF ? (Fv - margin32) - 2.4e-7f * __builtin_fabsf(Fv) : NEG_INF; };
+    float thr = NEG_INF;
+    double best_s = 0.0;
+    int best_i = 0x7fffffff;
+    bool have = false;
+    int leaves = 0, exact_n = 0;
+    bool overflow = false;
+    auto load_code = [&](int j, float (&n)[DIM]) {
+      const f32x4 *q = reinterpret_cast<const f32x4 *>(scb + (long)j * DIM);
+#pragma unroll
+      for (int k = 0; k < DIM / 4; ++k) {
+        const f32x4 v = q[k];
+        n[4 * k] = v.x; n[4 * k + 1] = v.y; n[4 * k + 2] = v.z; n[4 * k + 3] = v.w;
+      }
+    };
+    // NL leaves at once: lane `sub` takes codes sub, sub + 16, sub + 32, sub + 48 of each (a leaf's codes are contiguous: 256 B per
+    // group and load instruction; all CPL NL loads in flight together); leaves of more than 64 codes: further rounds.
+    // EXACT = false: F and thr follow; returns the largest f^ of the batch.  EXACT = true (the final pass): the codes with
+    // f^ >= thr receive the reference's arithmetic, one pending code per lane and trip of the loop.
+    auto visit = [&](auto nl_tag, auto exact_tag, const int (&leaf)[decltype(nl_tag)::value], int count) -> float {
+      constexpr int NL = decltype(nl_tag)::value;
+      constexpr bool EXACT = decltype(exact_tag)::value;
+      int s[NL], e[NL];
+      int longest = 0;
+#pragma unroll
+      for (int t = 0; t < NL; ++t) {
+        s[t] = s_start[leaf[t]];
+        e[t] = t < count ? s_start[leaf[t] + 1] : s[t];
+        longest = max(longest, e[t] - s[t]);
+      }
+      float bm = NEG_INF;
+      for (int off = 0; off < longest; off += GROUP * CPL) {          // (group-uniform trip count: one round for 64-code leaves)
+        float f[NL][CPL];
+        float m = NEG_INF;
+        {
+          float n[NL][CPL][DIM];
+#pragma unroll
+          for (int t = 0; t < NL; ++t)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              const int j = s[t] + off + sub + GROUP * c;
+              load_code(j < e[t] ? j : s[t], n[t][c]);
+            }
+#pragma unroll
+          for (int t = 0; t < NL; ++t)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              f[t][c] = s[t] + off + sub + GROUP * c < e[t] ? expansion(n[t][c]) : NEG_INF;
+              m = __builtin_fmaxf(m, f[t][c]);
+            }
+        }
+        if constexpr (!EXACT) {
+          m = group_max(m);
+          bm = __builtin_fmaxf(bm, m);
+          F = __builtin_fmaxf(F, m);
+          thr = thr_of(F);
+        } else {
+          unsigned pend = 0u;
+#pragma unroll
+          for (int t = 0; t < NL; ++t)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+              pend |= (f[t][c] > NEG_INF && !(f[t][c] < thr)) ? 1u << (t * CPL + c) : 0u;   // (a NaN value passes; such rows are `bad`)
+          while (__any(pend != 0u)) {
+            if (pend != 0u) {
+              const int q = __builtin_ctz(pend);
+              pend &= pend - 1u;
+              int st = s[0];
+#pragma unroll
+              for (int t = 1; t < NL; ++t) st = q / CPL == t ? s[t] : st;
+              const int j = st + off + sub + GROUP * (q % CPL);
+              float nn[DIM];
+              load_code(j, nn);
+              const int code = sidx[j];
+              double sc;
+              if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(nn, ops, p.beta);
+              else sc = vq_neg_dist(nn, ops, DIM);
+              if (!have || better_d(sc, code, best_s, best_i)) { best_s = sc; best_i = code; have = true; }
+              ++exact_n;
+            }
+          }
+        }
+      }
+      return bm;
+    };
+    using NL1 = std::integral_constant<int, 1>;
+    using NLU = std::integral_constant<int, LEAF_U>;
+    auto nonempty = [&](int leaf) { return s_start[leaf + 1] > s_start[leaf]; };
+    GQ_GRID_STAMP();   // 1: operands, bounds, margins
+
+#ifdef GQHIP_ABL
+    const bool abl_no_search = (p.abl & 1) != 0, abl_greedy_only = (p.abl & 2) != 0;
+#else
+    constexpr bool abl_no_search = false, abl_greedy_only = false;
+#endif
+    if (!bad && !abl_no_search) {
+      // ---- (1) greedy descent to ONE leaf (LDS only, then one round trip for its codes): a good F before anything is pruned
+      const float ub1 = grid_box_ub<DIM>(cA, cB, cM, s_box + sub * BOXF);
+      int first_leaf = -1;
+      float bmax_first = NEG_INF;
+      {
+        const unsigned b1 = group_bits(ub1 == group_max(ub1) && ub1 > NEG_INF);
+        if (b1 != 0u) {
+          const int g1 = __builtin_ctz(b1);
+          const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (g1 * 16 + sub) * BOXF);
+          const unsigned b2 = group_bits(ub2 == group_max(ub2) && ub2 > NEG_INF);
+          if (b2 != 0u) {
+            const int node = g1 * 16 + __builtin_ctz(b2);
+            const int lq = node * LPN + (sub & (LPN - 1));               // (every lane: leaf sub % 4 of the node)
+            const float ub3 = nonempty(lq) ? grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF) : NEG_INF;
+            const unsigned b3 = group_bits(ub3 == group_max(ub3) && ub3 > NEG_INF) & ((1u << LPN) - 1u);
+            if (b3 != 0u) {
+              first_leaf = node * LPN + __builtin_ctz(b3);
+              const int one[1] = {first_leaf};
+              bmax_first = visit(NL1{}, std::false_type{}, one, 1);
+              leaves = 1;
+            }
+          }
+        }
+      }
+      GQ_GRID_STAMP();   // 2: greedy descent (one round trip)
+      if (abl_greedy_only) thr = __builtin_inff();
+      // ---- (2) the L2 nodes, then the leaves, whose bound is within the margin of F -> lists (LDS only)
+      int *l2list = s_l2list[slot], *list = s_leaflist[slot];
+      const unsigned lt = (1u << sub) - 1u;
+      int nl2 = 0;
+      unsigned m1 = group_bits(!(ub1 < thr) && ub1 > NEG_INF);
+      while (m1 != 0u) {
+        const int q1 = __builtin_ctz(m1);
+        m1 &= m1 - 1u;
+        const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (q1 * 16 + sub) * BOXF);
+        const bool c = !(ub2 < thr) && ub2 > NEG_INF;
+        const unsigned pm = group_bits(c);
+        const int pos = nl2 + __builtin_popcount(pm & lt);
+        if (c && pos < kGridL2Cap) l2list[pos] = q1 * 16 + sub;
+        nl2 += __builtin_popcount(pm);
+      }
+      if (nl2 > kGridL2Cap) { overflow = true; nl2 = 0; }
+      wave_sync_lds();
+      int nleaf = 0;
+      for (int i0 = 0; i0 < nl2; i0 += GROUP / LPN) {                    // four listed nodes per step: lane -> (node sub / 4, leaf sub % 4)
+        const int k = i0 + sub / LPN;
+        const int lq = l2list[k < nl2 ? k : i0] * LPN + (sub & (LPN - 1));
+        const float ub3 = grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF);
+        const bool c = k < nl2 && nonempty(lq) && !(ub3 < thr) && lq != first_leaf;
+        const unsigned pm = group_bits(c);
+        const int pos = nleaf + __builtin_popcount(pm & lt);
+        if (c && pos < kGridLeafCap) list[pos] = lq;
+        nleaf += __builtin_popcount(pm);
+      }
+      if (nleaf > kGridLeafCap || nleaf + 1 > p.leaf_cap) { overflow = true; nleaf = 0; }
+      wave_sync_lds();
+      GQ_GRID_STAMP();   // 3: lists
+      // ---- (3) the listed leaves, LEAF_U per round trip
+      for (int i0 = 0; i0 < nleaf; i0 += LEAF_U) {
+        int lf[LEAF_U];
+#pragma unroll
+        for (int t = 0; t < LEAF_U; ++t) lf[t] = list[i0 + t < nleaf ? i0 + t : i0];
+        const float bm = visit(NLU{}, std::false_type{}, lf, min(LEAF_U, nleaf - i0));
+        if (sub == 0) s_bmax[slot][i0 / LEAF_U] = bm;
+      }
+      leaves += nleaf;
+      wave_sync_lds();
+      GQ_GRID_STAMP();   // 4: listed leaves
+      // ---- (4) the final threshold is known: the reference's arithmetic for every code within the margin
+      if (!overflow) {
+        if (first_leaf >= 0 && !(bmax_first < thr)) {
+          const int one[1] = {first_leaf};
+          visit(NL1{}, std::true_type{}, one, 1);
+        }
+        for (int i0 = 0; i0 < nleaf; i0 += LEAF_U) {
+          if (!(s_bmax[slot][i0 / LEAF_U] < thr)) {                      // (group-uniform)
+            int lf[LEAF_U];
+#pragma unroll
+            for (int t = 0; t < LEAF_U; ++t) lf[t] = list[i0 + t < nleaf ? i0 + t : i0];
+            visit(NLU{}, std::true_type{}, lf, min(LEAF_U, nleaf - i0));
+          }
+        }
+      }
+    }
+    GQ_GRID_STAMP();     // 5: exact pass
+    // ---- the row's winner
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) {
+      const double os = __shfl_xor(best_s, o);
+      const int oi = __shfl_xor(best_i, o);
+      const bool oh = __shfl_xor((int)have, o) != 0;
+      if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+    }
+    const bool decided = live && !bad && !overflow && have;
+    if (sub == 0) {
+      s_best[slot] = decided ? best_i : -1;
+      s_scan[slot] = (live && !decided) ? ((bad || !have) ? 2 : 1) : 0;
+      s_scan_thr[slot] = thr;
+      if (live && !decided) atomicAdd(&p.hdr->fb_count, 1);
+      if (p.stats && live) atomicAdd(&p.hdr->grid_leaves, (unsigned long long)leaves);
+    }
+    if (p.stats && live) {
+      int e = exact_n;
+#pragma unroll
+      for (int o = GROUP / 2; o > 0; o >>= 1) e += __shfl_xor(e, o);
+      if (sub == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)e);
+    }
+    if (p.zhat && decided)
+      for (int i = sub; i < DIM; i += GROUP) s_zhat[slot][i] = p.cb[(long)best_i * DIM + i];
+    __syncthreads();
+    GQ_GRID_STAMP();     // 6: reduce + block barrier
+    const long row0 = (long)vb * RPB;
+    if (tid < RPB) {
+      const int b = s_best[tid];
+      if (b >= 0) p.idx[out_idx_offset(p.omap, row0 + tid)] = (int64_t)b;
+    }
+    if (p.zhat) {
+      for (int j = tid; j < RPB * DIM; j += kGridThreads) {
+        int lr, g;
+        if (p.omap.mode == 1) { lr = j % RPB; g = j / RPB; } else { lr = j / DIM; g = j % DIM; }
+        if (s_best[lr] >= 0) p.zhat[out_zhat_offset(p.omap, row0 + lr, g, DIM)] = s_zhat[lr][g];
+      }
+    }
+    // ---- rows the search did not decide: the whole block, one after the other
+    for (int sl = 0; sl < RPB; ++sl) {
+      const int m = s_scan[sl];                           // block-uniform
+      if (m != 0) grid_finish_row_by_scan<MODE, DIM>(p, row0 + sl, s_scan_thr[sl], m == 2, s_ops[sl], sh_s, sh_i);
+    }
+    __syncthreads();
+#ifdef GQHIP_CLOCK_STAMPS
+    GQ_GRID_STAMP();     // 7: stores, scans, barrier
+    if (tid == 0 && vb == (int)blockIdx.x && blockIdx.x % 100 == 0 && blockIdx.x / 100 < 6) {   // six blocks' first row set, wave 0
+      for (int k = 0; k < 8; ++k) p.hdr->stamps[8 * (blockIdx.x / 100) + k] = k < nst_ ? st_[k] : 0ull;
+    }
+    nst_ = 8;
+#endif
+  }
+}
+
+}  // namespace gqhip

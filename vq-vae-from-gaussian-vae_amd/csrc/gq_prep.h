@@ -42,6 +42,8 @@ struct PrepParams {
   const float *cb;           // [n, dim]
   u32x4 *cbimg;              // [tiles_total + CT][NVEC][2][32] or NULL
   WsHeader *hdr;
+  unsigned long long *cache_sums;   // codebook cache: the kAbsmaxParts slice hashes it was built from, or NULL (no cache in this call)
+  int *cache_stale;                 // ... its `stale` word: set when a slice's hash differs (the builder that follows rebuilds)
   long rows;
   int n, tiles_total;
   int row_blocks;            // blocks [0, row_blocks) prepare rows, the kPrepCodeBlocks after them the codebook
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   if (blockIdx.x == 0 && tid == 0) {           // header for the kernels that follow on the stream
     p.hdr->fb_count = 0;
     p.hdr->reranked = 0ull;
+    p.hdr->grid_leaves = 0ull;
   }
 
 #if defined(GQHIP_ABL) && (GQHIP_ABL & 1024)   // diagnostic build (tools/abl_prep.sh): the code blocks do nothing
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     // ------------------------------------------------------------------ codebook image + max |cb|
     const int cbk = blockIdx.x - p.row_blocks;
     float amax = 0.0f, r2max = 0.0f;
+    unsigned long long hsum = 0ull;
     if (p.cbimg) {
       const long items = (long)p.tiles_total * 64;   // (tile, half, code)
       for (long t = (long)cbk * 256 + tid; t < items; t += (long)kPrepCodeBlocks * 256) {
@@ -218,23 +222,31 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
         }
       }
     } else {
+      // no operand image in this call (fp32 filter; grid search, gq_grid.h): max |cb| and the content hash of this block's slice
       const long count = (long)p.n * DIM;
       for (long i = (long)cbk * 256 + tid; i < count; i += (long)kPrepCodeBlocks * 256) {
-        const float a = fabsf(p.cb[i]);
+        const float x = p.cb[i];
+        const float a = fabsf(x);
         amax = (a != a) ? __builtin_inff() : __builtin_fmaxf(amax, a);
+        hsum += cb_hash_term(x, i);
       }
     }
     __shared__ float s_amax[4], s_r2[4];
+    __shared__ unsigned long long s_hsum[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       amax = __builtin_fmaxf(amax, __shfl_xor(amax, o));
       r2max = __builtin_fmaxf(r2max, __shfl_xor(r2max, o));
+      hsum += __shfl_xor(hsum, o);
     }
-    if ((tid & 63) == 0) { s_amax[tid >> 6] = amax; s_r2[tid >> 6] = r2max; }
+    if ((tid & 63) == 0) { s_amax[tid >> 6] = amax; s_r2[tid >> 6] = r2max; s_hsum[tid >> 6] = hsum; }
     __syncthreads();
     if (tid == 0) {
       p.hdr->absmax_part[cbk] = __builtin_fmaxf(__builtin_fmaxf(s_amax[0], s_amax[1]), __builtin_fmaxf(s_amax[2], s_amax[3]));
       p.hdr->r2_part[cbk] = __builtin_fmaxf(__builtin_fmaxf(s_r2[0], s_r2[1]), __builtin_fmaxf(s_r2[2], s_r2[3]));
+      const unsigned long long h = s_hsum[0] + s_hsum[1] + s_hsum[2] + s_hsum[3];
+      p.hdr->cbsum[cbk] = h;
+      if (p.cache_sums && p.cache_sums[cbk] != h) *p.cache_stale = 1;     // the cache was built from other bytes: rebuilt before its use
     }
     return;
   }

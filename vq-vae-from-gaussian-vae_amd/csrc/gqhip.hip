@@ -18,6 +18,7 @@
 #include "gq_common.h"
 #include "gq_filter.h"
 #include "gq_filter_bf16.h"
+#include "gq_grid.h"
 #include "gq_prep.h"
 #include "gq_rerank.h"
 #include "gq_scores.h"
@@ -84,6 +85,19 @@ std::atomic<int> g_filter_kind{[] {
 bool want_bf16_filter() { return g_filter_kind.load(std::memory_order_relaxed) != 1; }
 bool want_mixed_filter() { return g_filter_kind.load(std::memory_order_relaxed) == 3; }
 bool want_f16_filter() { return g_filter_kind.load(std::memory_order_relaxed) == 0; }
+
+// Grid search (gq_grid.h) instead of filter + re-rank: dims 4 / 8, filter selection AUTO, 2^14 <= n <= 2^20 codes, and the caller
+// passed a codebook cache of gqhip_cb_cache_bytes().  GQHIP_GRID=0 disables it, =4 / =8 restricts it to one dim (A/B timing).
+int64_t grid_cache_bytes(int64_t n, int64_t dim) {
+  if ((dim != 4 && dim != 8) || n < 16384 || n > (1 << 20)) return 0;
+  return grid_layout(n, dim).total;
+}
+bool grid_applies(int64_t n, int64_t dim, const void *cache, int64_t cache_bytes) {
+  static const int env = getenv("GQHIP_GRID") ? atoi(getenv("GQHIP_GRID")) : 4;     // default: dim 4 only (dim 8: =8 / =48)
+  if (env == 0 || (env == 4 && dim != 4) || (env == 8 && dim != 8)) return false;
+  const int64_t need = grid_cache_bytes(n, dim);
+  return need > 0 && cache && cache_bytes >= need && g_filter_kind.load(std::memory_order_relaxed) == 0;
+}
 
 Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   Plan pl{};
@@ -383,7 +397,7 @@ int launch_prep(const PrepParams &pp, int dim, bool mixed, bool f16, hipStream_t
 template <int MODE>
 int run_argmax(const PrepInput &in, const float *mu, const float *sd, const float *lsd, const float *cb, int64_t *idx,
                float *zhat, int64_t dim, int64_t rows, int64_t n, double beta, void *workspace,
-               int64_t workspace_bytes, const OutMap &omap, hipStream_t st) {
+               int64_t workspace_bytes, void *cb_cache, int64_t cb_cache_bytes, const OutMap &omap, hipStream_t st) {
   if (dim < 1 || dim > kMaxDim || rows < 0 || n < 1 || n > 0x3fffffff || rows > 0x3fffffff)
     return GQHIP_ERR_INVALID_ARG;
   if (rows == 0) return GQHIP_OK;   // empty batch: nothing to do (pointers may be NULL)
@@ -458,6 +472,42 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   pp.beta = (float)beta; pp.omap = omap;
   pp.rowscale = (mixed || f16) ? reinterpret_cast<float *>(ws + w.rowscale) : nullptr;
   pp.rowaux = f16 ? reinterpret_cast<float *>(ws + w.rowaux) : nullptr;
+  const bool grid = grid_applies(n, dim, cb_cache, cb_cache_bytes);
+  if (grid) {
+    // ---- dims 4 / 8: prep (rows, bound sums, max|cb|, codebook hash) -> index builder (exits unless the hash says the cache is
+    //      stale) -> pruned exact search (gq_grid.h).  Three launches, no filter, no re-rank.
+    GridHdr *gh = reinterpret_cast<GridHdr *>(cb_cache);
+    pp.rowimg = nullptr; pp.cbimg = nullptr; pp.rowscale = nullptr; pp.rowaux = nullptr;
+    pp.cache_sums = gh->blk_sum; pp.cache_stale = &gh->stale;
+    int rc = from_z ? launch_prep<MODE, true>(pp, (int)dim, false, false, st) : launch_prep<MODE, false>(pp, (int)dim, false, false, st);
+    if (rc != GQHIP_OK) return rc;
+    GridBuildParams bp{};
+    bp.cb = cb; bp.cache = static_cast<char *>(cb_cache); bp.hdr = hdr; bp.n = (int)n;
+    if (dim == 4) hipLaunchKernelGGL((gq_grid_build_kernel<4>), dim3(1), dim3(kGridBuildThreads), 0, st, bp);
+    else hipLaunchKernelGGL((gq_grid_build_kernel<8>), dim3(1), dim3(kGridBuildThreads), 0, st, bp);
+    rc = check_launch();
+    if (rc != GQHIP_OK) return rc;
+    GridParams gp{};
+    gp.mu = r_mu; gp.sd = r_sd; gp.lsd = r_lsd; gp.rowsum = pp.rowsum; gp.coef = pp.coef; gp.cb = cb;
+    gp.cache = static_cast<const char *>(cb_cache);
+    gp.idx = idx; gp.zhat = zhat; gp.hdr = hdr; gp.rows = (int)rows; gp.n = (int)n; gp.beta = (float)beta;
+    static const int env_cap = getenv("GQHIP_GRID_CAP") ? atoi(getenv("GQHIP_GRID_CAP")) : 0;
+    gp.leaf_cap = env_cap > 0 ? env_cap : kGridLeafCap + 1;
+    gp.stats = g_debug_stats; gp.omap = omap;
+    static const int env_abl = getenv("GQHIP_GRID_ABL") ? atoi(getenv("GQHIP_GRID_ABL")) : 0;   // diagnostic builds (make abl) only
+    gp.abl = env_abl;
+    const int64_t nsets = (rows + 31) / 32;
+    const dim3 ggrid((unsigned)(nsets < 512 ? nsets : 512));       // two 512-thread blocks per CU: one wave of blocks
+    ProfScope prof;
+#define GQ_GRID(D)                                                                                                   \
+  do {                                                                                                               \
+    if (prof.on) hipExtLaunchKernelGGL((gq_grid_kernel<MODE, D>), ggrid, dim3(kGridThreads), 0, st, prof.a, prof.b, 0, gp);    \
+    else hipLaunchKernelGGL((gq_grid_kernel<MODE, D>), ggrid, dim3(kGridThreads), 0, st, gp);                                  \
+  } while (0)
+    if (dim == 4) GQ_GRID(4); else GQ_GRID(8);
+#undef GQ_GRID
+    return check_launch();
+  }
   int rc = from_z ? launch_prep<MODE, true>(pp, (int)dim, mixed, f16, st) : launch_prep<MODE, false>(pp, (int)dim, mixed, f16, st);
   if (rc != GQHIP_OK) return rc;
 
@@ -527,6 +577,11 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
   out8[5] = pl.f16 ? (int)kF16EfCoeff : (pl.mixed ? (int)kMixedEfCoeff : (pl.bf16 ? (dim == 4 ? 332 : 220 + 24 * dim) : 2 * dim + 4));
   out8[6] = pl.rt; out8[7] = pl.waves;
   return GQHIP_OK;
+}
+
+int64_t gqhip_cb_cache_bytes(int64_t n, int64_t dim) {
+  if (n < 1 || dim < 1 || dim > kMaxDim) return -1;
+  return grid_cache_bytes(n, dim);
 }
 
 int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim) {
@@ -610,18 +665,18 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
 
 int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null, const float *cb,
                   int64_t *idx, float *zhat_or_null, int64_t dim, int64_t rows, int64_t n, double beta,
-                  void *workspace, int64_t workspace_bytes, void *stream) {
+                  void *workspace, int64_t workspace_bytes, void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream) {
   OutMap om{};
   om.mode = 0; om.K = 1; om.L = 1; om.c = (int)dim;
   return run_argmax<kModeGQ>(PrepInput{}, mu, sd, logsd_or_null, cb, idx, zhat_or_null, dim, rows, n, beta,
-                             workspace, workspace_bytes, om, static_cast<hipStream_t>(stream));
+                             workspace, workspace_bytes, cb_cache_or_null, cb_cache_bytes, om, static_cast<hipStream_t>(stream));
 }
 
 int gq_quantize_z_f32(const float *z, const float *noise_or_null, const float *cb, int64_t *idx,
                       float *zhat_or_null, float *zhat_noquant_or_null, float *mu_out_or_null,
                       float *sd_out_or_null, int64_t B, int64_t L, int64_t c, int64_t dim, int64_t n, int layout,
                       int grouping, double lv_min, double lv_max, double beta, void *workspace,
-                      int64_t workspace_bytes, void *stream) {
+                      int64_t workspace_bytes, void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream) {
   if (!z || !cb || !idx || B < 0 || L < 1 || c < 1 || dim < 1 || dim > kMaxDim || c % dim != 0)
     return GQHIP_ERR_INVALID_ARG;
   if ((layout != GQHIP_LAYOUT_BCHW && layout != GQHIP_LAYOUT_BLC) ||
@@ -639,7 +694,7 @@ int gq_quantize_z_f32(const float *z, const float *noise_or_null, const float *c
   om.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
   om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = grouping;
   return run_argmax<kModeGQ>(in, nullptr, nullptr, nullptr, cb, idx, zhat_or_null, dim, rows, n, beta, workspace,
-                             workspace_bytes, om, static_cast<hipStream_t>(stream));
+                             workspace_bytes, cb_cache_or_null, cb_cache_bytes, om, static_cast<hipStream_t>(stream));
 }
 
 int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B, int64_t L, int64_t K,
@@ -657,11 +712,12 @@ int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B, 
 }
 
 int vq_argmin_f32(const float *z, const float *emb, int64_t *idx, float *zq_or_null, int64_t dim,
-                  int64_t rows, int64_t n, void *workspace, int64_t workspace_bytes, void *stream) {
+                  int64_t rows, int64_t n, void *workspace, int64_t workspace_bytes, void *cb_cache_or_null,
+                  int64_t cb_cache_bytes, void *stream) {
   OutMap om{};
   om.mode = 0; om.K = 1; om.L = 1; om.c = (int)dim;
   return run_argmax<kModeVQ>(PrepInput{}, z, nullptr, nullptr, emb, idx, zq_or_null, dim, rows, n, 0.0, workspace,
-                             workspace_bytes, om, static_cast<hipStream_t>(stream));
+                             workspace_bytes, cb_cache_or_null, cb_cache_bytes, om, static_cast<hipStream_t>(stream));
 }
 
 int lfq_pack_f32(const float *x, int64_t *idx, float *q_or_null, int64_t rows, int64_t nbits,
@@ -831,6 +887,22 @@ int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
   if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
   if (fallback_rows_host) *fallback_rows_host = h.fb_count;
   if (reranked_halftiles_host) *reranked_halftiles_host = (int64_t)h.reranked;
+  return GQHIP_OK;
+}
+
+int gqhip_debug_grid(const void *workspace, const void *cb_cache, int64_t *out4_host) {
+  if (!workspace || !out4_host) return GQHIP_ERR_INVALID_ARG;
+  WsHeader h;
+  if (hipMemcpy(&h, workspace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
+  out4_host[0] = (int64_t)h.grid_leaves;
+  out4_host[1] = (int64_t)h.reranked;
+  out4_host[2] = h.fb_count;
+  out4_host[3] = -1;
+  if (cb_cache) {
+    GridHdr g;
+    if (hipMemcpy(&g, cb_cache, sizeof(g), hipMemcpyDeviceToHost) != hipSuccess) return check_launch();
+    out4_host[3] = (g.magic == kGridMagic && g.stale == 0) ? 1 : 0;
+  }
   return GQHIP_OK;
 }
 

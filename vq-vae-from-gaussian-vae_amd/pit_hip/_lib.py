@@ -19,7 +19,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
 LIB_PATH = os.environ.get("GQHIP_LIB", os.path.join(_CSRC, "libgqhip.so"))  # GQHIP_LIB: diagnostic builds
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 GNSTAT_WORDS = 8     # int64 words per (image, group) statistics record (gqhip.h: gqhip_gnstat_t)
 GQHIP_LAYOUT = {"bchw": 0, "blc": 1}
 GQHIP_GROUP_STRIDED = 0
@@ -35,17 +35,19 @@ _SIGNATURES = {
     "gqhip_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "gqhip_last_hip_error": (ctypes.c_int, []),
     "gqhip_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gqhip_cb_cache_bytes": (_i64, [_i64, _i64]),
+    "gqhip_debug_grid": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_i64)]),
     "gqhip_set_filter": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_get_filter": (ctypes.c_int, []),
     "gqhip_debug_plan": (ctypes.c_int, [_i64, _i64, _i64, ctypes.POINTER(_i64)]),
     "gq_scores_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double, _vp]),
-    "gq_argmax_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double, _vp, _i64, _vp]),
+    "gq_argmax_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_double, _vp, _i64, _vp, _i64, _vp]),
     "gq_quantize_z_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
-                                         ctypes.c_double, _vp, _i64, _vp]),
+                                         ctypes.c_double, _vp, _i64, _vp, _i64, _vp]),
     "gq_dequant_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
                                       ctypes.c_int, _vp]),
-    "vq_argmin_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "vq_argmin_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "lfq_pack_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "lfq_unpack_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "fsq_quantize_f32": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i64, _vp, _vp, _i64, _vp]),
@@ -163,15 +165,33 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 class Workspace:
-    """Caller-owned scratch, grown on demand and reused across calls.  One workspace serves one stream at a time
-    (its header carries the per-call counters).  While a HIP graph is being captured the buffer is never replaced:
-    a captured graph has the pointer baked in, so growing it then -- or after the capture, by an eager call with a
-    bigger shape -- would leave the graph writing into freed memory; size it with a warm-up call first
-    (``reserve``), and a capture that would need to grow raises instead."""
+    """Caller-owned scratch, grown on demand and reused across calls, plus the persistent CODEBOOK CACHE of the shapes that keep
+    one (gqhip.h: gqhip_cb_cache_bytes -- dims 4 / 8: the spatial index of the pruned search; the library validates it against a
+    content hash of the codebook on every call and rebuilds it in-stream when it is stale, so nothing here has to track the
+    codebook).  One workspace serves one stream at a time (its header carries the per-call counters).  While a HIP graph is being
+    captured the buffers are never replaced: a captured graph has the pointers baked in, so growing them then -- or after the
+    capture, by an eager call with a bigger shape -- would leave the graph writing into freed memory; size them with a warm-up
+    call first (``reserve``), and a capture that would need to grow raises instead."""
 
     def __init__(self) -> None:
         self.buf: Optional[torch.Tensor] = None
+        self.cache_buf: Optional[torch.Tensor] = None
+        self._cache_key = None
         self._pinned = False      # True once a graph capture has used this buffer: it must never be replaced
+
+    def cache(self, n: int, dim: int, device) -> Tuple[Optional[int], int]:
+        """(pointer, bytes) of the codebook cache for (n, dim), or (None, 0) for shapes that keep none."""
+        need = lib().gqhip_cb_cache_bytes(n, dim)
+        if need <= 0:
+            return None, 0
+        key = (n, dim, device)
+        if self.cache_buf is None or self._cache_key != key or self.cache_buf.numel() < need:
+            if torch.cuda.is_current_stream_capturing() or self._pinned:
+                raise GqHipError("the codebook cache would have to be (re)allocated during / after a HIP graph capture that uses "
+                                 "this Workspace: run a warm-up call of the same codebook shape before capturing")
+            self.cache_buf = torch.zeros(need, dtype=torch.uint8, device=device)    # zeros: no stamp -> built by the first call
+            self._cache_key = key
+        return self.cache_buf.data_ptr(), self.cache_buf.numel()
 
     def reserve(self, rows: int, n: int, dim: int, device) -> None:
         self.get(rows, n, dim, device)
@@ -218,8 +238,9 @@ def gq_argmax(mu, sd, cb, beta: float = 1.0, logsd=None, ws: Optional[Workspace]
     zhat = torch.empty(rows, dim, dtype=torch.float32, device=mu.device) if want_zhat else None
     with torch.cuda.device(mu.device):
         wptr, wbytes = ws.get(rows, n, dim, mu.device)
+        cptr, cbytes = ws.cache(n, dim, mu.device)
         _check(lib().gq_argmax_f32(mu.data_ptr(), sd.data_ptr(), _ptr(logsd), cb.data_ptr(), idx.data_ptr(),
-                                   _ptr(zhat), dim, rows, n, float(beta), wptr, wbytes, _stream()), "gq_argmax_f32")
+                                   _ptr(zhat), dim, rows, n, float(beta), wptr, wbytes, cptr, cbytes, _stream()), "gq_argmax_f32")
     return idx, zhat
 
 
@@ -256,10 +277,11 @@ def gq_quantize_z(z, cb, dim: int, layout: str, grouping: int, lv_range=(-30.0, 
         sd_o = torch.empty(rows, dim, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         wptr, wbytes = ws.get(max(rows, 1), n, dim, dev)
+        cptr, cbytes = ws.cache(n, dim, dev)
         _check(lib().gq_quantize_z_f32(z.data_ptr(), _ptr(noise), cb.data_ptr(), idx.data_ptr(), zhat.data_ptr(),
                                        _ptr(noquant), _ptr(mu_o), _ptr(sd_o), B, L, c, dim, n, GQHIP_LAYOUT[layout],
                                        grouping, float(lv_range[0]), float(lv_range[1]), float(beta),
-                                       wptr, wbytes, _stream()), "gq_quantize_z_f32")
+                                       wptr, wbytes, cptr, cbytes, _stream()), "gq_quantize_z_f32")
     out = (idx, zhat)
     if return_operands:
         out = out + (mu_o, sd_o)
@@ -291,8 +313,9 @@ def vq_argmin(z, emb, ws: Optional[Workspace] = None):
     zq = torch.empty(rows, dim, dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
         wptr, wbytes = ws.get(max(rows, 1), n, dim, z.device)
+        cptr, cbytes = ws.cache(n, dim, z.device)
         _check(lib().vq_argmin_f32(z.data_ptr(), emb.data_ptr(), idx.data_ptr(), zq.data_ptr(), dim, rows, n,
-                                   wptr, wbytes, _stream()), "vq_argmin_f32")
+                                   wptr, wbytes, cptr, cbytes, _stream()), "vq_argmin_f32")
     return idx, zq
 
 
@@ -1069,6 +1092,14 @@ def debug_records(ws: Workspace, rows: int, n: int, dim: int):
     split = torch.arange(sets, device=raw.device, dtype=torch.int32) // halves
     base2 = 2 * ((split * pl["tiles_per_split"]) // pl["gt"])
     return m, local + base2[:, None, None]
+
+
+def debug_grid(ws: Workspace) -> dict:
+    """Grid search statistics of the last call on ``ws`` (counted only while ``debug_enable(True)``; synchronous)."""
+    out = (_i64 * 4)()
+    cptr = None if ws.cache_buf is None else ws.cache_buf.data_ptr()
+    _check(lib().gqhip_debug_grid(ws.buf.data_ptr(), cptr, out), "gqhip_debug_grid")
+    return {"leaves": out[0], "exact_codes": out[1], "scanned_rows": out[2], "index_current": out[3]}
 
 
 def debug_counters(ws: Workspace) -> Tuple[int, int]:
