@@ -1,6 +1,7 @@
-"""-m gpu: the pruned exact search of dims 4 / 8 (csrc/gq_grid.h; BASELINE configs[3]: sd3unet_gq_1.00 / gq_0.50) through the C ABI
-against the CPU oracle -- bit-exact indices whatever the codebook looks like --, the codebook cache's self-validation (edits in
-place, other codebooks, clobbered buffers), the rows it hands to the block-wide scan, and the pruning itself (leaves visited).
+"""-m gpu: the pruned exact search of dim 4 (csrc/gq_grid.h; BASELINE configs[3]: sd3unet_gq_1.00; dim 8 cases run whatever path the
+library selects for them -- the dense filter today) through the C ABI against the CPU oracle -- bit-exact indices whatever the
+codebook looks like --, the codebook cache's self-validation (edits in place, other codebooks, clobbered buffers), the rows it
+hands to the block-wide scan, and the pruning itself (leaves visited).
 Reference arithmetic: pit/quantization/gaussian.py:136-150 (torch backend), vq.py:58-73."""
 import numpy as np
 import pytest
@@ -66,6 +67,12 @@ def _uses_grid(ws):
     return ws.cache_buf is not None
 
 
+def _grid_dims():
+    from pit_hip import _lib
+
+    return [d for d in (4, 8) if _lib.lib().gqhip_cb_cache_bytes(65536, d) > 0]
+
+
 @pytest.mark.parametrize("which", ["sobol", "uniform", "scaled", "clustered", "duplicates"])
 @pytest.mark.parametrize("kind", ["trained", "linear", "convex", "wide"])
 @pytest.mark.parametrize("dim,n,rows", [(4, 65536, 1000), (8, 65536, 777), (4, 16384, 37), (8, 100000, 300), (4, 70001, 130)])
@@ -76,7 +83,9 @@ def test_grid_indices_bit_exact_for_any_codebook(dim, n, rows, kind, which):
     mu, sd = _rows(rows, dim, 11 * dim + rows, kind)
     for beta in (1.0, 0.0):
         idx, zhat, lsd, ws = _gq(mu, sd, cb, beta)
-        assert _uses_grid(ws) and _lib.debug_grid(ws)["index_current"] == 1
+        assert _uses_grid(ws) == (dim in _grid_dims())
+        if _uses_grid(ws):
+            assert _lib.debug_grid(ws)["index_current"] == 1
         ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb, beta, logstd=lsd)
         assert np.array_equal(idx, ref_idx), (kind, which, beta, int((idx != ref_idx).sum()))
         assert np.array_equal(zhat, ref_zhat)
@@ -101,7 +110,7 @@ def test_grid_vq_matches_the_fp64_arbiter(dim):
     z[:300] = emb[torch.randint(0, 65536, (300,), generator=g)] + 1e-4 * torch.randn(300, dim, generator=g)
     ws = _lib.Workspace()
     idx, zq = _lib.vq_argmin(z.to(DEV), emb.to(DEV), ws=ws)
-    assert _uses_grid(ws)
+    assert _uses_grid(ws) == (dim in _grid_dims())
     oi = O.vq_argmin_rows(z.numpy(), emb.numpy())
     assert np.array_equal(idx.cpu().numpy(), oi)
     assert np.array_equal(zq.cpu().numpy(), emb.numpy()[oi])
@@ -185,8 +194,7 @@ def test_codebook_cache_validates_itself():
     # (3) garbage in the cache buffer (a caller that reused the memory)
     ws.cache_buf.copy_(torch.randint(0, 255, ws.cache_buf.shape, dtype=torch.uint8, device=DEV))
     check(cb2)
-    # (4) garbage everywhere but the stamp: header intact, sorted arrays destroyed -> the hash still matches, so this is the one
-    #     thing the contract forbids (the caller must not write the buffer); a REBUILD request through a zeroed stamp repairs it
+    # (4) a zeroed stamp (what a caller does to force a rebuild)
     ws.cache_buf[:4096].zero_()
     check(cb2)
     # (5) another codebook of the same shape through the same workspace
@@ -225,10 +233,11 @@ def test_grid_path_is_graph_capturable_and_sees_edits_on_replay():
     assert np.array_equal(idx.cpu().numpy(), ref1) and ref1[0] != ref[0]
 
 
-@pytest.mark.parametrize("dim,kind,limit", [(4, "trained", 12.0), (4, "linear", 16.0), (8, "trained", 120.0), (8, "linear", 220.0)])
+@pytest.mark.parametrize("dim,kind,limit", [(4, "trained", 8.0), (4, "linear", 20.0)])
 def test_grid_prunes(dim, kind, limit):
-    """The point of the formulation: leaves visited per row (of 4096; a leaf = 16 codes of the 65 536).  CPU study
-    (tools/grid_prune_study.py): 5-6 at dim 4, 54-95 at dim 8; the gate is 2x that."""
+    """The point of the formulation: leaves visited per row (of 1024; a leaf = 64 codes of the 65 536): ~4 at the trained operating
+    point, ~11 in the near-linear regime of sigma ~ 1 (the upper levels' boxes bound a nearly linear score poorly); no row is
+    handed to the scan."""
     from pit_hip import _lib
 
     cb = O.codebook(65536, dim, 42)

@@ -65,7 +65,7 @@ def main():
         _lib.debug_enable(False)
         print(f"rows={a.rows} dim={a.dim} n={a.n}: grid search kernel (gq_grid.h) {kms*1e3:.1f} us avg over {launches} launches -> "
               f"{tf:.1f} algorithmic TFLOP/s-equivalent ({tf/2500*100:.1f}% of the 2500 the dense form is priced against); "
-              f"{gs['leaves'] / a.rows:.1f} of 4096 leaves and {gs['exact_codes'] / a.rows:.2f} exactly scored codes per row, "
+              f"{gs['leaves'] / a.rows:.1f} of 1024 leaves (64 codes each) and {gs['exact_codes'] / a.rows:.2f} exactly scored codes per row, "
               f"{gs['scanned_rows']} rows scanned by their block; whole call wall {wall*1e6:.1f} us")
         return
     print(f"rows={a.rows} dim={a.dim} n={a.n}: {('fp32', 'split-bf16', 'fp16+fp8', 'fp16 main product')[kind]} filter kernel {kms*1e3:.1f} us avg over "

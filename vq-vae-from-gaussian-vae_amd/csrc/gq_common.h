@@ -72,7 +72,8 @@ struct WsHeader {
   int pad0;
   unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly (grid search: codes given the reference's arithmetic)
   unsigned long long grid_leaves;     // grid search (gq_grid.h), debug statistics: leaves visited, summed over the rows
-  int pad1[26];
+  int grid_next;                      // grid search: the next group of four rows a wave fetches
+  int pad1[25];
   float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
   int pad2[128];

@@ -43,7 +43,7 @@ constexpr int kGridLanes = 16;                     // lanes per row (one DPP row
 constexpr int kGridL1 = 16, kGridL2 = 256, kGridLeaves = 1024;    // 16 nodes x 16 nodes x 4 leaves
 constexpr int kGridFan2 = kGridLeaves / kGridL1;                    // leaves under an L1 node
 constexpr int kGridBuildThreads = 1024;
-constexpr int kGridL2Cap = 32, kGridLeafCap = 48;  // list capacities of the search (a row beyond them goes to the block-wide scan)
+constexpr int kGridLeafCap = 48;                   // leaf-list capacity of the search (a longer list is visited best first and rebuilt)
 
 struct GridHdr {                                   // first 4 KiB of the codebook cache
   unsigned magic;
@@ -286,6 +286,7 @@ struct GridParams {
   float beta;
   int leaf_cap;                    // leaves a row may visit before it is handed to the block-wide scan
   int stats;
+  int *next;                       // work counter of the search (WsHeader.grid_next; zeroed by the first launch): four rows per fetch
   int abl;                         // diagnostic builds only (GQHIP_ABL): 1 = no search, 2 = greedy descent only (wrong results, timing)
   OutMap omap;
 };
@@ -328,32 +329,32 @@ __device__ __forceinline__ float row16_max(float v) {
 
 constexpr int kGridThreads = 512;      // 8 waves x 4 rows: 32 rows per block pass share one LDS copy of the tree; two blocks per CU
 
-// The whole block scans ALL codes for one row (the re-rank's exhaustive semantics): codes with f^ >= thr (or all: keep_all) get the
-// reference's arithmetic.  Inlined at the block's end.
+// 16 lanes per row, 4 rows per wave; every wave walks its own share of the rows (no block barrier inside the loop: a
+// row's search is a chain of dependent steps of very uneven length, and waiting for the slowest of 32 rows at every pass cost a
+// third of the kernel: profiles/r05/grid_search_variants.txt).  The whole tree (three levels of boxes, the code ranges of the
+// leaves) sits in LDS.  A row:
+//   (1) greedy descent to ONE leaf -> F;
+//   (2) the L2 nodes, then the leaves, whose bound is within the margin of F go to a list with their bounds (LDS / VALU only);
+//   (3) best bound first, two leaves per round trip, until the best remaining bound is below the threshold (F and thr tighten with
+//       every batch): fp32 expansions; every lane keeps its own best code and its runner-up value (the re-rank's pass-1 scheme);
+//       a list that did not fit is rebuilt with the tighter threshold (visited leaves are remembered in a bitmap);
+//   (4) with the FINAL threshold, the lanes whose best code is within the margin give it the reference's arithmetic -- ONE instance
+//       of that long, divergent code per row; a lane with a SECOND code within the margin (a near-tie) sends the row through all
+//       its visited leaves again with the exact score for everything within the margin.
+// Undecided rows (non-finite operands or bounds, a non-finite codebook, lists that never fit) are scanned over ALL codes by the
+// whole block after its waves have run out of work (up to kGridScanCap per block; beyond that by the wave itself).
+constexpr int kGridScanCap = 64;
+
 template <int MODE, int DIM>
-__device__ __forceinline__ void grid_finish_row_by_scan(const GridParams &p, long row, float thr, bool keep_all, const float *ops,
-                                                        double *sh_s, int *sh_i) {
-  constexpr int NT = kGridThreads;
-  const int tid = threadIdx.x;
-  float cA[DIM], cB[DIM];
-  {
-    const f32x4 *q = reinterpret_cast<const f32x4 *>(p.coef + row * 2 * DIM);
-#pragma unroll
-    for (int k = 0; k < DIM / 4; ++k) {
-      const f32x4 a = q[k], b = q[DIM / 4 + k];
-      cA[4 * k] = a.x; cA[4 * k + 1] = a.y; cA[4 * k + 2] = a.z; cA[4 * k + 3] = a.w;
-      cB[4 * k] = b.x; cB[4 * k + 1] = b.y; cB[4 * k + 2] = b.z; cB[4 * k + 3] = b.w;
-    }
-  }
-  double best_s = 0.0;
-  int best_i = 0x7fffffff;
-  bool have = false;
+__device__ __forceinline__ void grid_scan_accumulate(const GridParams &p, const float (&cA)[DIM], const float (&cB)[DIM], const float *ops,
+                                                     float thr, bool keep_all, int first, int stride, double &best_s, int &best_i,
+                                                     bool &have) {
   constexpr int U = 8;
-  for (int j0 = tid; j0 < p.n; j0 += NT * U) {
+  for (int j0 = first; j0 < p.n; j0 += stride * U) {
     float n[U][DIM];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int j = j0 + NT * u;
+      const int j = j0 + stride * u;
       const f32x4 *q = reinterpret_cast<const f32x4 *>(p.cb + (long)(j < p.n ? j : p.n - 1) * DIM);
 #pragma unroll
       for (int k = 0; k < DIM / 4; ++k) {
@@ -363,7 +364,7 @@ __device__ __forceinline__ void grid_finish_row_by_scan(const GridParams &p, lon
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int j = j0 + NT * u;
+      const int j = j0 + stride * u;
       float f = 0.0f;
 #pragma unroll
       for (int i = 0; i < DIM; ++i) f = __builtin_fmaf(__builtin_fmaf(cA[i], n[u][i], cB[i]), n[u][i], f);
@@ -375,34 +376,24 @@ __device__ __forceinline__ void grid_finish_row_by_scan(const GridParams &p, lon
       }
     }
   }
-  __syncthreads();
-  sh_s[tid] = best_s;
-  sh_i[tid] = have ? best_i : 0x7fffffff;
-  __syncthreads();
-  for (int o = NT / 2; o > 0; o >>= 1) {
-    if (tid < o) {
-      const double os = sh_s[tid + o];
-      const int oi = sh_i[tid + o];
-      const bool mine = sh_i[tid] != 0x7fffffff;
-      if (oi != 0x7fffffff && (!mine || better_d(os, oi, sh_s[tid], sh_i[tid]))) { sh_s[tid] = os; sh_i[tid] = oi; }
-    }
-    __syncthreads();
-  }
-  const int best = sh_i[0];
-  if (best != 0x7fffffff) {
-    if (tid == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best;
-    if (p.zhat && tid < DIM) p.zhat[out_zhat_offset(p.omap, row, tid, DIM)] = p.cb[(long)best * DIM + tid];
-  }
-  __syncthreads();
 }
 
-// 16 lanes per row, 4 rows per wave, 32 rows per block pass; blocks walk row sets.  The whole tree (three levels of boxes, the code
-// ranges of the leaves) sits in LDS.  A row: (1) greedy descent to ONE leaf -> F; (2) the L2 nodes, then the leaves, whose bound is
-// within the margin of F go to lists (LDS / VALU only); (3) the listed leaves, two per round trip: fp32 expansions, F and thr
-// tighten, the maximum of every batch is remembered; (4) with the FINAL threshold, only the batches that reached it are read again
-// (cache hits) and their codes within the margin get the reference's arithmetic -- one instance of that (long, divergent) code
-// per wave and pending code instead of one per batch and slot: the kernel is bound by VALU issue, not by memory
-// (profiles/r05/grid_search_variants.txt).
+template <int DIM>
+__device__ __forceinline__ void grid_load_coef(const GridParams &p, long row, float (&cA)[DIM], float (&cB)[DIM]) {
+  const f32x4 *q = reinterpret_cast<const f32x4 *>(p.coef + row * 2 * DIM);
+#pragma unroll
+  for (int k = 0; k < DIM / 4; ++k) {
+    const f32x4 a = q[k], b = q[DIM / 4 + k];
+    cA[4 * k] = a.x; cA[4 * k + 1] = a.y; cA[4 * k + 2] = a.z; cA[4 * k + 3] = a.w;
+    cB[4 * k] = b.x; cB[4 * k + 1] = b.y; cB[4 * k + 2] = b.z; cB[4 * k + 3] = b.w;
+  }
+}
+
+__device__ __forceinline__ void grid_write_result(const GridParams &p, long row, int best, int who, int dim) {
+  if (who == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best;
+  if (p.zhat && who < dim) p.zhat[out_zhat_offset(p.omap, row, who, dim)] = p.cb[(long)best * dim + who];
+}
+
 template <int MODE, int DIM>
 __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel(const GridParams p) {
   constexpr int GROUP = kGridLanes;
@@ -413,16 +404,17 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   constexpr int LPN = kGridLeaves / kGridL2;            // leaves per L2 node: 4
   constexpr int CPL = 4;                                // codes per lane and leaf in one round (64-code leaves: one round)
   constexpr int LEAF_U = 2;                             // leaves per round trip
+  constexpr int EPL = kGridLeafCap / GROUP;             // list entries per lane: 3
   __shared__ __attribute__((aligned(16))) float s_box[TREE_F];
   __shared__ __attribute__((aligned(16))) int s_start[START_N];
   __shared__ float s_ops[RPB][3 * DIM + 1];
-  __shared__ float s_zhat[RPB][DIM + 1];
-  __shared__ int s_l2list[RPB][kGridL2Cap];             // per row: L2 nodes / leaves whose bound is within the margin
   __shared__ int s_leaflist[RPB][kGridLeafCap];
-  __shared__ float s_bmax[RPB][kGridLeafCap / LEAF_U];  // per batch of listed leaves: its largest f^
-  __shared__ int s_best[RPB];
-  __shared__ int s_scan[RPB];                           // 0: decided; 1: scan with threshold; 2: scan, keep everything
-  __shared__ float s_scan_thr[RPB];
+  __shared__ float s_leafub[RPB][kGridLeafCap];
+  __shared__ unsigned s_visited[RPB][kGridLeaves / 32];
+  __shared__ int s_nscan;
+  __shared__ int s_scan_row[kGridScanCap];              // (row << 1) | keep_all
+  __shared__ float s_scan_thr[kGridScanCap];
+  __shared__ float s_sops[3 * DIM + 1];
   __shared__ double sh_s[kGridThreads];
   __shared__ int sh_i[kGridThreads];
   const GridLayout L = grid_layout(p.n, DIM);
@@ -445,36 +437,32 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     const f32x4 *src2 = reinterpret_cast<const f32x4 *>(p.cache + L.start);
     f32x4 *dst2 = reinterpret_cast<f32x4 *>(s_start);
     for (int k = tid; k < START_N / 4; k += kGridThreads) dst2[k] = src2[k];
+    if (tid == 0) s_nscan = 0;
   }
   const float *s_box2 = s_box + kGridL1 * BOXF, *s_box3 = s_box + (kGridL1 + kGridL2) * BOXF;
   const float N1f = wave_absmax(p.hdr->absmax_part, lane);
   const float NEG_INF = -__builtin_inff();
-  const int nsets = (p.rows + RPB - 1) / RPB;
+  const int nquads = (p.rows + RPW - 1) / RPW;
   __syncthreads();
 
 #ifdef GQHIP_CLOCK_STAMPS
   unsigned long long st_[8];
   int nst_ = 0;
+  bool first_pass_ = true;
 #define GQ_GRID_STAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (nst_ < 8) st_[nst_++] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GQ_GRID_STAMP() do { } while (0)
 #endif
-  for (int vb = blockIdx.x; vb < nsets; vb += gridDim.x) {
-    GQ_GRID_STAMP();   // 0: row set starts
-    const long pos_raw = (long)vb * RPB + slot;
+  // Static work split, eight consecutive quads (32 rows: whole cache lines of every row array) per block and round: a device-wide
+  // work counter was tried and serialised the kernel on its atomics (16 384 fetches of one address: 245 us instead of ~100).
+  for (int quad = (int)blockIdx.x * (kGridThreads / 64) + wave; quad < nquads; quad += (int)gridDim.x * (kGridThreads / 64)) {
+    GQ_GRID_STAMP();   // 0: four rows start
+    const long pos_raw = (long)quad * RPW + grp;
     const bool live = pos_raw < p.rows;
     const long row = live ? pos_raw : p.rows - 1;
     // ---- row operands
     float cA[DIM], cB[DIM], cM[DIM];
-    {
-      const f32x4 *q = reinterpret_cast<const f32x4 *>(p.coef + row * 2 * DIM);
-#pragma unroll
-      for (int k = 0; k < DIM / 4; ++k) {
-        const f32x4 a = q[k], b = q[DIM / 4 + k];
-        cA[4 * k] = a.x; cA[4 * k + 1] = a.y; cA[4 * k + 2] = a.z; cA[4 * k + 3] = a.w;
-        cB[4 * k] = b.x; cB[4 * k + 1] = b.y; cB[4 * k + 2] = b.z; cB[4 * k + 3] = b.w;
-      }
-    }
+    grid_load_coef<DIM>(p, row, cA, cB);
     double rs[4];
     {
       const double *q = p.rowsum + row * 4;
@@ -490,6 +478,9 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         ops[2 * DIM + i] = p.lsd[row * DIM + i];
       }
     }
+    unsigned *visited = s_visited[slot];
+#pragma unroll
+    for (int k = 0; k < kGridLeaves / 32 / GROUP; ++k) visited[sub + GROUP * k] = 0u;
 #pragma unroll
     for (int i = 0; i < DIM; ++i) cM[i] = cA[i] < 0.0f ? (-0.5f * cB[i]) / cA[i] : 0.0f;   // the parabola's vertex (any point is valid)
     const double u = 5.9604644775390625e-08;
@@ -511,6 +502,8 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     // thr: what a box / a code must reach (rounded down: the subtraction and F's own last bit)
     auto thr_of = [&](float Fv) { return Fv > NEG_INF ? (Fv - margin32) - 2.4e-7f * __builtin_fabsf(Fv) : NEG_INF; };
     float thr = NEG_INF;
+    float fb = NEG_INF, fsecond = NEG_INF;         // this lane's best code (value, sorted position) and its runner-up value
+    int jb = -1;
     double best_s = 0.0;
     int best_i = 0x7fffffff;
     bool have = false;
@@ -524,11 +517,21 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         n[4 * k] = v.x; n[4 * k + 1] = v.y; n[4 * k + 2] = v.z; n[4 * k + 3] = v.w;
       }
     };
+    auto exact_code = [&](int j) {
+      float nn[DIM];
+      load_code(j, nn);
+      const int code = sidx[j];
+      double sc;
+      if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(nn, ops, p.beta);
+      else sc = vq_neg_dist(nn, ops, DIM);
+      if (!have || better_d(sc, code, best_s, best_i)) { best_s = sc; best_i = code; have = true; }
+      ++exact_n;
+    };
     // NL leaves at once: lane `sub` takes codes sub, sub + 16, sub + 32, sub + 48 of each (a leaf's codes are contiguous: 256 B per
     // group and load instruction; all CPL NL loads in flight together); leaves of more than 64 codes: further rounds.
-    // EXACT = false: F and thr follow; returns the largest f^ of the batch.  EXACT = true (the final pass): the codes with
-    // f^ >= thr receive the reference's arithmetic, one pending code per lane and trip of the loop.
-    auto visit = [&](auto nl_tag, auto exact_tag, const int (&leaf)[decltype(nl_tag)::value], int count) -> float {
+    // EXACT = false: F and thr follow, the lane's best code and runner-up value are kept.  EXACT = true (the rare second pass of a
+    // near-tie): every code with f^ >= thr receives the reference's arithmetic.
+    auto visit = [&](auto nl_tag, auto exact_tag, const int (&leaf)[decltype(nl_tag)::value], int count) {
       constexpr int NL = decltype(nl_tag)::value;
       constexpr bool EXACT = decltype(exact_tag)::value;
       int s[NL], e[NL];
@@ -539,10 +542,8 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         e[t] = t < count ? s_start[leaf[t] + 1] : s[t];
         longest = max(longest, e[t] - s[t]);
       }
-      float bm = NEG_INF;
       for (int off = 0; off < longest; off += GROUP * CPL) {          // (group-uniform trip count: one round for 64-code leaves)
         float f[NL][CPL];
-        float m = NEG_INF;
         {
           float n[NL][CPL][DIM];
 #pragma unroll
@@ -555,15 +556,19 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
 #pragma unroll
           for (int t = 0; t < NL; ++t)
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-              f[t][c] = s[t] + off + sub + GROUP * c < e[t] ? expansion(n[t][c]) : NEG_INF;
-              m = __builtin_fmaxf(m, f[t][c]);
-            }
+            for (int c = 0; c < CPL; ++c) f[t][c] = s[t] + off + sub + GROUP * c < e[t] ? expansion(n[t][c]) : NEG_INF;
         }
         if constexpr (!EXACT) {
-          m = group_max(m);
-          bm = __builtin_fmaxf(bm, m);
-          F = __builtin_fmaxf(F, m);
+#pragma unroll
+          for (int t = 0; t < NL; ++t)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              const bool better = f[t][c] > fb;
+              fsecond = __builtin_fmaxf(fsecond, better ? fb : f[t][c]);
+              jb = better ? s[t] + off + sub + GROUP * c : jb;
+              fb = better ? f[t][c] : fb;
+            }
+          F = __builtin_fmaxf(F, group_max(fb));
           thr = thr_of(F);
         } else {
           unsigned pend = 0u;
@@ -571,7 +576,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
           for (int t = 0; t < NL; ++t)
 #pragma unroll
             for (int c = 0; c < CPL; ++c)
-              pend |= (f[t][c] > NEG_INF && !(f[t][c] < thr)) ? 1u << (t * CPL + c) : 0u;   // (a NaN value passes; such rows are `bad`)
+              pend |= (f[t][c] > NEG_INF && !(f[t][c] < thr)) ? 1u << (t * CPL + c) : 0u;
           while (__any(pend != 0u)) {
             if (pend != 0u) {
               const int q = __builtin_ctz(pend);
@@ -579,24 +584,17 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
               int st = s[0];
 #pragma unroll
               for (int t = 1; t < NL; ++t) st = q / CPL == t ? s[t] : st;
-              const int j = st + off + sub + GROUP * (q % CPL);
-              float nn[DIM];
-              load_code(j, nn);
-              const int code = sidx[j];
-              double sc;
-              if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(nn, ops, p.beta);
-              else sc = vq_neg_dist(nn, ops, DIM);
-              if (!have || better_d(sc, code, best_s, best_i)) { best_s = sc; best_i = code; have = true; }
-              ++exact_n;
+              exact_code(st + off + sub + GROUP * (q % CPL));
             }
           }
         }
       }
-      return bm;
     };
     using NL1 = std::integral_constant<int, 1>;
     using NLU = std::integral_constant<int, LEAF_U>;
     auto nonempty = [&](int leaf) { return s_start[leaf + 1] > s_start[leaf]; };
+    auto mark_visited = [&](int leaf) { if (sub == 0) visited[leaf >> 5] |= 1u << (leaf & 31); };
+    auto was_visited = [&](int leaf) { return (visited[leaf >> 5] >> (leaf & 31)) & 1u; };
     GQ_GRID_STAMP();   // 1: operands, bounds, margins
 
 #ifdef GQHIP_ABL
@@ -607,8 +605,6 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     if (!bad && !abl_no_search) {
       // ---- (1) greedy descent to ONE leaf (LDS only, then one round trip for its codes): a good F before anything is pruned
       const float ub1 = grid_box_ub<DIM>(cA, cB, cM, s_box + sub * BOXF);
-      int first_leaf = -1;
-      float bmax_first = NEG_INF;
       {
         const unsigned b1 = group_bits(ub1 == group_max(ub1) && ub1 > NEG_INF);
         if (b1 != 0u) {
@@ -621,9 +617,9 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
             const float ub3 = nonempty(lq) ? grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF) : NEG_INF;
             const unsigned b3 = group_bits(ub3 == group_max(ub3) && ub3 > NEG_INF) & ((1u << LPN) - 1u);
             if (b3 != 0u) {
-              first_leaf = node * LPN + __builtin_ctz(b3);
-              const int one[1] = {first_leaf};
-              bmax_first = visit(NL1{}, std::false_type{}, one, 1);
+              const int one[1] = {node * LPN + __builtin_ctz(b3)};
+              mark_visited(one[0]);
+              visit(NL1{}, std::false_type{}, one, 1);
               leaves = 1;
             }
           }
@@ -631,60 +627,101 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       }
       GQ_GRID_STAMP();   // 2: greedy descent (one round trip)
       if (abl_greedy_only) thr = __builtin_inff();
-      // ---- (2) the L2 nodes, then the leaves, whose bound is within the margin of F -> lists (LDS only)
-      int *l2list = s_l2list[slot], *list = s_leaflist[slot];
+      int *list = s_leaflist[slot];
+      float *lub = s_leafub[slot];
       const unsigned lt = (1u << sub) - 1u;
-      int nl2 = 0;
-      unsigned m1 = group_bits(!(ub1 < thr) && ub1 > NEG_INF);
-      while (m1 != 0u) {
-        const int q1 = __builtin_ctz(m1);
-        m1 &= m1 - 1u;
-        const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (q1 * 16 + sub) * BOXF);
-        const bool c = !(ub2 < thr) && ub2 > NEG_INF;
-        const unsigned pm = group_bits(c);
-        const int pos = nl2 + __builtin_popcount(pm & lt);
-        if (c && pos < kGridL2Cap) l2list[pos] = q1 * 16 + sub;
-        nl2 += __builtin_popcount(pm);
-      }
-      if (nl2 > kGridL2Cap) { overflow = true; nl2 = 0; }
-      wave_sync_lds();
-      int nleaf = 0;
-      for (int i0 = 0; i0 < nl2; i0 += GROUP / LPN) {                    // four listed nodes per step: lane -> (node sub / 4, leaf sub % 4)
-        const int k = i0 + sub / LPN;
-        const int lq = l2list[k < nl2 ? k : i0] * LPN + (sub & (LPN - 1));
-        const float ub3 = grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF);
-        const bool c = k < nl2 && nonempty(lq) && !(ub3 < thr) && lq != first_leaf;
-        const unsigned pm = group_bits(c);
-        const int pos = nleaf + __builtin_popcount(pm & lt);
-        if (c && pos < kGridLeafCap) list[pos] = lq;
-        nleaf += __builtin_popcount(pm);
-      }
-      if (nleaf > kGridLeafCap || nleaf + 1 > p.leaf_cap) { overflow = true; nleaf = 0; }
-      wave_sync_lds();
-      GQ_GRID_STAMP();   // 3: lists
-      // ---- (3) the listed leaves, LEAF_U per round trip
-      for (int i0 = 0; i0 < nleaf; i0 += LEAF_U) {
-        int lf[LEAF_U];
+      for (int round = 0;; ++round) {
+        wave_sync_lds();                                                  // (the visited bitmap of the previous round)
+        // ---- (2) the unvisited leaves whose bound -- and whose L1 and L2 nodes' bounds -- are within the margin of F -> a list with
+        //      their bounds (LDS / VALU only).  Per passing L1 node: its 16 L2 bounds (one per lane), then the leaves of the passing
+        //      L2 nodes four nodes at a time: lane -> (the (sub / 4)-th of them, leaf sub % 4)
+        int nleaf = 0;
+        bool truncated = false;
+        unsigned m1 = group_bits(!(ub1 < thr) && ub1 > NEG_INF);
+        while (m1 != 0u) {
+          const int q1 = __builtin_ctz(m1);
+          m1 &= m1 - 1u;
+          const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (q1 * 16 + sub) * BOXF);
+          unsigned pm2 = group_bits(!(ub2 < thr) && ub2 > NEG_INF);
+          while (pm2 != 0u) {
+            int nd = 0;
+            bool on = false;
 #pragma unroll
-        for (int t = 0; t < LEAF_U; ++t) lf[t] = list[i0 + t < nleaf ? i0 + t : i0];
-        const float bm = visit(NLU{}, std::false_type{}, lf, min(LEAF_U, nleaf - i0));
-        if (sub == 0) s_bmax[slot][i0 / LEAF_U] = bm;
+            for (int t = 0; t < GROUP / LPN; ++t) {
+              const bool here = pm2 != 0u;
+              const int c2 = here ? __builtin_ctz(pm2) : 0;
+              pm2 &= pm2 - 1u;                                            // (0 stays 0)
+              if (sub / LPN == t) { nd = c2; on = here; }
+            }
+            const int lq = (q1 * 16 + nd) * LPN + (sub & (LPN - 1));
+            const float ub3 = grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF);
+            const bool c = on && nonempty(lq) && !(ub3 < thr) && !was_visited(lq);
+            const unsigned pm = group_bits(c);
+            const int pos = nleaf + __builtin_popcount(pm & lt);
+            if (c && pos < kGridLeafCap) { list[pos] = lq; lub[pos] = ub3; }
+            nleaf += __builtin_popcount(pm);
+          }
+        }
+        truncated = truncated || nleaf > kGridLeafCap;
+        nleaf = min(nleaf, kGridLeafCap);
+        wave_sync_lds();
+        GQ_GRID_STAMP();   // 3: lists (first round)
+        // ---- (3) best bound first, LEAF_U leaves per round trip, until the best remaining bound is below the threshold
+        float eu[EPL];
+        int el[EPL];
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+          const int i = sub + GROUP * k;
+          eu[k] = i < nleaf ? lub[i] : NEG_INF;
+          el[k] = i < nleaf ? list[i] : 0;
+        }
+        int budget = truncated ? 16 : kGridLeafCap;                       // a truncated list: its best leaves, then a rebuild with the tighter thr
+        while (budget > 0) {
+          int lf[LEAF_U];
+          int cnt = 0;
+#pragma unroll
+          for (int t = 0; t < LEAF_U; ++t) {
+            float em = eu[0];
+#pragma unroll
+            for (int k = 1; k < EPL; ++k) em = __builtin_fmaxf(em, eu[k]);
+            const float gm = group_max(em);
+            const bool go = gm > NEG_INF && !(gm < thr);
+            const unsigned ob = group_bits(em == gm);
+            const int owner = ob ? __builtin_ctz(ob) : 0;
+            int mine = el[0];
+            bool taken = false;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+              const bool hit = !taken && eu[k] == gm;
+              mine = hit ? el[k] : mine;
+              if (go && sub == owner && hit) eu[k] = NEG_INF;
+              taken = taken || hit;
+            }
+            lf[t] = __shfl(mine, gshift + owner);
+            if (go) { ++cnt; mark_visited(lf[t]); } else if (t > 0) lf[t] = lf[0];
+          }
+          if (cnt == 0) break;
+          visit(NLU{}, std::false_type{}, lf, cnt);
+          leaves += cnt;
+          budget -= cnt;
+        }
+        if (!truncated) break;
+        if (round >= 24 || leaves > p.leaf_cap) { overflow = true; break; }
       }
-      leaves += nleaf;
-      wave_sync_lds();
       GQ_GRID_STAMP();   // 4: listed leaves
       // ---- (4) the final threshold is known: the reference's arithmetic for every code within the margin
       if (!overflow) {
-        if (first_leaf >= 0 && !(bmax_first < thr)) {
-          const int one[1] = {first_leaf};
-          visit(NL1{}, std::true_type{}, one, 1);
-        }
-        for (int i0 = 0; i0 < nleaf; i0 += LEAF_U) {
-          if (!(s_bmax[slot][i0 / LEAF_U] < thr)) {                      // (group-uniform)
-            int lf[LEAF_U];
-#pragma unroll
-            for (int t = 0; t < LEAF_U; ++t) lf[t] = list[i0 + t < nleaf ? i0 + t : i0];
-            visit(NLU{}, std::true_type{}, lf, min(LEAF_U, nleaf - i0));
+        if (jb >= 0 && !(fb < thr)) exact_code(jb);
+        if (group_bits(fsecond > NEG_INF && !(fsecond < thr)) != 0u) {
+          // a lane holds a second code within the margin (a near-tie): every visited leaf again, everything within the margin exactly
+          wave_sync_lds();
+          for (int w = 0; w < kGridLeaves / 32; ++w) {
+            unsigned bits = visited[w];                                   // (group-uniform)
+            while (bits != 0u) {
+              const int one[1] = {w * 32 + __builtin_ctz(bits)};
+              bits &= bits - 1u;
+              visit(NL1{}, std::true_type{}, one, 1);
+            }
           }
         }
       }
@@ -699,48 +736,95 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
     }
     const bool decided = live && !bad && !overflow && have;
-    if (sub == 0) {
-      s_best[slot] = decided ? best_i : -1;
-      s_scan[slot] = (live && !decided) ? ((bad || !have) ? 2 : 1) : 0;
-      s_scan_thr[slot] = thr;
-      if (live && !decided) atomicAdd(&p.hdr->fb_count, 1);
-      if (p.stats && live) atomicAdd(&p.hdr->grid_leaves, (unsigned long long)leaves);
-    }
+    if (decided) grid_write_result(p, row, best_i, sub, DIM);
     if (p.stats && live) {
       int e = exact_n;
 #pragma unroll
       for (int o = GROUP / 2; o > 0; o >>= 1) e += __shfl_xor(e, o);
-      if (sub == 0) atomicAdd(&p.hdr->reranked, (unsigned long long)e);
-    }
-    if (p.zhat && decided)
-      for (int i = sub; i < DIM; i += GROUP) s_zhat[slot][i] = p.cb[(long)best_i * DIM + i];
-    __syncthreads();
-    GQ_GRID_STAMP();     // 6: reduce + block barrier
-    const long row0 = (long)vb * RPB;
-    if (tid < RPB) {
-      const int b = s_best[tid];
-      if (b >= 0) p.idx[out_idx_offset(p.omap, row0 + tid)] = (int64_t)b;
-    }
-    if (p.zhat) {
-      for (int j = tid; j < RPB * DIM; j += kGridThreads) {
-        int lr, g;
-        if (p.omap.mode == 1) { lr = j % RPB; g = j / RPB; } else { lr = j / DIM; g = j % DIM; }
-        if (s_best[lr] >= 0) p.zhat[out_zhat_offset(p.omap, row0 + lr, g, DIM)] = s_zhat[lr][g];
+      if (sub == 0) {
+        atomicAdd(&p.hdr->reranked, (unsigned long long)e);
+        atomicAdd(&p.hdr->grid_leaves, (unsigned long long)leaves);
       }
     }
-    // ---- rows the search did not decide: the whole block, one after the other
-    for (int sl = 0; sl < RPB; ++sl) {
-      const int m = s_scan[sl];                           // block-uniform
-      if (m != 0) grid_finish_row_by_scan<MODE, DIM>(p, row0 + sl, s_scan_thr[sl], m == 2, s_ops[sl], sh_s, sh_i);
+    // ---- an undecided row: to the block's list (scanned by the whole block at its end), or, the list full, by this wave now
+    if (__any(live && !decided)) {
+      const bool keep_all = bad || !have || overflow && !(thr > NEG_INF);
+      int pos = kGridScanCap;
+      if (live && !decided && sub == 0) {
+        atomicAdd(&p.hdr->fb_count, 1);
+        pos = atomicAdd(&s_nscan, 1);
+        if (pos < kGridScanCap) { s_scan_row[pos] = (int)(row << 1) | (keep_all ? 1 : 0); s_scan_thr[pos] = thr; }
+      }
+      pos = __shfl(pos, gshift);
+      for (int g = 0; g < RPW; ++g) {                                   // (wave-uniform loop: one group's row at a time, all 64 lanes)
+        const bool need = __shfl((int)(live && !decided && pos >= kGridScanCap), g * GROUP) != 0;
+        if (!need) continue;
+        const long srow = __shfl((int)row, g * GROUP);
+        const float sthr = __shfl(thr, g * GROUP);
+        const bool skeep = __shfl((int)keep_all, g * GROUP) != 0;
+        float sA[DIM], sB[DIM];
+        grid_load_coef<DIM>(p, srow, sA, sB);
+        double bs = 0.0;
+        int bi = 0x7fffffff;
+        bool hv = false;
+        grid_scan_accumulate<MODE, DIM>(p, sA, sB, s_ops[wave * RPW + g], sthr, skeep, lane, 64, bs, bi, hv);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const double os = __shfl_xor(bs, o);
+          const int oi = __shfl_xor(bi, o);
+          const bool oh = __shfl_xor((int)hv, o) != 0;
+          if (oh && (!hv || better_d(os, oi, bs, bi))) { bs = os; bi = oi; hv = true; }
+        }
+        if (hv) grid_write_result(p, srow, bi, lane, DIM);
+      }
     }
-    __syncthreads();
 #ifdef GQHIP_CLOCK_STAMPS
-    GQ_GRID_STAMP();     // 7: stores, scans, barrier
-    if (tid == 0 && vb == (int)blockIdx.x && blockIdx.x % 100 == 0 && blockIdx.x / 100 < 6) {   // six blocks' first row set, wave 0
+    GQ_GRID_STAMP();     // 6: reduce, stores
+    if (lane == 0 && first_pass_ && wave == 0 && blockIdx.x % 100 == 0 && blockIdx.x / 100 < 6) {   // six blocks' wave 0, first four rows
       for (int k = 0; k < 8; ++k) p.hdr->stamps[8 * (blockIdx.x / 100) + k] = k < nst_ ? st_[k] : 0ull;
     }
+    first_pass_ = false;
     nst_ = 8;
 #endif
+  }
+  // ---- the block's undecided rows: all 512 threads over ALL codes, one row after the other
+  __syncthreads();
+  const int nscan = min(s_nscan, kGridScanCap);
+  for (int i = 0; i < nscan; ++i) {
+    const long row = s_scan_row[i] >> 1;
+    const bool keep_all = (s_scan_row[i] & 1) != 0;
+    const float thr = s_scan_thr[i];
+    if (tid < DIM) {
+#pragma clang fp contract(off)
+      s_sops[tid] = p.mu[row * DIM + tid];
+      if constexpr (MODE == kModeGQ) {
+        const float sg = p.sd[row * DIM + tid];
+        s_sops[DIM + tid] = 2.0f * (sg * sg);
+        s_sops[2 * DIM + tid] = p.lsd[row * DIM + tid];
+      }
+    }
+    __syncthreads();
+    float sA[DIM], sB[DIM];
+    grid_load_coef<DIM>(p, row, sA, sB);
+    double bs = 0.0;
+    int bi = 0x7fffffff;
+    bool hv = false;
+    grid_scan_accumulate<MODE, DIM>(p, sA, sB, s_sops, thr, keep_all, tid, kGridThreads, bs, bi, hv);
+    sh_s[tid] = bs;
+    sh_i[tid] = hv ? bi : 0x7fffffff;
+    __syncthreads();
+    for (int o = kGridThreads / 2; o > 0; o >>= 1) {
+      if (tid < o) {
+        const double os = sh_s[tid + o];
+        const int oi = sh_i[tid + o];
+        const bool mine = sh_i[tid] != 0x7fffffff;
+        if (oi != 0x7fffffff && (!mine || better_d(os, oi, sh_s[tid], sh_i[tid]))) { sh_s[tid] = os; sh_i[tid] = oi; }
+      }
+      __syncthreads();
+    }
+    const int best = sh_i[0];
+    if (best != 0x7fffffff) grid_write_result(p, row, best, tid, DIM);
+    __syncthreads();
   }
 }
 

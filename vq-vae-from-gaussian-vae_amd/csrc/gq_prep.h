@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     p.hdr->fb_count = 0;
     p.hdr->reranked = 0ull;
     p.hdr->grid_leaves = 0ull;
+    p.hdr->grid_next = 0;
   }
 
 #if defined(GQHIP_ABL) && (GQHIP_ABL & 1024)   // diagnostic build (tools/abl_prep.sh): the code blocks do nothing

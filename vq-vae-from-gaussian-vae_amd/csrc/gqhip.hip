@@ -88,13 +88,15 @@ bool want_f16_filter() { return g_filter_kind.load(std::memory_order_relaxed) ==
 
 // Grid search (gq_grid.h) instead of filter + re-rank: dims 4 / 8, filter selection AUTO, 2^14 <= n <= 2^20 codes, and the caller
 // passed a codebook cache of gqhip_cb_cache_bytes().  GQHIP_GRID=0 disables it, =4 / =8 restricts it to one dim (A/B timing).
+bool grid_dim_enabled(int64_t dim) {
+  static const int env = getenv("GQHIP_GRID") ? atoi(getenv("GQHIP_GRID")) : 4;     // default: dim 4 only (dim 8 is slower than the
+  return env == 48 ? (dim == 4 || dim == 8) : (env != 0 && dim == env);              // dense path today: =8 / =48 for experiments)
+}
 int64_t grid_cache_bytes(int64_t n, int64_t dim) {
-  if ((dim != 4 && dim != 8) || n < 16384 || n > (1 << 20)) return 0;
+  if (!grid_dim_enabled(dim) || n < 16384 || n > (1 << 20)) return 0;
   return grid_layout(n, dim).total;
 }
 bool grid_applies(int64_t n, int64_t dim, const void *cache, int64_t cache_bytes) {
-  static const int env = getenv("GQHIP_GRID") ? atoi(getenv("GQHIP_GRID")) : 4;     // default: dim 4 only (dim 8: =8 / =48)
-  if (env == 0 || (env == 4 && dim != 4) || (env == 8 && dim != 8)) return false;
   const int64_t need = grid_cache_bytes(n, dim);
   return need > 0 && cache && cache_bytes >= need && g_filter_kind.load(std::memory_order_relaxed) == 0;
 }
@@ -492,11 +494,12 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     gp.cache = static_cast<const char *>(cb_cache);
     gp.idx = idx; gp.zhat = zhat; gp.hdr = hdr; gp.rows = (int)rows; gp.n = (int)n; gp.beta = (float)beta;
     static const int env_cap = getenv("GQHIP_GRID_CAP") ? atoi(getenv("GQHIP_GRID_CAP")) : 0;
-    gp.leaf_cap = env_cap > 0 ? env_cap : kGridLeafCap + 1;
+    gp.leaf_cap = env_cap > 0 ? env_cap : 256;     // leaves a row may visit before it is handed to the scan (a flat score)
     gp.stats = g_debug_stats; gp.omap = omap;
     static const int env_abl = getenv("GQHIP_GRID_ABL") ? atoi(getenv("GQHIP_GRID_ABL")) : 0;   // diagnostic builds (make abl) only
     gp.abl = env_abl;
-    const int64_t nsets = (rows + 31) / 32;
+    gp.next = &hdr->grid_next;
+    const int64_t nsets = (rows + 31) / 32;                        // (a block's eight waves fetch four rows at a time from a counter)
     const dim3 ggrid((unsigned)(nsets < 512 ? nsets : 512));       // two 512-thread blocks per CU: one wave of blocks
     ProfScope prof;
 #define GQ_GRID(D)                                                                                                   \
