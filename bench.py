@@ -183,10 +183,11 @@ def build_model(device, cfg):
     return vae.eval().to(device)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/<round>/pmc_FETCH_SIZE.csv,
-    pmc_WRITE_SIZE.csv: separate passes of tools/kbench.py at this shape; newest round that has the kernel).  Units
-    are KiB; gfx950 reports half of a wide coalesced read stream, so FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM).
+def pmc_traffic(kernel, config="gq_0.25"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of tools/kbench.py AT THIS CONFIG'S SHAPE
+    (profiles/<round>/pmc_FETCH_SIZE_<config>.csv, pmc_WRITE_SIZE_<config>.csv; for gq_0.25 -- BASELINE configs[1] -- also the
+    unsuffixed files of earlier rounds; newest round that has the kernel; None when no pass of this shape is committed).  Units are
+    KiB; gfx950 reports half of a wide coalesced read stream, so FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM).
     Returns (bytes | None, provenance)."""
     import csv
     import hashlib
@@ -195,7 +196,9 @@ def pmc_traffic(kernel):
     for rnd in sorted((d for d in os.listdir(prof) if d.startswith("r")), reverse=True) if os.path.isdir(prof) else []:
         vals, src = {}, {}
         for name in ("FETCH_SIZE", "WRITE_SIZE"):
-            path = os.path.join(prof, rnd, f"pmc_{name}.csv")
+            path = os.path.join(prof, rnd, f"pmc_{name}_{config}.csv")
+            if not os.path.exists(path) and config == "gq_0.25":
+                path = os.path.join(prof, rnd, f"pmc_{name}.csv")
             if not os.path.exists(path):
                 break
             rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
@@ -395,14 +398,18 @@ def reference_vq_forward(z, emb):
     return zq.permute(0, 3, 1, 2).contiguous(), ind.view(b, h, w, 1).permute(0, 3, 1, 2).contiguous()
 
 
-def reference_gpu_path(vae, x, cfg, product_indices, product_images_per_s, steps=3):
+def reference_gpu_path(vae, x, cfg, product_indices, product_images_per_s, steps=10, warmup=8):
     """Rank 0, N = 1, after the timed region: what the REFERENCE is on this device.  Same weights and input as the product
     path, but NCHW modules on ATen / MIOpen ops (reference_ops) and the reference's quantiser call sequence: backend="cuda",
     i.e. the extension_cpp::gq op into the persistent rows x 65 536 `perturbed` buffer, torch.argmax, index_select
     (pit/quantization/gaussian.py:124-133 / :289-298; VQ: the einsum distance matrix + argmin of vq.py:58-73; LFQ: elementwise,
     the product module itself).  The op behind `gq_cuda.ops.gq_cuda` is this repo's HIP build of it (the CUDA source cannot be
     built here) -- faster than the reference's one-thread-per-pair kernel would be, so the leg errs in the reference's favour.
-    1 warm-up + `steps` timed steps; the step = encode -> quantise -> decode -> PSNR -> pack, as in the product loop."""
+    `warmup` (>= 8: MIOpen's immediate mode runs a process's first eight calls of a convolution on a slow generic kernel) untimed
+    steps, then `steps` timed ones -- the same treatment as the product loop; the step = encode -> quantise -> decode -> PSNR ->
+    pack, as in the product loop.  Reported: the MEDIAN per-step device time (and the wall mean).  MIOpen in immediate mode
+    (torch.backends.cudnn.benchmark as the product loop has it, --miopen-benchmark); find mode costs minutes of warm-up on a
+    fresh box and measured the same steady state (main(), comment at cudnn.benchmark)."""
     import copy
 
     from pit_hip.eval_dist import StepRecord, psnr_zero_mean
@@ -452,7 +459,8 @@ def reference_gpu_path(vae, x, cfg, product_indices, product_images_per_s, steps
             if ev: ev[4].record()
             return ind
 
-        one()                                     # warm-up: MIOpen solver selection / kernel load, the `perturbed` allocation
+        for _ in range(max(warmup, 8)):           # MIOpen solver selection / kernel load / its slow first eight calls, `perturbed`
+            one()
         torch.cuda.synchronize()
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
         t0 = time.perf_counter()
@@ -461,13 +469,15 @@ def reference_gpu_path(vae, x, cfg, product_indices, product_images_per_s, steps
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / steps
     med = lambda i: sorted(e[i].elapsed_time(e[i + 1]) for e in evs)[steps // 2]
+    step_med_ms = sorted(e[0].elapsed_time(e[4]) for e in evs)[steps // 2]
     eq = float((ind.reshape(-1) == product_indices.reshape(-1).to(ind.device)).float().mean())
-    ips = x.shape[0] / wall
+    ips = x.shape[0] / (step_med_ms * 1e-3)
     return {
         "what": "the reference's own call sequence on this GPU, same weights / input / run: NCHW modules on ATen + MIOpen ops "
                 f"(GroupNorm, silu, conv2d + bias, scaled_dot_product_attention), quantiser = {seq} "
                 "(pit/quantization/gaussian.py:124-133); the gq op is this repo's HIP build (the CUDA source is unbuildable here)",
-        "images_per_s": round(ips, 2), "ms_per_step": round(wall * 1e3, 3), "steps": steps, "warmup": 1,
+        "images_per_s": round(ips, 2), "ms_per_step": round(step_med_ms, 3), "ms_per_step_wall_mean": round(wall * 1e3, 3),
+        "steps": steps, "warmup": max(warmup, 8), "statistic": "median per-step device time (torch events around the whole step)",
         "stages_ms": {"encoder": round(med(0), 3), "quantiser": round(med(1), 3), "decoder": round(med(2), 3),
                       "psnr+pack": round(med(3), 3)},
         "indices_equal_frac_vs_product": eq,
@@ -662,9 +672,41 @@ def main():
             bf16 = kind >= 1
             whole = flops / (stages["quantiser"] * 1e-3) / 1e12
             whole_b2b = flops / (call_us * 1e-6) / 1e12
-            if bf16:
+            grid = bool(_lib.lib().gqhip_grid_search_applies(N_CODES, dim)) and cfg["family"] != "lfq"
+            launch_names = None
+            if grid:
+                # dim 4: no filter / re-rank -- a pruned exact search over a cached box tree of the codebook (csrc/gq_grid.h)
+                kname = "gq_grid_kernel"
+                traffic, prov = pmc_traffic(kname, args.config)
+                with torch.no_grad():
+                    zq_ = vae.encoder(x)
+                    _lib.debug_enable(True)
+                    try:
+                        vae.regularization(zq_)
+                        torch.cuda.synchronize()
+                        gs = _lib.debug_grid(vae.regularization._ws)
+                    finally:
+                        _lib.debug_enable(False)
+                bf16 = True        # (priced against the dense fp16 / bf16 peak, like the filter it replaces)
+                launch_names = ("gq_prep_kernel", "gq_grid_build_kernel", kname)
+                roofline = {"kernel": f"{kname} (pruned exact search over a 16 -> 256 -> 1024-leaf box tree of the codebook held in LDS; it "
+                                      "replaces filter + re-rank at dim 4: the dense MFMA form is bound by the VALU fold of its own outputs "
+                                      "there, profiles/r04/pmc_filter_gq_1.00_dim4_round3_kernels.txt)",
+                            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                            "visited": {"leaves_per_row": round(gs["leaves"] / rows, 2), "leaves_total": 1024, "codes_per_leaf": N_CODES // 1024,
+                                        "fraction_of_the_codebook_scored": round(gs["leaves"] / rows / 1024, 5),
+                                        "exactly_scored_codes_per_row": round(gs["exact_codes"] / rows, 3),
+                                        "rows_scanned_over_all_codes": int(gs["scanned_rows"])},
+                            "note": "achieved = the DENSE algorithmic flops of the shape (SURVEY 8d: 4*dim*N per row) / launch time, against "
+                                    "the dense fp16 MFMA peak the replaced filter was priced on -- an equivalence rate, not work done: the "
+                                    "kernel scores `visited.fraction_of_the_codebook_scored` of the pairs (fp32 FMAs on the vector ALUs, no "
+                                    "matrix instruction) and is bound by dependent round trips and VALU issue (profiles/r05/"
+                                    "grid_search_variants.txt); indices bit-identical to the reference's either way",
+                            "traffic": traffic, "traffic_source": prov}
+            elif bf16:
                 kname = "gq_filter_bf16_kernel"
-                traffic, prov = pmc_traffic(kname)
+                traffic, prov = pmc_traffic(kname, args.config)
                 # executed work per algorithmic fp32 MAC, in bf16-rate MACs: split-bf16 = 3 bf16 MACs (A_h s_h + A_h s_l +
                 # A_l s_h); fp16 + fp8 = 1 fp16 MAC + 2 fp8 MACs on the block-scaled instruction (twice the bf16 rate) = 2
                 ex = {1: 3, 2: 2, 3: 1}[kind]
@@ -692,21 +734,21 @@ def main():
                                                "frac": round(flops / (fp32_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS, 4)}
             else:
                 kname = "gq_filter_kernel"
-                traffic, prov = pmc_traffic(kname)
+                traffic, prov = pmc_traffic(kname, args.config)
                 roofline = {"kernel": f"{kname} (fp32 MFMA filter of the fused quantiser)",
                             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": prov}
             peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
             roofline["whole_call"] = {
-                "what": "algorithmic flops / time of the WHOLE quantiser call (prep + filter + re-rank: three launches, + the "
-                        "module's torch ops), i.e. what a caller gets",
+                "what": "algorithmic flops / time of the WHOLE quantiser call (three launches: prep + filter + re-rank, or -- dim 4 -- "
+                        "prep + index check + search; + the module's torch ops), i.e. what a caller gets",
                 "in_step_ms": stages["quantiser"], "achieved": round(whole, 2), "frac": round(whole / peak, 4),
                 "back_to_back_us": round(call_us, 1), "back_to_back_achieved": round(whole_b2b, 2),
                 "back_to_back_frac": round(whole_b2b / peak, 4)}
             # HBM traffic of the WHOLE call: the three launches' PMC bytes summed (same committed passes as `traffic`)
             parts = {}
-            for kn in ("gq_prep_kernel", kname, "gq_rerank_kernel"):      # the call's three launches
-                tb, _ = pmc_traffic(kn)
+            for kn in launch_names or ("gq_prep_kernel", kname, "gq_rerank_kernel"):      # the call's three launches
+                tb, _ = pmc_traffic(kn, args.config)
                 parts[kn] = tb
             alg_bytes = rows * (2 * dim * 4 + 8 + dim * 4) + 4 * dim * N_CODES     # rows in / index + zhat out + codebook once
             if all(v is not None for v in parts.values()):
@@ -755,7 +797,10 @@ def main():
                               "(tools/conv3_bench.py, tools/bmm_bf16x3.py, tools/wino_gemm2_bench.py, tests/test_gpu_round2.py); "
                               "the decoder's conv_out (128 -> 3): fp32 FMAs; the encoder's conv_out (the layer that produces z) and the decoder's conv_in: "
                               "libgqhip's conv3x3_f32 on the fp32 matrix cores in a fixed summation order (bit-reproducible); the "
-                              "encoder's conv_in (3 -> 128): MIOpen native fp32 MFMA",
+                              "encoder's conv_in (3 -> 128): libgqhip's conv3x3_cin_small_f32, fp32 FMAs in a fixed order (no library "
+                              "convolution runs at this shape).  psnr+pack: gq_step_record_f32, ONE launch -- its per-image PSNR sums the "
+                              "reference's fp32 terms in fp64 and takes log10 in fp64, so it equals the torch fp32 expression "
+                              "(pit/evaluations/psnr.py:17-28) to ~2e-6 dB, not bit for bit (include/gqhip.h)",
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "dist_backend": args.dist_backend if world > 1 else None,
             "gather_ms": {"p50": pick(gather_ms, 0.5), "p90": pick(gather_ms, 0.9),
@@ -769,11 +814,13 @@ def main():
         if world == 1 and not args.no_reference_gpu:
             with torch.no_grad():
                 _, info_p = vae.encode(x, return_reg_log=True)
-            line["reference_gpu_path"] = reference_gpu_path(vae, x, cfg, info_p["indices"], line["value"])
-            # no published number exists for this metric; the same-node, same-run measurement of the reference's
-            # own GPU call sequence is the baseline this line is compared with
-            line["vs_baseline"] = line["reference_gpu_path"]["product_over_reference"]
-            line["vs_baseline_note"] = "value / reference_gpu_path.images_per_s (measured in this run; BASELINE.md has no published number)"
+            line["reference_gpu_path"] = reference_gpu_path(vae, x, cfg, info_p["indices"], line["value"],
+                                                            steps=min(max(args.steps, 3), 20), warmup=max(args.warmup, 8))
+            # `vs_baseline` stays null: BASELINE.md holds no published number for this metric.  The same-node, same-run measurement of
+            # the reference's own GPU call sequence is reported beside it (reference_gpu_path.product_over_reference), steady state
+            # against steady state.
+            line["vs_baseline_note"] = ("null: BASELINE.md has no published number for this metric; the reference's own GPU call sequence, "
+                                        "measured in this run with the same warm-up treatment, is in reference_gpu_path")
         if world == 1 and not args.no_cpu_baseline and cfg["family"] == "gq":
             line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(vae, x, cfg, args.channels_last)
         print(json.dumps(line), flush=True)

@@ -112,6 +112,9 @@ int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim);
  * Without a cache (NULL) every shape runs the filter + re-rank path.  (No reference counterpart: the reference recomputes
  * everything per call, pit/quantization/gaussian.py:136-150.) */
 int64_t gqhip_cb_cache_bytes(int64_t n, int64_t dim);
+/* 1 when a call with this codebook shape and a cache runs the pruned search (today: dim 4, 2^14 <= n <= 2^20, filter selection
+ * AUTO), 0 when it runs filter + re-rank (dims 8 / 16 / 32 then keep the filter's fp16 codebook image in the cache). */
+int gqhip_grid_search_applies(int64_t n, int64_t dim);
 
 /* ---- compat op: the reference's native boundary ---------------------------
  * out[r, j] = sum_i -((cb[j,i]-mu[r,i])/sd[r,i])^2 + cb[j,i]^2 * beta

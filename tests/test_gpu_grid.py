@@ -63,14 +63,10 @@ def _gq(mu, sd, cb, beta=1.0, ws=None):
     return idx.cpu().numpy(), zhat.cpu().numpy(), lsd, ws
 
 
-def _uses_grid(ws):
-    return ws.cache_buf is not None
-
-
 def _grid_dims():
     from pit_hip import _lib
 
-    return [d for d in (4, 8) if _lib.lib().gqhip_cb_cache_bytes(65536, d) > 0]
+    return [d for d in (4, 8) if _lib.lib().gqhip_grid_search_applies(65536, d)]
 
 
 @pytest.mark.parametrize("which", ["sobol", "uniform", "scaled", "clustered", "duplicates"])
@@ -83,9 +79,8 @@ def test_grid_indices_bit_exact_for_any_codebook(dim, n, rows, kind, which):
     mu, sd = _rows(rows, dim, 11 * dim + rows, kind)
     for beta in (1.0, 0.0):
         idx, zhat, lsd, ws = _gq(mu, sd, cb, beta)
-        assert _uses_grid(ws) == (dim in _grid_dims())
-        if _uses_grid(ws):
-            assert _lib.debug_grid(ws)["index_current"] == 1
+        if dim in _grid_dims():
+            assert ws.cache_buf is not None and _lib.debug_grid(ws)["index_current"] == 1
         ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb, beta, logstd=lsd)
         assert np.array_equal(idx, ref_idx), (kind, which, beta, int((idx != ref_idx).sum()))
         assert np.array_equal(zhat, ref_zhat)
@@ -110,7 +105,7 @@ def test_grid_vq_matches_the_fp64_arbiter(dim):
     z[:300] = emb[torch.randint(0, 65536, (300,), generator=g)] + 1e-4 * torch.randn(300, dim, generator=g)
     ws = _lib.Workspace()
     idx, zq = _lib.vq_argmin(z.to(DEV), emb.to(DEV), ws=ws)
-    assert _uses_grid(ws) == (dim in _grid_dims())
+    assert ws.cache_buf is not None or dim not in _grid_dims()
     oi = O.vq_argmin_rows(z.numpy(), emb.numpy())
     assert np.array_equal(idx.cpu().numpy(), oi)
     assert np.array_equal(zq.cpu().numpy(), emb.numpy()[oi])
@@ -254,3 +249,44 @@ def test_grid_prunes(dim, kind, limit):
     assert per_row <= limit and g["scanned_rows"] == 0
     ref_idx, _ = O.argmax_rows(mu.numpy()[:1024], sd.numpy()[:1024], cb, 1.0, logstd=lsd[:1024])
     assert np.array_equal(idx[:1024], ref_idx)
+
+
+@pytest.mark.parametrize("dim", [16, 8, 32])
+def test_cached_codebook_image_is_validated_slice_by_slice(dim):
+    """Dims 8 / 16 / 32: the fp16 operand image of the codebook lives in the codebook cache; each of its 256 slices is validated by
+    the code block of the first launch that owns it (content hash of the slice's codes) and rebuilt only when stale.  An unchanged
+    codebook writes nothing; an edit through .data (no version bump) rewrites exactly the slices it touches and the call already
+    sees it; garbage in the buffer is repaired; another codebook of the same shape replaces everything."""
+    from pit_hip import _lib
+
+    n, rows = 65536, 640
+    if _lib.lib().gqhip_cb_cache_bytes(n, dim) <= 0:
+        pytest.skip("no cached image for this dim with the current filter selection")
+    cb0 = O.codebook(n, dim, 42)
+    cbt = torch.from_numpy(cb0.copy()).to(DEV)
+    mu, sd = _rows(rows, dim, 21)
+    ws = _lib.Workspace()
+
+    def check(cb_np):
+        idx, zhat, lsd, _ = _gq(mu, sd, cbt, ws=ws)
+        ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb_np, 1.0, logstd=lsd)
+        assert np.array_equal(idx, ref_idx) and np.array_equal(zhat, ref_zhat)
+        return idx
+
+    i0 = check(cb0)
+    snap = ws.cache_buf.clone()
+    check(cb0)
+    assert torch.equal(ws.cache_buf, snap)                         # current slices are not rewritten
+    cb1 = cb0.copy()
+    cb1[i0[0], :] += 3.0                                           # the winner of row 0 moves away
+    cbt.data[int(i0[0]), :] += 3.0
+    i1 = check(cb1)
+    assert i1[0] != i0[0]
+    changed = (ws.cache_buf != snap).view(-1)
+    hashes = changed[320:320 + 2048].view(256, 8).any(1)           # gq_grid.h:GridHdr.blk_sum (256 x u64 at byte 320)
+    assert int(hashes.sum()) == 1                                  # ONE slice was restamped: the one that holds the edited code
+    ws.cache_buf.copy_(torch.randint(0, 255, ws.cache_buf.shape, dtype=torch.uint8, device=DEV))
+    check(cb1)
+    cb2 = np.random.default_rng(1).normal(0, 1, (n, dim)).astype(np.float32)
+    cbt.data.copy_(torch.from_numpy(cb2))
+    check(cb2)

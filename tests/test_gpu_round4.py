@@ -224,6 +224,52 @@ def test_statistics_arena_changes_no_bit_and_survives_reentry():
     assert enc.__dict__["_gq_stats_arena"].buf is not None and enc.__dict__["_gq_stats_arena"].used > 0
 
 
+@pytest.mark.e2e
+def test_statistics_arena_is_per_stream_and_never_baked_into_a_graph():
+    """(1) a captured forward must not hold the arena's address -- an eager forward with a bigger batch afterwards
+    reallocates the arena, and the replay would zero / accumulate into freed memory: captured forwards take per-call records;
+    (2) two streams running the same module must not share one arena (one forward's re-zeroing would wipe records the other is
+    still accumulating): one arena per (thread, stream).  Bit-equality with the eager result in both cases."""
+    from pit_hip.modules import unet as U
+
+    torch.manual_seed(1234)
+    enc = U.Encoder(**FULL).eval().to(DEV).to(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(5)
+    x2 = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    x4 = (torch.rand(4, 3, 256, 256, generator=g) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref2 = enc(x2).clone()
+        ref4 = enc(x4).clone()
+        enc(x2)                                            # arena sized for the smaller batch again? (it only grows) -- and warm
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                yg = enc(x2)
+        assert "_gq_stats_arenas" in enc.__dict__
+        for a in enc.__dict__["_gq_stats_arenas"].values():     # force the hazard: every arena is dropped and its memory recycled
+            a.buf = None
+        junk = [torch.full((1 << 20,), 7, dtype=torch.int64, device=DEV) for _ in range(8)]
+        assert torch.equal(enc(x4), ref4)                  # eager, bigger batch: new arena
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, ref2)
+        del junk
+        # two streams, interleaved forwards of the same module
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                outs.append((enc(x4), ref4))
+            with torch.cuda.stream(s2):
+                outs.append((enc(x2), ref2))
+        torch.cuda.synchronize()
+        assert len(enc.__dict__["_gq_stats_arenas"]) >= 3
+        for y, r in outs:
+            assert torch.equal(y, r)
+
+
 # ------------------------------------------------------------------------------------------ g16: the other quantiser shapes, trained-like z
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_g16_groupings_at_the_trained_operating_point_vs_reference_golden(channels_last):

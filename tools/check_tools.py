@@ -1,4 +1,5 @@
 """Do the scripts in tools/ still run against the library as it is (C ABI version, pit_hip._lib, the switches of pit_hip.modules.unet)?
+tools/ = this round's recipes; tools/convstack/ = the (frozen) conv stack's benches and diagnoses; tools/calibration/ = hardware probes.
 Static checks only (no GPU needed): every .py byte-compiles, every attribute it reads from `_lib` / `U` (= pit_hip.modules.unet) /
 `bench` exists today, every .sh parses; `--hip`: every .hip probe compiles for gfx950.  Exit code 1 lists what is stale.
 
@@ -32,7 +33,7 @@ def main():
 
     targets = {"_lib": _lib, "U": unet, "unet": unet, "bench": bench}
     bad = []
-    files = sorted(os.listdir(HERE))
+    files = sorted(os.path.relpath(os.path.join(d, f), HERE) for d, _, fs in os.walk(HERE) for f in fs if "__pycache__" not in d)
     for f in files:
         path = os.path.join(HERE, f)
         if f.endswith(".py"):

@@ -57,7 +57,7 @@ def main():
     ex = {1: 3, 2: 2, 3: 1}.get(kind, 1)   # bf16-rate MACs executed per algorithmic MAC (fp16 + fp8: 1 fp16 + 2 fp8 at twice the rate)
     rate = (f"{tf:.1f} algorithmic TFLOP/s = {tf/157.3:.2f}x the fp32 MFMA peak; executed {ex}x = {ex*tf:.0f} TFLOP/s bf16-equivalent "
             f"({ex*tf/2500*100:.1f}% of 2500)") if bf16 else f"{tf:.1f} TFLOP/s ({tf/157.3*100:.1f}% of 157.3)"
-    if ws.cache_buf is not None and (a.filter in (None, "auto")):     # dims 4 / 8: the pruned search replaced filter + re-rank
+    if _lib.lib().gqhip_grid_search_applies(a.n, a.dim):     # dim 4: the pruned search replaced filter + re-rank
         _lib.debug_enable(True)
         _lib.gq_argmax(mu, sd, cb, 1.0, ws=ws)
         torch.cuda.synchronize()

@@ -748,7 +748,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     }
     // ---- an undecided row: to the block's list (scanned by the whole block at its end), or, the list full, by this wave now
     if (__any(live && !decided)) {
-      const bool keep_all = bad || !have || overflow && !(thr > NEG_INF);
+      const bool keep_all = bad || !have || (overflow && !(thr > NEG_INF));
       int pos = kGridScanCap;
       if (live && !decided && sub == 0) {
         atomicAdd(&p.hdr->fb_count, 1);

@@ -109,6 +109,29 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     unsigned long long hsum = 0ull;
     if (p.cbimg) {
       const long items = (long)p.tiles_total * 64;   // (tile, half, code)
+      // A CACHED image (F16 with a codebook cache, gqhip.h): pass 0 only reads -- max |cb|, the norm bound and the content hash of this
+      // block's slice of the codebook --; if the hash is the one this slice of the image was built from, the slice is current and
+      // nothing is written; otherwise pass 1 rebuilds it (from L2-hot data) and the block restamps its hash.  Slices are disjoint, so
+      // every block validates and repairs its own: no flag, no other kernel, and an edit of the codebook by any route is seen here.
+      const bool cached = F16 && p.cache_sums != nullptr && p.cache_stale == nullptr;
+      __shared__ unsigned long long s_h2[4];
+      __shared__ int s_slice_current;
+      for (int pass = 0; pass < (cached ? 2 : 1); ++pass) {
+      const bool do_write = !cached || pass == 1;
+      if (cached && pass == 1) {
+        unsigned long long hh = hsum;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hh += __shfl_xor(hh, o);
+        if ((tid & 63) == 0) s_h2[tid >> 6] = hh;
+        __syncthreads();
+        if (tid == 0) {
+          const unsigned long long h = s_h2[0] + s_h2[1] + s_h2[2] + s_h2[3];
+          s_slice_current = p.cache_sums[cbk] == h ? 1 : 0;
+          if (!s_slice_current) p.cache_sums[cbk] = h;          // (restamped by the block that rewrites the slice below)
+        }
+        __syncthreads();
+        if (s_slice_current) break;
+      }
       for (long t = (long)cbk * 256 + tid; t < items; t += (long)kPrepCodeBlocks * 256) {
         const int tile = (int)(t >> 6), c = (int)t & 31, h = (int)(t >> 5) & 1;
         const long code = (long)tile * 32 + c;
@@ -122,11 +145,15 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
             nv[k] = code < p.n ? p.cb[code * DIM + k] : 0.0f;
-            const float a = fabsf(nv[k]);
-            amax = (a != a) ? __builtin_inff() : __builtin_fmaxf(amax, a);
-            r2 = __builtin_fmaf(nv[k], nv[k], r2);
+            if (pass == 0) {
+              const float a = fabsf(nv[k]);
+              amax = (a != a) ? __builtin_inff() : __builtin_fmaxf(amax, a);
+              r2 = __builtin_fmaf(nv[k], nv[k], r2);
+              if (h == 0 && code < p.n) hsum += cb_hash_term(nv[k], code * DIM + k);
+            }
           }
-          r2max = (r2 != r2) ? __builtin_inff() : __builtin_fmaxf(r2max, r2);
+          if (pass == 0) r2max = (r2 != r2) ? __builtin_inff() : __builtin_fmaxf(r2max, r2);
+          if (!do_write) continue;
           typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #pragma unroll
           for (int m = 0; m < NV; ++m) {
@@ -222,6 +249,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
           }
         }
       }
+      }   // pass
     } else {
       // no operand image in this call (fp32 filter; grid search, gq_grid.h): max |cb| and the content hash of this block's slice
       const long count = (long)p.n * DIM;
@@ -247,7 +275,8 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
       p.hdr->r2_part[cbk] = __builtin_fmaxf(__builtin_fmaxf(s_r2[0], s_r2[1]), __builtin_fmaxf(s_r2[2], s_r2[3]));
       const unsigned long long h = s_hsum[0] + s_hsum[1] + s_hsum[2] + s_hsum[3];
       p.hdr->cbsum[cbk] = h;
-      if (p.cache_sums && p.cache_sums[cbk] != h) *p.cache_stale = 1;     // the cache was built from other bytes: rebuilt before its use
+      // grid index (gq_grid.h): built from other bytes -> rebuilt, by the one-block kernel that follows, before its use
+      if (p.cache_sums && p.cache_stale && p.cache_sums[cbk] != h) *p.cache_stale = 1;
     }
     return;
   }

@@ -100,6 +100,10 @@ bool grid_applies(int64_t n, int64_t dim, const void *cache, int64_t cache_bytes
   const int64_t need = grid_cache_bytes(n, dim);
   return need > 0 && cache && cache_bytes >= need && g_filter_kind.load(std::memory_order_relaxed) == 0;
 }
+// Dims 8 / 16 / 32 (the fp16 main-product filter): the codebook's fp16 operand image is kept in the cache, every 1/256 slice of it
+// validated against -- and, when stale, rebuilt and restamped by -- the code block of the first launch that owns it (gq_prep.h).
+// GQHIP_IMG_CACHE=0 disables it (A/B timing): the image is then rebuilt in the workspace on every call, as before round 5.
+int64_t image_cache_bytes(int64_t n, int64_t dim);   // (needs make_plan)
 
 Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
   Plan pl{};
@@ -167,6 +171,14 @@ Plan make_plan(int64_t rows, int64_t n, int64_t dim) {
 }
 
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+int64_t image_cache_bytes(int64_t n, int64_t dim) {
+  static const bool off = getenv("GQHIP_IMG_CACHE") && atoi(getenv("GQHIP_IMG_CACHE")) == 0;
+  if (off || (dim != 8 && dim != 16 && dim != 32) || n < 1 || g_filter_kind.load(std::memory_order_relaxed) != 0) return 0;
+  const Plan pl = make_plan(65536, n, dim);       // (what the image depends on -- tiles, chunk padding, vectors -- does not depend on rows)
+  if (!pl.f16) return 0;
+  return (int64_t)sizeof(GridHdr) + align256((int64_t)(pl.tiles_total + pl.ct) * (dim / 8) * 64 * 16);
+}
 
 struct WsLayout {
   int64_t hdr, rec, fb, dbg, mu, sd, lsd, rowsum, coef, cbimg, rowimg, rowscale, rowaux, total;
@@ -511,6 +523,12 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
 #undef GQ_GRID
     return check_launch();
   }
+  if (f16 && cb_cache && image_cache_bytes(n, dim) > 0 && cb_cache_bytes >= image_cache_bytes(n, dim)) {
+    GridHdr *ih = reinterpret_cast<GridHdr *>(cb_cache);          // (only its slice hashes are used: a slice is current iff its hash matches)
+    pp.cbimg = reinterpret_cast<u32x4 *>(static_cast<char *>(cb_cache) + sizeof(GridHdr));
+    pp.cache_sums = ih->blk_sum;
+    pp.cache_stale = nullptr;
+  }
   int rc = from_z ? launch_prep<MODE, true>(pp, (int)dim, mixed, f16, st) : launch_prep<MODE, false>(pp, (int)dim, mixed, f16, st);
   if (rc != GQHIP_OK) return rc;
 
@@ -582,9 +600,12 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
   return GQHIP_OK;
 }
 
+int gqhip_grid_search_applies(int64_t n, int64_t dim) { return grid_cache_bytes(n, dim) > 0 && g_filter_kind.load(std::memory_order_relaxed) == 0; }
+
 int64_t gqhip_cb_cache_bytes(int64_t n, int64_t dim) {
   if (n < 1 || dim < 1 || dim > kMaxDim) return -1;
-  return grid_cache_bytes(n, dim);
+  const int64_t g = grid_cache_bytes(n, dim);
+  return g > 0 ? g : image_cache_bytes(n, dim);
 }
 
 int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim) {

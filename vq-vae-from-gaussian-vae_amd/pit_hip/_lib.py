@@ -36,6 +36,7 @@ _SIGNATURES = {
     "gqhip_last_hip_error": (ctypes.c_int, []),
     "gqhip_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gqhip_cb_cache_bytes": (_i64, [_i64, _i64]),
+    "gqhip_grid_search_applies": (ctypes.c_int, [_i64, _i64]),
     "gqhip_debug_grid": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_i64)]),
     "gqhip_set_filter": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_get_filter": (ctypes.c_int, []),
@@ -457,8 +458,8 @@ def gn_silu(x, gamma, beta, groups: int, eps: float, silu: bool = True, pre_bias
         raise GqHipError("gn_silu needs a dense fp32 NCHW / channels_last HIP tensor")
     B, C = x.shape[0], x.shape[1]
     HW = x.shape[2] * x.shape[3]
-    # statistics scratch: a fresh (stream-ordered, caching-allocator) tensor per call -- a process-global buffer would be
-    # shared by concurrent streams / models and baked into captured graphs
+    # statistics scratch: from the forward's arena (one per module, thread and stream, never under a graph capture:
+    # modules/unet.py:_with_stats_arena) or a fresh stream-ordered tensor from the caching allocator
     ws = _stats_records(GNSTAT_WORDS * B * groups, x.device)
     y = torch.empty_like(x)  # preserves the memory format
     with torch.cuda.device(x.device):

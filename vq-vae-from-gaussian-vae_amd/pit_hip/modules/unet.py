@@ -409,15 +409,24 @@ class _WeightGuard:
 
 
 def _with_stats_arena(module: nn.Module, run, x: torch.Tensor):
-    """run(x) with every GroupNorm statistics record of the forward carved out of the module's arena (one fill per forward instead
-    of one small memset launch per producing kernel: _lib.StatsArena)."""
-    if not (STATS_ARENA and FUSED_GN and x.is_cuda and not torch.is_grad_enabled()):
+    """run(x) with every GroupNorm statistics record of the forward carved out of an arena of the module (one fill per forward
+    instead of one small memset launch per producing kernel: _lib.StatsArena).  One arena per (thread, stream): the buffer is
+    re-zeroed and reused in stream order, so two streams (or threads) running the same module must not share it.  Never under a
+    graph capture: a captured graph would bake in the arena's address, and a later eager forward with a bigger batch reallocates
+    the buffer -- the replay would then zero and accumulate into memory the allocator may have handed to someone else; captured
+    forwards take per-call records from the caching allocator, which the capture keeps alive."""
+    if not (STATS_ARENA and FUSED_GN and x.is_cuda and not torch.is_grad_enabled()) or torch.cuda.is_current_stream_capturing():
         return run(x)
+    import threading
+
     from .. import _lib
 
-    arena = module.__dict__.get("_gq_stats_arena")
+    key = (threading.get_ident(), torch.cuda.current_stream(x.device).cuda_stream)
+    arenas = module.__dict__.setdefault("_gq_stats_arenas", {})
+    arena = arenas.get(key)
     if arena is None:
-        arena = module.__dict__["_gq_stats_arena"] = _lib.StatsArena()
+        arena = arenas[key] = _lib.StatsArena()
+        module.__dict__.setdefault("_gq_stats_arena", arena)      # (the first one: what tests / tools look at)
     with _lib.stats_arena(arena, x.device):
         return run(x)
 
