@@ -92,3 +92,18 @@ def test_rank_count_mismatch_fails_fast_with_a_message():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert p.returncode == 2 and "torch.distributed.run" in p.stderr
+
+
+def test_more_rccl_ranks_than_devices_exits_2_before_any_rendezvous_or_device_context():
+    """the first real 8-GPU driver run must not die in argument handling -- and a box with fewer devices than
+    `--gpus` must be told so at once: a rank of an 8-rank RCCL launch (RANK / WORLD_SIZE / MASTER_* set, as `python -m
+    torch.distributed.run --nproc-per-node 8` sets them) on a box with fewer than 8 visible devices exits 2 with the explanatory
+    message BEFORE init_process_group (nobody listens on the port: a rendezvous would hang) and before any HIP call
+    (torch.cuda.device_count() does not create a context).  eval.py:78-107 is the reference's launch."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="8", LOCAL_WORLD_SIZE="8", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "nccl", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2, (p.returncode, p.stderr[-400:])
+    assert "needs 8 devices" in p.stderr and "--dist-backend gloo" in p.stderr
+    assert p.stdout.strip() == ""

@@ -214,6 +214,19 @@ def test_reference_smoke_loop_shape_max_size(filter_kind):
     # abs(randn) sigmas (tiny ones included): ~3 % of the rows are left undecided by the fp32 filter (finished by the in-block fp64 scan);
     # the wider margins of the 16-bit filters leave more of these ill-conditioned rows undecided (still exact)
     assert fb < (rows // 10 if filter_kind == "fp32" else rows // 2), f"fallback rows {fb}"
+    # The in-block scan's worst case has a price: an undecided row re-reads its record sets' codes -- up to the whole
+    # L2-resident codebook -- by itself, so a call with tens of thousands of such rows costs milliseconds where a decided call costs
+    # 0.3 ms (profiles/r04/conditioning_and_smoke_shape.txt: 14.4 ms at this shape behind the fp16 filter, 9.7 ms behind fp32).  The
+    # bound documents and pins that cliff: 4x the measured figure; a regression to "every row scans every set" would be ~80 ms.
+    mud, sdd, nd = mu.to(dev), sd.to(dev), noise.to(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.gq_argmax(mud, sdd, nd, 1.0, ws=ws)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b)
+    print(f"smoke-loop shape, filter {filter_kind}: {fb} of {rows} rows finished by the in-block scan, call {ms:.2f} ms")
+    assert ms < 60.0, ms
     # compat op on the first 64 rows: same arg-max wherever the top-2 gap is not a rounding tie
     out = torch.zeros(64, n, device=dev)
     _lib.gq_scores(mu[:64].to(dev), sd[:64].to(dev), noise.to(dev), out, 1.0)

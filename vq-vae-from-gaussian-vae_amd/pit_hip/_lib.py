@@ -195,7 +195,9 @@ class Workspace:
         return self.cache_buf.data_ptr(), self.cache_buf.numel()
 
     def reserve(self, rows: int, n: int, dim: int, device) -> None:
+        """Size the scratch and the codebook cache for a shape ahead of a graph capture."""
         self.get(rows, n, dim, device)
+        self.cache(n, dim, device)
 
     def get(self, rows: int, n: int, dim: int, device) -> Tuple[int, int]:
         need = lib().gqhip_workspace_bytes(rows, n, dim)
