@@ -933,11 +933,15 @@ def test_bench_line_contract_small_run():
     assert allr["rows"] == 16384 and allr["images"] == 16 and allr["indices_equal_frac"] == 1.0
     assert allr["indices_differing"] == 0 and allr["zhat_bit_equal"] is True
     assert "256x256" in line["metric"]
-    # round 4: the reference's own GPU call sequence timed in the same run, and vs_baseline against it
+    # the reference's own GPU call sequence timed in the same run with the product loop's treatment (>= 8 warm-ups, median step);
+    # vs_baseline itself stays null: BASELINE.md publishes no number for this metric
     ref = line["reference_gpu_path"]
-    assert ref["images_per_s"] > 10 and ref["steps"] == 3 and set(ref["stages_ms"]) == {"encoder", "quantiser", "decoder", "psnr+pack"}
+    assert ref["images_per_s"] > 10 and ref["steps"] >= 3 and ref["warmup"] >= 8
+    assert set(ref["stages_ms"]) == {"encoder", "quantiser", "decoder", "psnr+pack"}
     assert ref["indices_equal_frac_vs_product"] >= 0.995
-    assert abs(line["vs_baseline"] - line["value"] / ref["images_per_s"]) < 0.02 * line["vs_baseline"] and line["vs_baseline"] > 1.0
+    assert line["vs_baseline"] is None and "null" in line["vs_baseline_note"]
+    assert abs(ref["product_over_reference"] - line["value"] / ref["images_per_s"]) < 0.02 * ref["product_over_reference"]
+    assert ref["product_over_reference"] > 1.0
     wt = rf["whole_call_traffic"]
     assert wt and wt["bytes"] > rf["traffic"] and set(wt["per_kernel"]) >= {"gq_prep_kernel", "gq_rerank_kernel"} and len(wt["per_kernel"]) == 3
     assert par["reference_top2_gap_at_differing_rows"] == [] or max(par["reference_top2_gap_at_differing_rows"]) < bench.GATES["near_tie_gap"]
