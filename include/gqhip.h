@@ -135,7 +135,9 @@ int gq_scores_f32(const float *mu, const float *sd, const float *cb, float *out,
  * logsd_or_null: log(sd) as the caller computed it; NULL -> the kernel uses
  *           float(log(double(sd))) (correctly rounded).
  * dim: any 1..64 (4, 8, 16, 32 run on the MFMA filter; others exhaustive).
- * Three launches on `stream` for the MFMA dims: prep (operand images, bound sums,
+ * Dim 4 with a codebook cache: prep -> index check -> pruned exact search -> finish of the rows it left undecided
+ * (csrc/gq_grid.h; four launches, the second and fourth exit at once in the common case).
+ * Three launches on `stream` for the other MFMA dims: prep (operand images, bound sums,
  * max|cb|) -> filter -> exact re-rank (rows the filter leaves undecided are
  * finished inside it by a block-wide scan of their record sets). */
 int gq_argmax_f32(const float *mu, const float *sd, const float *logsd_or_null,

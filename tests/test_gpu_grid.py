@@ -231,8 +231,9 @@ def test_grid_path_is_graph_capturable_and_sees_edits_on_replay():
 @pytest.mark.parametrize("dim,kind,limit", [(4, "trained", 8.0), (4, "linear", 20.0)])
 def test_grid_prunes(dim, kind, limit):
     """The point of the formulation: leaves visited per row (of 1024; a leaf = 64 codes of the 65 536): ~4 at the trained operating
-    point, ~11 in the near-linear regime of sigma ~ 1 (the upper levels' boxes bound a nearly linear score poorly); no row is
-    handed to the scan."""
+    point, ~9 in the near-linear regime of sigma ~ 1 (a nearly linear score reaches into the codebook's tails, where leaves are
+    large and their boxes loose); there a percent or so of the rows has more candidate leaves than the list holds even after one
+    rebuild and is handed to the block's two-pass scan."""
     from pit_hip import _lib
 
     cb = O.codebook(65536, dim, 42)
@@ -246,7 +247,7 @@ def test_grid_prunes(dim, kind, limit):
     per_row = g["leaves"] / 8192
     print(f"dim {dim}, {kind}: {per_row:.1f} leaves and {g['exact_codes'] / 8192:.2f} exactly scored codes per row, "
           f"{g['scanned_rows']} rows scanned")
-    assert per_row <= limit and g["scanned_rows"] == 0
+    assert per_row <= limit and g["scanned_rows"] <= (0 if kind == "trained" else 8192 // 25)
     ref_idx, _ = O.argmax_rows(mu.numpy()[:1024], sd.numpy()[:1024], cb, 1.0, logstd=lsd[:1024])
     assert np.array_equal(idx[:1024], ref_idx)
 

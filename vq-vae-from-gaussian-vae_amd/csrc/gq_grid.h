@@ -22,9 +22,11 @@
 //     U^ >= F - 2 E32 - 2 E_r >= F - margin32: the box is visited, at either level, whatever F was at the time (F only grows).
 //   * Inside a leaf, j* has f^(j*) >= F - 2 E32 - 2 E_r >= F - margin32 as well, so it receives the reference's arithmetic; the
 //     winner among everything that did is taken in torch.argmax order (score, then lowest index; NaN first).
-//   * Rows with a non-finite operand or bound, any non-finite codebook (max|cb| not finite) and rows whose leaf list overflows
-//     (a flat score: everything within the margin) are finished by the whole block with a scan of ALL codes -- the re-rank's
-//     exhaustive semantics -- after the block's other rows have left.
+//   * Rows the search does not decide go to a list and are finished by gq_grid_finish_kernel (the launch after the search; it exits
+//     at once when the list is empty), a block per row: a row whose leaf list does not fit even after one rebuild (a long tail of
+//     loose boxes: nearly linear scores reach into the codebook's tails, where leaves are large) over its candidate leaves -- pass 1
+//     the largest expansion, pass 2 the reference's arithmetic within the margin --; rows with a non-finite operand or bound, or
+//     behind a non-finite codebook, over ALL codes, everything exact (the re-rank's exhaustive semantics).
 //
 // The index lives in a caller-owned, persistent buffer (the "codebook cache": gqhip_cb_cache_bytes), is validated on EVERY call
 // against a content hash of the codebook the caller passes (the first launch hashes it anyway while it reduces max|cb|), and is
@@ -285,15 +287,20 @@ struct GridParams {
   int rows, n;
   float beta;
   int leaf_cap;                    // leaves a row may visit before it is handed to the block-wide scan
+  int inwave_cap;                  // listed leaves a row's 16 lanes walk themselves; a longer list goes to gq_grid_finish_kernel
   int stats;
-  int *next;                       // work counter of the search (WsHeader.grid_next; zeroed by the first launch): four rows per fetch
+  int *und_row;                    // [rows] undecided rows, appended by the search ((row << 1) | keep_all), finished by gq_grid_finish_kernel
+  float *und_thr, *und_margin;     // [rows] their threshold so far and margin32
   int abl;                         // diagnostic builds only (GQHIP_ABL): 1 = no search, 2 = greedy descent only (wrong results, timing)
   OutMap omap;
 };
 
-// max over the box [lo, hi] of sum_i A_i v_i^2 + B_i v_i: per axis at the clamped vertex (A < 0) or at the better endpoint
+// max over the box [lo, hi] of sum_i A_i v_i^2 + B_i v_i: per axis at the clamped vertex (A < 0) or at the better endpoint.
+// `concave` (wave-uniform): every axis of every row of the wave has A < 0 -- the trained operating point, sigma < 1 / sqrt(beta) --
+// and the endpoint arithmetic is skipped (3 instead of 8 instructions per axis; the search is VALU-issue bound).
 template <int DIM>
-__device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float (&B)[DIM], const float (&M)[DIM], const float *box) {
+__device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float (&B)[DIM], const float (&M)[DIM], const float *box,
+                                             bool concave) {
   float lo[DIM], hi[DIM];
   const f32x4 *q = reinterpret_cast<const f32x4 *>(box);
 #pragma unroll
@@ -303,12 +310,20 @@ __device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float 
     hi[4 * k] = b.x; hi[4 * k + 1] = b.y; hi[4 * k + 2] = b.z; hi[4 * k + 3] = b.w;
   }
   float u = 0.0f;
+  if (concave) {
 #pragma unroll
-  for (int i = 0; i < DIM; ++i) {
-    const float vin = __builtin_amdgcn_fmed3f(M[i], lo[i], hi[i]);
-    const float e = __builtin_fmaf(A[i], hi[i] + lo[i], B[i]) > 0.0f ? hi[i] : lo[i];
-    const float v = A[i] < 0.0f ? vin : e;
-    u = __builtin_fmaf(__builtin_fmaf(A[i], v, B[i]), v, u);
+    for (int i = 0; i < DIM; ++i) {
+      const float v = __builtin_amdgcn_fmed3f(M[i], lo[i], hi[i]);
+      u = __builtin_fmaf(__builtin_fmaf(A[i], v, B[i]), v, u);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const float vin = __builtin_amdgcn_fmed3f(M[i], lo[i], hi[i]);
+      const float e = __builtin_fmaf(A[i], hi[i] + lo[i], B[i]) > 0.0f ? hi[i] : lo[i];
+      const float v = A[i] < 0.0f ? vin : e;
+      u = __builtin_fmaf(__builtin_fmaf(A[i], v, B[i]), v, u);
+    }
   }
   return lo[0] <= hi[0] ? u : -__builtin_inff();     // empty node (or a NaN box: never visited; such books are scanned)
 }
@@ -341,9 +356,8 @@ constexpr int kGridThreads = 512;      // 8 waves x 4 rows: 32 rows per block pa
 //   (4) with the FINAL threshold, the lanes whose best code is within the margin give it the reference's arithmetic -- ONE instance
 //       of that long, divergent code per row; a lane with a SECOND code within the margin (a near-tie) sends the row through all
 //       its visited leaves again with the exact score for everything within the margin.
-// Undecided rows (non-finite operands or bounds, a non-finite codebook, lists that never fit) are scanned over ALL codes by the
-// whole block after its waves have run out of work (up to kGridScanCap per block; beyond that by the wave itself).
-constexpr int kGridScanCap = 64;
+// Undecided rows (non-finite operands or bounds, a non-finite codebook, a list that does not fit after one rebuild) go to the call's
+// list and are finished by gq_grid_finish_kernel, the next launch.
 
 template <int MODE, int DIM>
 __device__ __forceinline__ void grid_scan_accumulate(const GridParams &p, const float (&cA)[DIM], const float (&cB)[DIM], const float *ops,
@@ -411,12 +425,6 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   __shared__ int s_leaflist[RPB][kGridLeafCap];
   __shared__ float s_leafub[RPB][kGridLeafCap];
   __shared__ unsigned s_visited[RPB][kGridLeaves / 32];
-  __shared__ int s_nscan;
-  __shared__ int s_scan_row[kGridScanCap];              // (row << 1) | keep_all
-  __shared__ float s_scan_thr[kGridScanCap];
-  __shared__ float s_sops[3 * DIM + 1];
-  __shared__ double sh_s[kGridThreads];
-  __shared__ int sh_i[kGridThreads];
   const GridLayout L = grid_layout(p.n, DIM);
   const float *scb = reinterpret_cast<const float *>(p.cache + L.scb);
   const int *sidx = reinterpret_cast<const int *>(p.cache + L.sidx);
@@ -437,7 +445,6 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     const f32x4 *src2 = reinterpret_cast<const f32x4 *>(p.cache + L.start);
     f32x4 *dst2 = reinterpret_cast<f32x4 *>(s_start);
     for (int k = tid; k < START_N / 4; k += kGridThreads) dst2[k] = src2[k];
-    if (tid == 0) s_nscan = 0;
   }
   const float *s_box2 = s_box + kGridL1 * BOXF, *s_box3 = s_box + (kGridL1 + kGridL2) * BOXF;
   const float N1f = wave_absmax(p.hdr->absmax_part, lane);
@@ -481,8 +488,15 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     unsigned *visited = s_visited[slot];
 #pragma unroll
     for (int k = 0; k < kGridLeaves / 32 / GROUP; ++k) visited[sub + GROUP * k] = 0u;
+    // the parabola's vertex, to within an ulp or two (v_rcp_f32): a bound evaluated a relative 1e-7 beside it is below the true one
+    // by ~|A| mu'^2 1e-14, nothing against E32
+    bool concave_row = true;
 #pragma unroll
-    for (int i = 0; i < DIM; ++i) cM[i] = cA[i] < 0.0f ? (-0.5f * cB[i]) / cA[i] : 0.0f;   // the parabola's vertex (any point is valid)
+    for (int i = 0; i < DIM; ++i) {
+      cM[i] = cA[i] < 0.0f ? -0.5f * cB[i] * __builtin_amdgcn_rcpf(cA[i]) : 0.0f;
+      concave_row = concave_row && cA[i] < 0.0f;
+    }
+    const bool concave = __all(concave_row);
     const double u = 5.9604644775390625e-08;
     const double N1 = (double)N1f;
     double T, G;
@@ -604,17 +618,17 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
 #endif
     if (!bad && !abl_no_search) {
       // ---- (1) greedy descent to ONE leaf (LDS only, then one round trip for its codes): a good F before anything is pruned
-      const float ub1 = grid_box_ub<DIM>(cA, cB, cM, s_box + sub * BOXF);
+      const float ub1 = grid_box_ub<DIM>(cA, cB, cM, s_box + sub * BOXF, concave);
       {
         const unsigned b1 = group_bits(ub1 == group_max(ub1) && ub1 > NEG_INF);
         if (b1 != 0u) {
           const int g1 = __builtin_ctz(b1);
-          const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (g1 * 16 + sub) * BOXF);
+          const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (g1 * 16 + sub) * BOXF, concave);
           const unsigned b2 = group_bits(ub2 == group_max(ub2) && ub2 > NEG_INF);
           if (b2 != 0u) {
             const int node = g1 * 16 + __builtin_ctz(b2);
             const int lq = node * LPN + (sub & (LPN - 1));               // (every lane: leaf sub % 4 of the node)
-            const float ub3 = nonempty(lq) ? grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF) : NEG_INF;
+            const float ub3 = nonempty(lq) ? grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF, concave) : NEG_INF;
             const unsigned b3 = group_bits(ub3 == group_max(ub3) && ub3 > NEG_INF) & ((1u << LPN) - 1u);
             if (b3 != 0u) {
               const int one[1] = {node * LPN + __builtin_ctz(b3)};
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         while (m1 != 0u) {
           const int q1 = __builtin_ctz(m1);
           m1 &= m1 - 1u;
-          const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (q1 * 16 + sub) * BOXF);
+          const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (q1 * 16 + sub) * BOXF, concave);
           unsigned pm2 = group_bits(!(ub2 < thr) && ub2 > NEG_INF);
           while (pm2 != 0u) {
             int nd = 0;
@@ -654,7 +668,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
               if (sub / LPN == t) { nd = c2; on = here; }
             }
             const int lq = (q1 * 16 + nd) * LPN + (sub & (LPN - 1));
-            const float ub3 = grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF);
+            const float ub3 = grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF, concave);
             const bool c = on && nonempty(lq) && !(ub3 < thr) && !was_visited(lq);
             const unsigned pm = group_bits(c);
             const int pos = nleaf + __builtin_popcount(pm & lt);
@@ -664,6 +678,9 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         }
         truncated = truncated || nleaf > kGridLeafCap;
         nleaf = min(nleaf, kGridLeafCap);
+        // a long list: 16 lanes would walk it two leaves per round trip while the wave's other three rows wait -- a whole block
+        // (gq_grid_finish_kernel) does it in a few microseconds
+        if (nleaf > p.inwave_cap) { overflow = true; break; }
         wave_sync_lds();
         GQ_GRID_STAMP();   // 3: lists (first round)
         // ---- (3) best bound first, LEAF_U leaves per round trip, until the best remaining bound is below the threshold
@@ -675,7 +692,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
           eu[k] = i < nleaf ? lub[i] : NEG_INF;
           el[k] = i < nleaf ? list[i] : 0;
         }
-        int budget = truncated ? 16 : kGridLeafCap;                       // a truncated list: its best leaves, then a rebuild with the tighter thr
+        int budget = truncated ? 8 : kGridLeafCap;                        // a truncated list: its best leaves, then ONE rebuild with the tighter thr
         while (budget > 0) {
           int lf[LEAF_U];
           int cnt = 0;
@@ -706,7 +723,10 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
           budget -= cnt;
         }
         if (!truncated) break;
-        if (round >= 24 || leaves > p.leaf_cap) { overflow = true; break; }
+        // still more than the list holds: a row with a long tail of loose boxes (near-linear scores reach far into the codebook's
+        // tails, where leaves are large) -- 16 lanes walking hundreds of leaves would hold up its wave for 100+ us (measured: the
+        // bench's gq_1.00 z, 330 us per launch); the whole block scans it at its end instead, two passes over the codes
+        if (round >= 1 || leaves > p.leaf_cap) { overflow = true; break; }
       }
       GQ_GRID_STAMP();   // 4: listed leaves
       // ---- (4) the final threshold is known: the reference's arithmetic for every code within the margin
@@ -746,37 +766,13 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         atomicAdd(&p.hdr->grid_leaves, (unsigned long long)leaves);
       }
     }
-    // ---- an undecided row: to the block's list (scanned by the whole block at its end), or, the list full, by this wave now
-    if (__any(live && !decided)) {
-      const bool keep_all = bad || !have || (overflow && !(thr > NEG_INF));
-      int pos = kGridScanCap;
-      if (live && !decided && sub == 0) {
-        atomicAdd(&p.hdr->fb_count, 1);
-        pos = atomicAdd(&s_nscan, 1);
-        if (pos < kGridScanCap) { s_scan_row[pos] = (int)(row << 1) | (keep_all ? 1 : 0); s_scan_thr[pos] = thr; }
-      }
-      pos = __shfl(pos, gshift);
-      for (int g = 0; g < RPW; ++g) {                                   // (wave-uniform loop: one group's row at a time, all 64 lanes)
-        const bool need = __shfl((int)(live && !decided && pos >= kGridScanCap), g * GROUP) != 0;
-        if (!need) continue;
-        const long srow = __shfl((int)row, g * GROUP);
-        const float sthr = __shfl(thr, g * GROUP);
-        const bool skeep = __shfl((int)keep_all, g * GROUP) != 0;
-        float sA[DIM], sB[DIM];
-        grid_load_coef<DIM>(p, srow, sA, sB);
-        double bs = 0.0;
-        int bi = 0x7fffffff;
-        bool hv = false;
-        grid_scan_accumulate<MODE, DIM>(p, sA, sB, s_ops[wave * RPW + g], sthr, skeep, lane, 64, bs, bi, hv);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const double os = __shfl_xor(bs, o);
-          const int oi = __shfl_xor(bi, o);
-          const bool oh = __shfl_xor((int)hv, o) != 0;
-          if (oh && (!hv || better_d(os, oi, bs, bi))) { bs = os; bi = oi; hv = true; }
-        }
-        if (hv) grid_write_result(p, srow, bi, lane, DIM);
-      }
+    // ---- an undecided row: to the call's list; gq_grid_finish_kernel (the next launch) finishes it with a whole block
+    if (live && !decided && sub == 0) {
+      const bool keep_all = bad || (!overflow && !have) || !(thr > NEG_INF);      // (an overflowed row: its candidate leaves under thr)
+      const int pos = atomicAdd(&p.hdr->fb_count, 1);
+      p.und_row[pos] = (int)(row << 1) | (keep_all ? 1 : 0);
+      p.und_thr[pos] = thr;
+      p.und_margin[pos] = margin32;
     }
 #ifdef GQHIP_CLOCK_STAMPS
     GQ_GRID_STAMP();     // 6: reduce, stores
@@ -787,13 +783,51 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     nst_ = 8;
 #endif
   }
-  // ---- the block's undecided rows: all 512 threads over ALL codes, one row after the other
+}
+
+// The rows the search left undecided (the 4th launch of a dim-4 call; exits at once when there are none).  A block per row, round
+// robin over the call's list -- its own kernel so that clustered rows (flat image regions give runs of them) spread over the
+// whole chip, and so that this code's registers are not the search's.
+template <int MODE, int DIM>
+__global__ __launch_bounds__(kGridThreads, 2) void gq_grid_finish_kernel(const GridParams p) {
+  const int nund = p.hdr->fb_count;
+  if (nund == 0) return;                                  // (uniform)
+  constexpr int BOXF = 2 * DIM;
+  constexpr int START_N = kGridLeaves + 16;
+  __shared__ __attribute__((aligned(16))) float s_box3f[kGridLeaves * BOXF];
+  __shared__ __attribute__((aligned(16))) int s_start[START_N];
+  __shared__ int s_nblist;
+  __shared__ float s_sops[3 * DIM + 1];
+  __shared__ float s_red[kGridThreads / 64];
+  __shared__ double sh_s[kGridThreads];
+  __shared__ int sh_i[kGridThreads];
+  const GridLayout L = grid_layout(p.n, DIM);
+  const float *scb = reinterpret_cast<const float *>(p.cache + L.scb);
+  const int *sidx = reinterpret_cast<const int *>(p.cache + L.sidx);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float NEG_INF = -__builtin_inff();
+  {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cache + L.box3);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(s_box3f);
+    for (int k = tid; k < kGridLeaves * BOXF / 4; k += kGridThreads) dst[k] = src[k];
+    const f32x4 *src2 = reinterpret_cast<const f32x4 *>(p.cache + L.start);
+    f32x4 *dst2 = reinterpret_cast<f32x4 *>(s_start);
+    for (int k = tid; k < START_N / 4; k += kGridThreads) dst2[k] = src2[k];
+  }
+  const float *s_box3 = s_box3f;
+  // ---- the block's undecided rows, one after the other, all 512 threads.  A row with a finite threshold (a list that did not fit:
+  //      a long tail of loose boxes) is finished over its CANDIDATE LEAVES only: every thread bounds two of the 1024 leaves, the
+  //      passing ones go to a list, a wave takes a leaf at a time (64 lanes = its 64 codes): pass 1 the largest expansion -> the
+  //      final threshold, pass 2 the reference's arithmetic for the codes within the margin.  (A scan of all codes costs ~20 us of
+  //      the block per row: 1.5 % of the rows of the bench's gq_1.00 z are such rows.)  Rows with non-finite operands / bounds, or
+  //      behind a non-finite codebook: all codes, everything exact.
   __syncthreads();
-  const int nscan = min(s_nscan, kGridScanCap);
-  for (int i = 0; i < nscan; ++i) {
-    const long row = s_scan_row[i] >> 1;
-    const bool keep_all = (s_scan_row[i] & 1) != 0;
-    const float thr = s_scan_thr[i];
+  int *s_blist = reinterpret_cast<int *>(sh_s);          // (sh_s is free until a row's final reduction)
+  static_assert(sizeof(double) * kGridThreads >= sizeof(int) * kGridLeaves, "the block's leaf list fits the reduction buffer");
+  for (int i = (int)blockIdx.x; i < nund; i += (int)gridDim.x) {
+    const long row = p.und_row[i] >> 1;
+    const bool keep_all = (p.und_row[i] & 1) != 0;
+    const float thr = p.und_thr[i];
     if (tid < DIM) {
 #pragma clang fp contract(off)
       s_sops[tid] = p.mu[row * DIM + tid];
@@ -803,13 +837,65 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         s_sops[2 * DIM + tid] = p.lsd[row * DIM + tid];
       }
     }
+    if (tid == 0) s_nblist = 0;
     __syncthreads();
     float sA[DIM], sB[DIM];
     grid_load_coef<DIM>(p, row, sA, sB);
     double bs = 0.0;
     int bi = 0x7fffffff;
     bool hv = false;
-    grid_scan_accumulate<MODE, DIM>(p, sA, sB, s_sops, thr, keep_all, tid, kGridThreads, bs, bi, hv);
+    if (keep_all) {
+      grid_scan_accumulate<MODE, DIM>(p, sA, sB, s_sops, thr, true, tid, kGridThreads, bs, bi, hv);
+    } else {
+      float sM[DIM];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) sM[k] = sA[k] < 0.0f ? -0.5f * sB[k] * __builtin_amdgcn_rcpf(sA[k]) : 0.0f;
+      for (int lf = tid; lf < kGridLeaves; lf += kGridThreads) {
+        const float ub = s_start[lf + 1] > s_start[lf] ? grid_box_ub<DIM>(sA, sB, sM, s_box3 + lf * BOXF, false) : NEG_INF;
+        if (ub > NEG_INF && !(ub < thr)) s_blist[atomicAdd(&s_nblist, 1)] = lf;
+      }
+      __syncthreads();
+      const int nl = s_nblist;
+      auto leaf_codes = [&](auto &&body) {                // wave w: leaves w, w + 8, ...; lane: codes lane, lane + 64, ... of the leaf
+        for (int k = wave; k < nl; k += kGridThreads / 64) {
+          const int lf = s_blist[k];
+          for (int j = s_start[lf] + lane; j < s_start[lf + 1]; j += 64) {
+            float n[DIM];
+            const f32x4 *q = reinterpret_cast<const f32x4 *>(scb + (long)j * DIM);
+#pragma unroll
+            for (int c = 0; c < DIM / 4; ++c) {
+              const f32x4 v = q[c];
+              n[4 * c] = v.x; n[4 * c + 1] = v.y; n[4 * c + 2] = v.z; n[4 * c + 3] = v.w;
+            }
+            float f = 0.0f;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) f = __builtin_fmaf(__builtin_fmaf(sA[d], n[d], sB[d]), n[d], f);
+            body(j, n, f);
+          }
+        }
+      };
+      float fm = NEG_INF;
+      leaf_codes([&](int, const float (&)[DIM], float f) { fm = __builtin_fmaxf(fm, f); });
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) fm = __builtin_fmaxf(fm, __shfl_xor(fm, o));
+      if (lane == 0) s_red[wave] = fm;
+      __syncthreads();
+      fm = s_red[0];
+#pragma unroll
+      for (int w = 1; w < kGridThreads / 64; ++w) fm = __builtin_fmaxf(fm, s_red[w]);
+      const float t2 = (fm - p.und_margin[i]) - 2.4e-7f * __builtin_fabsf(fm);
+      const float thr2 = t2 > thr ? t2 : thr;             // (the row's own F was found among these leaves' codes or earlier: fm >= it)
+      leaf_codes([&](int j, const float (&n)[DIM], float f) {
+        if (!(f < thr2)) {
+          const int code = sidx[j];
+          double sc;
+          if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(n, s_sops, p.beta);
+          else sc = vq_neg_dist(n, s_sops, DIM);
+          if (!hv || better_d(sc, code, bs, bi)) { bs = sc; bi = code; hv = true; }
+        }
+      });
+      __syncthreads();                                    // (the leaf list lives in sh_s)
+    }
     sh_s[tid] = bs;
     sh_i[tid] = hv ? bi : 0x7fffffff;
     __syncthreads();

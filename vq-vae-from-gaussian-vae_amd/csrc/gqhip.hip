@@ -507,10 +507,15 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     gp.idx = idx; gp.zhat = zhat; gp.hdr = hdr; gp.rows = (int)rows; gp.n = (int)n; gp.beta = (float)beta;
     static const int env_cap = getenv("GQHIP_GRID_CAP") ? atoi(getenv("GQHIP_GRID_CAP")) : 0;
     gp.leaf_cap = env_cap > 0 ? env_cap : 256;     // leaves a row may visit before it is handed to the scan (a flat score)
+    static const int env_inwave = getenv("GQHIP_GRID_INWAVE") ? atoi(getenv("GQHIP_GRID_INWAVE")) : 0;   // diagnostics / tuning
+    gp.inwave_cap = env_inwave > 0 ? env_inwave : kGridLeafCap;
     gp.stats = g_debug_stats; gp.omap = omap;
     static const int env_abl = getenv("GQHIP_GRID_ABL") ? atoi(getenv("GQHIP_GRID_ABL")) : 0;   // diagnostic builds (make abl) only
     gp.abl = env_abl;
-    gp.next = &hdr->grid_next;
+    // the list of undecided rows lives in the (otherwise unused) candidate-record region: 16 B x rows x record sets >= 12 B x rows
+    gp.und_row = reinterpret_cast<int *>(ws + w.rec);
+    gp.und_thr = reinterpret_cast<float *>(ws + w.rec) + rows;
+    gp.und_margin = reinterpret_cast<float *>(ws + w.rec) + 2 * rows;
     const int64_t nsets = (rows + 31) / 32;                        // (a block's eight waves fetch four rows at a time from a counter)
     const dim3 ggrid((unsigned)(nsets < 512 ? nsets : 512));       // two 512-thread blocks per CU: one wave of blocks
     ProfScope prof;
@@ -521,6 +526,12 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   } while (0)
     if (dim == 4) GQ_GRID(4); else GQ_GRID(8);
 #undef GQ_GRID
+    rc = check_launch();
+    if (rc != GQHIP_OK) return rc;
+    // launch 4: the rows the search left undecided, a block per row (exits at once when there are none)
+    const dim3 fgrid(256);
+    if (dim == 4) hipLaunchKernelGGL((gq_grid_finish_kernel<MODE, 4>), fgrid, dim3(kGridThreads), 0, st, gp);
+    else hipLaunchKernelGGL((gq_grid_finish_kernel<MODE, 8>), fgrid, dim3(kGridThreads), 0, st, gp);
     return check_launch();
   }
   if (f16 && cb_cache && image_cache_bytes(n, dim) > 0 && cb_cache_bytes >= image_cache_bytes(n, dim)) {
