@@ -291,3 +291,33 @@ def test_cached_codebook_image_is_validated_slice_by_slice(dim):
     cb2 = np.random.default_rng(1).normal(0, 1, (n, dim)).astype(np.float32)
     cbt.data.copy_(torch.from_numpy(cb2))
     check(cb2)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("GQ_GRID_SEEDS", "32")))))
+def test_grid_randomized_parity(seed):
+    """Randomized sweep through the dim-4 search: codebook kind, size (incl. non-multiples of anything), row conditioning, beta,
+    mode (Gaussian score / VQ) drawn per seed; indices and zhat bit-exact against the oracle (GQ_GRID_SEEDS widens it)."""
+    from pit_hip import _lib
+
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([16384, 20000, 65536, 70001, 131072]))
+    which = str(rng.choice(["sobol", "uniform", "scaled", "clustered", "duplicates"]))
+    kind = str(rng.choice(["trained", "linear", "convex", "wide"]))
+    rows = int(rng.integers(1, 700))
+    beta = float(rng.choice([0.0, 0.5, 1.0, 2.0]))
+    cb = _books(n, 4, which, seed=seed)
+    mu, sd = _rows(rows, 4, 7 * seed + 1, kind)
+    if rng.random() < 0.3:                       # a few exactly flat / degenerate rows in the mix
+        k = int(rng.integers(0, rows))
+        mu[k] = 0.0
+        sd[k] = 1.0
+    if rng.random() < 0.25:                      # VQ through the same kernels (A = -1, B = 2 z; fp64 arbiter)
+        z = mu * 2.0
+        ws = _lib.Workspace()
+        idx, zq = _lib.vq_argmin(z.to(DEV), torch.from_numpy(cb).to(DEV), ws=ws)
+        assert np.array_equal(idx.cpu().numpy(), O.vq_argmin_rows(z.numpy(), cb)), (seed, n, which)
+        return
+    idx, zhat, lsd, ws = _gq(mu, sd, cb, beta)
+    ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb, beta, logstd=lsd)
+    assert np.array_equal(idx, ref_idx), (seed, n, which, kind, beta, int((idx != ref_idx).sum()))
+    assert np.array_equal(zhat, ref_zhat)
