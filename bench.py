@@ -717,13 +717,15 @@ def main():
                         _lib.debug_enable(False)
                 bf16 = True        # (priced against the dense fp16 / bf16 peak, like the filter it replaces)
                 launch_names = ("gq_prep_kernel", "gq_grid_build_kernel", kname)
-                roofline = {"kernel": f"{kname} (pruned exact search over a 16 -> 256 -> 1024-leaf box tree of the codebook held in LDS; it "
-                                      "replaces filter + re-rank at dim 4: the dense MFMA form is bound by the VALU fold of its own outputs "
-                                      "there, profiles/r04/pmc_filter_gq_1.00_dim4_round3_kernels.txt)",
+                roofline = {"kernel": f"{kname} (pruned exact search over a box tree of the codebook: 16 -> 256 -> 1024 leaves held in LDS, "
+                                      "4096 sub-leaves of 16 codes fetched from the codebook cache; it replaces filter + re-rank at dim 4: "
+                                      "the dense MFMA form is bound by the VALU fold of its own outputs there, "
+                                      "profiles/r04/pmc_filter_gq_1.00_dim4_round3_kernels.txt)",
                             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                            "visited": {"leaves_per_row": round(gs["leaves"] / rows, 2), "leaves_total": 1024, "codes_per_leaf": N_CODES // 1024,
-                                        "fraction_of_the_codebook_scored": round(gs["leaves"] / rows / 1024, 5),
+                            "visited": {"sub_leaves_per_row": round(gs["sub_leaves"] / rows, 2), "sub_leaves_total": 4096,
+                                        "codes_per_sub_leaf": N_CODES // 4096,
+                                        "fraction_of_the_codebook_scored": round(gs["sub_leaves"] / rows / 4096, 5),
                                         "exactly_scored_codes_per_row": round(gs["exact_codes"] / rows, 3),
                                         "rows_scanned_over_all_codes": int(gs["scanned_rows"])},
                             "note": "achieved = the DENSE algorithmic flops of the shape (SURVEY 8d: 4*dim*N per row) / launch time, against "

@@ -102,8 +102,8 @@ int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim);
 /* ---- codebook cache ---------------------------------------------------------
  * Bytes of PERSISTENT device memory (256-B aligned) in which the fused arg-max keeps what it derives from a codebook of `n` codes
  * of width `dim` across calls; 0 when this shape keeps nothing (then pass NULL / 0).  Today: dims 4 and 8 with 2^14 <= n <= 2^20
- * -- a three-level tree of bounding boxes over the codes sorted into 4096 leaves, which lets those dims run a pruned exact search
- * (5-6 leaves of ~16 codes per row at dim 4 instead of all n codes; csrc/gq_grid.h) in place of filter + re-rank.
+ * -- the codes sorted into 4096 sub-leaves under a tree of bounding boxes (16 -> 256 -> 1024 -> 4096), which lets dim 4 run a pruned
+ * exact search (~8 sub-leaves of ~16 codes per row instead of all n codes; csrc/gq_grid.h) in place of filter + re-rank.
  * Contract: the caller owns the buffer, hands the SAME buffer to every call that uses the same codebook, and never writes it;
  * its initial contents are don't-care.  The library validates it on EVERY call -- the first launch hashes the codebook it is
  * given (it reads it anyway) and compares with the hashes the cache was stamped with -- and rebuilds it in-stream (one extra
@@ -439,9 +439,10 @@ int gqhip_profile_collect(int *launches_host, double *total_ms_host);
 int gqhip_debug_enable(int on);
 int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
                          int64_t *reranked_halftiles_host);
-/* Grid search (dims 4 / 8 with a codebook cache), last call on `workspace`, synchronous copy: out4 = { leaves visited summed over
- * the rows (counted only after gqhip_debug_enable(1)), codes that received the reference's arithmetic (likewise), rows handed to
- * the block-wide scan, 1 if `cb_cache_or_null` holds a current index / 0 if not / -1 without a cache }.  A leaf is ~n / 4096 codes. */
+/* Grid search (dims 4 / 8 with a codebook cache), last call on `workspace`, synchronous copy: out4 = { sub-leaves visited summed
+ * over the rows (counted only after gqhip_debug_enable(1); a sub-leaf is ~n / 4096 codes, a whole leaf counts four), codes that
+ * received the reference's arithmetic (likewise; a row with ONE code within the margin needs none), rows handed to
+ * gq_grid_finish_kernel, 1 if `cb_cache_or_null` holds a current index / 0 if not / -1 without a cache }. */
 int gqhip_debug_grid(const void *workspace, const void *cb_cache_or_null, int64_t *out4_host);
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """-m gpu: the pruned exact search of dim 4 (csrc/gq_grid.h; BASELINE configs[3]: sd3unet_gq_1.00; dim 8 cases run whatever path the
 library selects for them -- the dense filter today) through the C ABI against the CPU oracle -- bit-exact indices whatever the
 codebook looks like --, the codebook cache's self-validation (edits in place, other codebooks, clobbered buffers), the rows it
-hands to the block-wide scan, and the pruning itself (leaves visited).
+hands to the finish kernel, and the pruning itself (sub-leaves visited).
 Reference arithmetic: pit/quantization/gaussian.py:136-150 (torch backend), vq.py:58-73."""
 import numpy as np
 import pytest
@@ -228,12 +228,13 @@ def test_grid_path_is_graph_capturable_and_sees_edits_on_replay():
     assert np.array_equal(idx.cpu().numpy(), ref1) and ref1[0] != ref[0]
 
 
-@pytest.mark.parametrize("dim,kind,limit", [(4, "trained", 8.0), (4, "linear", 20.0)])
+@pytest.mark.parametrize("dim,kind,limit", [(4, "trained", 12.0), (4, "linear", 24.0)])
 def test_grid_prunes(dim, kind, limit):
-    """The point of the formulation: leaves visited per row (of 1024; a leaf = 64 codes of the 65 536): ~4 at the trained operating
-    point, ~9 in the near-linear regime of sigma ~ 1 (a nearly linear score reaches into the codebook's tails, where leaves are
-    large and their boxes loose); there a percent or so of the rows has more candidate leaves than the list holds even after one
-    rebuild and is handed to the block's two-pass scan."""
+    """The point of the formulation: sub-leaves visited per row (of 4096; a sub-leaf = 16 codes of the 65 536; the leaf of the first
+    round trip counts four): ~8 at the trained operating point, ~13 in the near-linear regime of sigma ~ 1 (a nearly linear score
+    reaches into the codebook's tails, where boxes are large and their bounds loose); there a fraction of a percent of the rows has
+    more candidates than the lists hold even after one rebuild and is handed to the finish kernel.  A row with ONE code within the
+    margin of its best expansion never needs the reference's arithmetic: ~0.1 exactly scored codes per row."""
     from pit_hip import _lib
 
     cb = O.codebook(65536, dim, 42)
@@ -244,10 +245,11 @@ def test_grid_prunes(dim, kind, limit):
         g = _lib.debug_grid(ws)
     finally:
         _lib.debug_enable(False)
-    per_row = g["leaves"] / 8192
-    print(f"dim {dim}, {kind}: {per_row:.1f} leaves and {g['exact_codes'] / 8192:.2f} exactly scored codes per row, "
-          f"{g['scanned_rows']} rows scanned")
-    assert per_row <= limit and g["scanned_rows"] <= (0 if kind == "trained" else 8192 // 25)
+    per_row = g["sub_leaves"] / 8192
+    print(f"dim {dim}, {kind}: {per_row:.1f} sub-leaves and {g['exact_codes'] / 8192:.2f} exactly scored codes per row, "
+          f"{g['scanned_rows']} rows to the finish kernel")
+    assert per_row <= limit and g["scanned_rows"] <= (0 if kind == "trained" else 8192 // 50)
+    assert g["exact_codes"] / 8192 <= 0.5
     ref_idx, _ = O.argmax_rows(mu.numpy()[:1024], sd.numpy()[:1024], cb, 1.0, logstd=lsd[:1024])
     assert np.array_equal(idx[:1024], ref_idx)
 

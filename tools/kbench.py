@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--vq", action="store_true", help="time vq_argmin (A = -1, B = 2 z) instead of the Gaussian score")
     ap.add_argument("--filter", default=None, choices=["auto", "fp32", "bf16", "mixed"], help="filter kernel (default: library default)")
+    ap.add_argument("--flat", action="store_true", help="rows of the bench's seeded-random encoder (sigma ~ 1: nearly linear scores) "
+                    "instead of the trained operating point of SURVEY 8(d)")
     a = ap.parse_args()
     if a.filter:
         _lib.set_filter(a.filter)
@@ -28,6 +30,9 @@ def main():
     g = torch.Generator().manual_seed(0)
     mu = (0.9 * torch.randn(a.rows, a.dim, generator=g)).to(dev)
     sd = torch.exp(0.5 * (-1.5 + 0.3 * torch.randn(a.rows, a.dim, generator=g))).to(dev)
+    if a.flat:
+        mu = (0.6 * torch.randn(a.rows, a.dim, generator=g)).to(dev)
+        sd = torch.exp(0.5 * (0.1 * torch.randn(a.rows, a.dim, generator=g))).to(dev)
     cb = torch.randn(a.n, a.dim, generator=g).clamp(-4.6, 4.6).to(dev)
     ws = _lib.Workspace()
     if a.vq:
@@ -65,7 +70,7 @@ def main():
         _lib.debug_enable(False)
         print(f"rows={a.rows} dim={a.dim} n={a.n}: grid search kernel (gq_grid.h) {kms*1e3:.1f} us avg over {launches} launches -> "
               f"{tf:.1f} algorithmic TFLOP/s-equivalent ({tf/2500*100:.1f}% of the 2500 the dense form is priced against); "
-              f"{gs['leaves'] / a.rows:.1f} of 1024 leaves (64 codes each) and {gs['exact_codes'] / a.rows:.2f} exactly scored codes per row, "
+              f"{gs['sub_leaves'] / a.rows:.1f} of 4096 sub-leaves (16 codes each) and {gs['exact_codes'] / a.rows:.2f} exactly scored codes per row, "
               f"{gs['scanned_rows']} rows scanned by their block; whole call wall {wall*1e6:.1f} us")
         return
     print(f"rows={a.rows} dim={a.dim} n={a.n}: {('fp32', 'split-bf16', 'fp16+fp8', 'fp16 main product')[kind]} filter kernel {kms*1e3:.1f} us avg over "

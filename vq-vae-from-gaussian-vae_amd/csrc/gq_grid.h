@@ -40,12 +40,14 @@
 
 namespace gqhip {
 
-constexpr unsigned kGridMagic = 0x47514732u;
+constexpr unsigned kGridMagic = 0x47514733u;
 constexpr int kGridLanes = 16;                     // lanes per row (one DPP row)
 constexpr int kGridL1 = 16, kGridL2 = 256, kGridLeaves = 1024;    // 16 nodes x 16 nodes x 4 leaves
 constexpr int kGridFan2 = kGridLeaves / kGridL1;                    // leaves under an L1 node
+constexpr int kGridSubPerLeaf = 4, kGridSubs = kGridLeaves * kGridSubPerLeaf;   // sub-leaves (boxes in the cache, not in LDS): 4096
 constexpr int kGridBuildThreads = 1024;
-constexpr int kGridLeafCap = 48;                   // leaf-list capacity of the search (a longer list is visited best first and rebuilt)
+constexpr int kGridLeafCap = 48;                   // leaf-list capacity of the search
+constexpr int kGridSubCap = 96;                    // sub-leaf list capacity (a longer list: its best part is visited, then ONE rebuild)
 
 struct GridHdr {                                   // first 4 KiB of the codebook cache
   unsigned magic;
@@ -59,7 +61,7 @@ struct GridHdr {                                   // first 4 KiB of the codeboo
 static_assert(sizeof(GridHdr) == 4096, "cache header is 4 KiB");
 
 struct GridLayout {
-  int64_t hdr, box1, box2, box3, start, scb, sidx, total;      // box1 | box2 | box3 | start are contiguous: one linear copy into LDS
+  int64_t hdr, box1, box2, box3, start, sstart, sbox, scb, sidx, total;   // box1 | box2 | box3 | start are contiguous: one linear copy into LDS
 };
 __host__ __device__ inline int64_t grid_align(int64_t v) { return (v + 255) / 256 * 256; }
 __host__ __device__ inline GridLayout grid_layout(int64_t n, int64_t dim) {
@@ -70,21 +72,24 @@ __host__ __device__ inline GridLayout grid_layout(int64_t n, int64_t dim) {
   g.box2 = off;  off += kGridL2 * 2 * dim * 4;
   g.box3 = off;  off += (int64_t)kGridLeaves * 2 * dim * 4;
   g.start = off; off += grid_align((kGridLeaves + 16) * 4);
+  g.sstart = off; off += grid_align((kGridSubs + 16) * 4);
+  g.sbox = off;  off += (int64_t)kGridSubs * 2 * dim * 4;
   g.scb = off;   off += grid_align(n * dim * 4);
   g.sidx = off;  off += grid_align(n * 4);
   g.total = off;
   return g;
 }
 
-// cells per axis: dim 4: 8 x 8 x 4 x 4; dim 8: 4 x 4 x 2 x 2 x 2 x 2 x 2 x 2 -- 1024 leaves either way, and for a scrambled-Sobol
-// codebook of 65 536 points mapped through the normal quantile (pit/quantization/gaussian.py:15-19) exactly 64 codes in each (a
-// (t, m, s)-net: every elementary interval holds its share).  Leaf id = l1 * 64 + l2 * 4 + l3 (three levels of boxes: 16 -> 256 ->
-// 1024): l1 = the top bit of the coordinates of axes 0..3; dim 4: l2 = the second bit of axes 0, 1 and the low bit of axes 2, 3,
-// l3 = the low bit of axes 0, 1; dim 8: l2 = the low bit of axes 0, 1 and the bits of axes 4, 5, l3 = the bits of axes 6, 7.
-template <int DIM> __device__ __forceinline__ int grid_cells_of_axis(int i) { return DIM == 4 ? (i < 2 ? 8 : 4) : (i < 2 ? 4 : 2); }
+// cells per axis: dim 4: 8 x 8 x 8 x 8; dim 8: 4 x 4 x 4 x 4 x 2 x 2 x 2 x 2 -- 4096 sub-leaves either way, four to a leaf, and for a
+// scrambled-Sobol codebook of 65 536 points mapped through the normal quantile (pit/quantization/gaussian.py:15-19) exactly 16
+// codes in each (a (t, m, s)-net: every elementary interval holds its share).  Sub-leaf id = ((l1 * 16 + l2) * 4 + l3) * 4 + l4
+// (boxes: 16 -> 256 -> 1024 leaves -> 4096 sub-leaves): l1 = the top bit of the coordinates of axes 0..3; dim 4: l2 = their second
+// bit, l3 = the low bit of axes 0, 1, l4 = the low bit of axes 2, 3; dim 8: l2 = the low bit of axes 0, 1 and the bits of axes 4, 5,
+// l3 = the bits of axes 6, 7, l4 = the low bit of axes 2, 3.
+template <int DIM> __device__ __forceinline__ int grid_cells_of_axis(int i) { return DIM == 4 ? 8 : (i < 4 ? 4 : 2); }
 
 template <int DIM>
-__device__ __forceinline__ int grid_leaf_of(const float (&x)[DIM], const float (*thr)[8]) {
+__device__ __forceinline__ int grid_sub_of(const float (&x)[DIM], const float (*thr)[8]) {
   int c[DIM];
 #pragma unroll
   for (int i = 0; i < DIM; ++i) {
@@ -94,17 +99,19 @@ __device__ __forceinline__ int grid_leaf_of(const float (&x)[DIM], const float (
       if (t < grid_cells_of_axis<DIM>(i) - 1) k += x[i] >= thr[i][t] ? 1 : 0;       // NaN: 0
     c[i] = k;
   }
-  int l1, l2, l3;
+  int l1, l2, l3, l4;
   if constexpr (DIM == 4) {
-    l1 = (c[0] >> 2) | ((c[1] >> 2) << 1) | ((c[2] >> 1) << 2) | ((c[3] >> 1) << 3);
-    l2 = ((c[0] >> 1) & 1) | (((c[1] >> 1) & 1) << 1) | ((c[2] & 1) << 2) | ((c[3] & 1) << 3);
+    l1 = (c[0] >> 2) | ((c[1] >> 2) << 1) | ((c[2] >> 2) << 2) | ((c[3] >> 2) << 3);
+    l2 = ((c[0] >> 1) & 1) | (((c[1] >> 1) & 1) << 1) | (((c[2] >> 1) & 1) << 2) | (((c[3] >> 1) & 1) << 3);
     l3 = (c[0] & 1) | ((c[1] & 1) << 1);
+    l4 = (c[2] & 1) | ((c[3] & 1) << 1);
   } else {
-    l1 = (c[0] >> 1) | ((c[1] >> 1) << 1) | (c[2] << 2) | (c[3] << 3);
+    l1 = (c[0] >> 1) | ((c[1] >> 1) << 1) | ((c[2] >> 1) << 2) | ((c[3] >> 1) << 3);
     l2 = (c[0] & 1) | ((c[1] & 1) << 1) | (c[4] << 2) | (c[5] << 3);
     l3 = c[6] | (c[7] << 1);
+    l4 = (c[2] & 1) | ((c[3] & 1) << 1);
   }
-  return (l1 * 16 + l2) * 4 + l3;
+  return (((l1 * 16 + l2) * 4 + l3) * 4) + l4;
 }
 
 // ---------------------------------------------------------------------------------------------------- builder (one block)
@@ -123,13 +130,15 @@ __global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const 
   float *box1 = reinterpret_cast<float *>(p.cache + L.box1), *box2 = reinterpret_cast<float *>(p.cache + L.box2);
   float *box3 = reinterpret_cast<float *>(p.cache + L.box3);
   int *start = reinterpret_cast<int *>(p.cache + L.start);
+  int *sstart = reinterpret_cast<int *>(p.cache + L.sstart);
+  float *sbox = reinterpret_cast<float *>(p.cache + L.sbox);
   float *scb = reinterpret_cast<float *>(p.cache + L.scb);
   int *sidx = reinterpret_cast<int *>(p.cache + L.sidx);
   constexpr int NT = kGridBuildThreads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ double s_red[NT / 64][2 * DIM];
   __shared__ float s_thr[8][8];
-  __shared__ int s_cnt[kGridLeaves];
+  __shared__ int s_cnt[kGridSubs];
   __shared__ int s_wsum[NT / 64];
 
   // ---- 1. per-axis mean / deviation -> thresholds at the normal quantiles (any thresholds are valid; these balance a Gaussian book)
@@ -171,23 +180,23 @@ __global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const 
     s_thr[i][t] = th;
     gh->thr[i][t] = th;
   }
-  for (int c = tid; c < kGridLeaves; c += NT) s_cnt[c] = 0;
+  for (int c = tid; c < kGridSubs; c += NT) s_cnt[c] = 0;
   __syncthreads();
 
-  // ---- 2. leaf histogram
-  auto leaf_of_code = [&](int j) {
+  // ---- 2. sub-leaf histogram
+  auto sub_of_code = [&](int j) {
     float x[DIM];
 #pragma unroll
     for (int i = 0; i < DIM; ++i) x[i] = p.cb[(long)j * DIM + i];
-    return grid_leaf_of<DIM>(x, s_thr);
+    return grid_sub_of<DIM>(x, s_thr);
   };
-  for (int j = tid; j < p.n; j += NT) atomicAdd(&s_cnt[leaf_of_code(j)], 1);
+  for (int j = tid; j < p.n; j += NT) atomicAdd(&s_cnt[sub_of_code(j)], 1);
   __syncthreads();
 
-  // ---- 3. exclusive scan of the leaf counters (one per thread) -> start[], cursors in s_cnt
+  // ---- 3. exclusive scan of the sub-leaf counters (one leaf = four of them per thread) -> sstart[], start[], cursors in s_cnt
   {
-    constexpr int PER = kGridLeaves / NT;
-    static_assert(kGridLeaves % NT == 0, "whole counters per thread");
+    constexpr int PER = kGridSubs / NT;
+    static_assert(kGridSubs % NT == 0 && PER == kGridSubPerLeaf && NT == kGridLeaves, "a thread scans the sub-leaves of one leaf");
     int loc[PER], sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) { loc[k] = s_cnt[tid * PER + k]; sum += loc[k]; }
@@ -202,13 +211,14 @@ __global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const 
     int base = 0;
     for (int w = 0; w < wave; ++w) base += s_wsum[w];
     int run = base + inc - sum;
+    start[tid] = run;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      start[tid * PER + k] = run;
+      sstart[tid * PER + k] = run;
       s_cnt[tid * PER + k] = run;
       run += loc[k];
     }
-    if (tid == NT - 1) start[kGridLeaves] = run;
+    if (tid == NT - 1) { start[kGridLeaves] = run; sstart[kGridSubs] = run; }
   }
   __syncthreads();
 
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const 
     float x[DIM];
 #pragma unroll
     for (int i = 0; i < DIM; ++i) x[i] = p.cb[(long)j * DIM + i];
-    const int pos = atomicAdd(&s_cnt[grid_leaf_of<DIM>(x, s_thr)], 1);
+    const int pos = atomicAdd(&s_cnt[grid_sub_of<DIM>(x, s_thr)], 1);
 #pragma unroll
     for (int i = 0; i < DIM; ++i) scb[(long)pos * DIM + i] = x[i];
     sidx[pos] = j;
@@ -227,11 +237,11 @@ __global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const 
 
   // ---- 5. tight bounding boxes, bottom-up ([lo | hi]; an empty node: lo = +inf, hi = -inf)
   const float INF = __builtin_inff();
-  for (int c = tid; c < kGridLeaves; c += NT) {
+  for (int c = tid; c < kGridSubs; c += NT) {
     float lo[DIM], hi[DIM];
 #pragma unroll
     for (int i = 0; i < DIM; ++i) { lo[i] = INF; hi[i] = -INF; }
-    const int s = start[c], e = start[c + 1];
+    const int s = sstart[c], e = sstart[c + 1];
     for (int j = s; j < e; ++j) {
 #pragma unroll
       for (int i = 0; i < DIM; ++i) {
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const 
       }
     }
 #pragma unroll
-    for (int i = 0; i < DIM; ++i) { box3[(long)c * 2 * DIM + i] = lo[i]; box3[(long)c * 2 * DIM + DIM + i] = hi[i]; }
+    for (int i = 0; i < DIM; ++i) { sbox[(long)c * 2 * DIM + i] = lo[i]; sbox[(long)c * 2 * DIM + DIM + i] = hi[i]; }
   }
   __threadfence();
   __syncthreads();
@@ -257,11 +267,14 @@ __global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const 
 #pragma unroll
     for (int i = 0; i < DIM; ++i) { parent[(long)node * 2 * DIM + i] = lo[i]; parent[(long)node * 2 * DIM + DIM + i] = hi[i]; }
   };
+  if (tid < kGridLeaves) merge(sbox, box3, tid, kGridSubPerLeaf);
+  __threadfence();
+  __syncthreads();
   if (tid < kGridL2) merge(box3, box2, tid, kGridLeaves / kGridL2);
   __threadfence();
   __syncthreads();
   if (tid < kGridL1) merge(box2, box1, tid, kGridL2 / kGridL1);
-  if (tid < 15) start[kGridLeaves + 1 + tid] = p.n;      // padding of the start table (copied to LDS in 16-byte pieces)
+  if (tid < 15) { start[kGridLeaves + 1 + tid] = p.n; sstart[kGridSubs + 1 + tid] = p.n; }   // padding (start: copied to LDS in 16-byte pieces)
   // ---- 6. stamp: the hashes this call's first launch computed of the very codebook that was just indexed
   if (tid < kAbsmaxParts) gh->blk_sum[tid] = p.hdr->cbsum[tid];
   __threadfence();
@@ -299,9 +312,7 @@ struct GridParams {
 // `concave` (wave-uniform): every axis of every row of the wave has A < 0 -- the trained operating point, sigma < 1 / sqrt(beta) --
 // and the endpoint arithmetic is skipped (3 instead of 8 instructions per axis; the search is VALU-issue bound).
 template <int DIM>
-__device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float (&B)[DIM], const float (&M)[DIM], const float *box,
-                                             bool concave) {
-  float lo[DIM], hi[DIM];
+__device__ __forceinline__ void grid_load_box(const float *box, float (&lo)[DIM], float (&hi)[DIM]) {
   const f32x4 *q = reinterpret_cast<const f32x4 *>(box);
 #pragma unroll
   for (int k = 0; k < DIM / 4; ++k) {
@@ -309,6 +320,10 @@ __device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float 
     lo[4 * k] = a.x; lo[4 * k + 1] = a.y; lo[4 * k + 2] = a.z; lo[4 * k + 3] = a.w;
     hi[4 * k] = b.x; hi[4 * k + 1] = b.y; hi[4 * k + 2] = b.z; hi[4 * k + 3] = b.w;
   }
+}
+template <int DIM>
+__device__ __forceinline__ float grid_box_ub_v(const float (&A)[DIM], const float (&B)[DIM], const float (&M)[DIM], const float (&lo)[DIM],
+                                               const float (&hi)[DIM], bool concave) {
   float u = 0.0f;
   if (concave) {
 #pragma unroll
@@ -326,6 +341,13 @@ __device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float 
     }
   }
   return lo[0] <= hi[0] ? u : -__builtin_inff();     // empty node (or a NaN box: never visited; such books are scanned)
+}
+template <int DIM>
+__device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float (&B)[DIM], const float (&M)[DIM], const float *box,
+                                             bool concave) {
+  float lo[DIM], hi[DIM];
+  grid_load_box<DIM>(box, lo, hi);
+  return grid_box_ub_v<DIM>(A, B, M, lo, hi, concave);
 }
 
 // Reductions over the 16 lanes of a DPP row (= one search group) without an LDS round trip: quad_perm [1,0,3,2], [2,3,0,1],
@@ -416,18 +438,26 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   constexpr int TREE_F = (kGridL1 + kGridL2 + kGridLeaves) * BOXF;  // floats of box1 | box2 | box3
   constexpr int START_N = kGridLeaves + 16;
   constexpr int LPN = kGridLeaves / kGridL2;            // leaves per L2 node: 4
-  constexpr int CPL = 4;                                // codes per lane and leaf in one round (64-code leaves: one round)
-  constexpr int LEAF_U = 2;                             // leaves per round trip
-  constexpr int EPL = kGridLeafCap / GROUP;             // list entries per lane: 3
+  constexpr int SPL = kGridSubPerLeaf;                  // sub-leaves per leaf: 4
+  constexpr int CPL = 4;                                // codes per lane and LEAF in one round (64-code leaves: one round)
+  constexpr int SUB_U = 6;                              // sub-leaves per round trip (16-code sub-leaves: one code per lane each)
+  constexpr int FIRST_N = 2;                            // leaves of the first round trip of a non-concave row (a beam; concave rows: one)
+  constexpr int CHUNKS = 3;                             // sub-box fetches in flight: 3 x (4 leaves x 4 sub-leaves = the 16 lanes)
+  constexpr int EPL = kGridSubCap / GROUP;              // sub-list entries per lane: 6
+  static_assert(SPL * (GROUP / SPL) == GROUP && kGridSubCap % GROUP == 0, "lane -> (leaf of the chunk, sub-leaf) mapping");
   __shared__ __attribute__((aligned(16))) float s_box[TREE_F];
   __shared__ __attribute__((aligned(16))) int s_start[START_N];
   __shared__ float s_ops[RPB][3 * DIM + 1];
   __shared__ int s_leaflist[RPB][kGridLeafCap];
-  __shared__ float s_leafub[RPB][kGridLeafCap];
-  __shared__ unsigned s_visited[RPB][kGridLeaves / 32];
+  __shared__ float s_subub[RPB][kGridSubCap];
+  __shared__ unsigned s_subpk[RPB][kGridSubCap];        // start (24 bits: n <= 2^20) | length << 24 (longer than 255: the row is handed on)
+  __shared__ unsigned s_sel[RPB][SUB_U];
+  __shared__ int s_next;
   const GridLayout L = grid_layout(p.n, DIM);
   const float *scb = reinterpret_cast<const float *>(p.cache + L.scb);
   const int *sidx = reinterpret_cast<const int *>(p.cache + L.sidx);
+  const float *gsbox = reinterpret_cast<const float *>(p.cache + L.sbox);
+  const int *gsstart = reinterpret_cast<const int *>(p.cache + L.sstart);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % GROUP, grp = lane / GROUP, slot = wave * RPW + grp;
   const int gshift = grp * GROUP;
@@ -438,7 +468,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  {   // the whole tree -> LDS: box1 | box2 | box3 | start are contiguous in the cache (grid_layout)
+  {   // three levels of boxes and the leaves' code ranges -> LDS: box1 | box2 | box3 | start are contiguous in the cache (grid_layout)
     const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cache + L.box1);
     f32x4 *dst = reinterpret_cast<f32x4 *>(s_box);
     for (int k = tid; k < TREE_F / 4; k += kGridThreads) dst[k] = src[k];
@@ -450,6 +480,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   const float N1f = wave_absmax(p.hdr->absmax_part, lane);
   const float NEG_INF = -__builtin_inff();
   const int nquads = (p.rows + RPW - 1) / RPW;
+  if (tid == 0) s_next = 0;
   __syncthreads();
 
 #ifdef GQHIP_CLOCK_STAMPS
@@ -460,9 +491,18 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
 #else
 #define GQ_GRID_STAMP() do { } while (0)
 #endif
-  // Static work split, eight consecutive quads (32 rows: whole cache lines of every row array) per block and round: a device-wide
-  // work counter was tried and serialised the kernel on its atomics (16 384 fetches of one address: 245 us instead of ~100).
-  for (int quad = (int)blockIdx.x * (kGridThreads / 64) + wave; quad < nquads; quad += (int)gridDim.x * (kGridThreads / 64)) {
+  // Work split: a block owns a contiguous share of the row sets (four rows each) and its eight waves draw from it through a counter
+  // in LDS -- a row set takes 10 to 50 us depending on its rows (a flat score: long lists, a second round), and with a static
+  // four sets per wave the slowest wave ended the kernel at twice the mean.  (A device-wide counter was tried first and serialised
+  // the kernel on its atomics: 16 384 fetches of one address, 245 us instead of ~100; strided instead of contiguous shares: the
+  // same within the lease-to-lease noise, and a few percent slower at the trained operating point.)
+  const int per_block = (nquads + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int quad_lo = (int)blockIdx.x * per_block, quad_hi = min(nquads, quad_lo + per_block);
+  for (;;) {
+    int quad = 0;
+    if (lane == 0) quad = quad_lo + atomicAdd(&s_next, 1);
+    quad = __builtin_amdgcn_readfirstlane(quad);
+    if (quad >= quad_hi) break;
     GQ_GRID_STAMP();   // 0: four rows start
     const long pos_raw = (long)quad * RPW + grp;
     const bool live = pos_raw < p.rows;
@@ -485,9 +525,6 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         ops[2 * DIM + i] = p.lsd[row * DIM + i];
       }
     }
-    unsigned *visited = s_visited[slot];
-#pragma unroll
-    for (int k = 0; k < kGridLeaves / 32 / GROUP; ++k) visited[sub + GROUP * k] = 0u;
     // the parabola's vertex, to within an ulp or two (v_rcp_f32): a bound evaluated a relative 1e-7 beside it is below the true one
     // by ~|A| mu'^2 1e-14, nothing against E32
     bool concave_row = true;
@@ -521,10 +558,11 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     double best_s = 0.0;
     int best_i = 0x7fffffff;
     bool have = false;
-    int leaves = 0, exact_n = 0;
+    int units = 0, exact_n = 0;                    // units: visited sub-leaves (a whole leaf counts SPL)
     bool overflow = false;
     auto load_code = [&](int j, float (&n)[DIM]) {
-      const f32x4 *q = reinterpret_cast<const f32x4 *>(scb + (long)j * DIM);
+      // (a 32-bit byte offset from a uniform base: one VALU instruction per address instead of a 64-bit multiply-add; n <= 2^20)
+      const f32x4 *q = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(scb) + (unsigned)j * (unsigned)(DIM * 4));
 #pragma unroll
       for (int k = 0; k < DIM / 4; ++k) {
         const f32x4 v = q[k];
@@ -541,42 +579,38 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       if (!have || better_d(sc, code, best_s, best_i)) { best_s = sc; best_i = code; have = true; }
       ++exact_n;
     };
-    // NL leaves at once: lane `sub` takes codes sub, sub + 16, sub + 32, sub + 48 of each (a leaf's codes are contiguous: 256 B per
-    // group and load instruction; all CPL NL loads in flight together); leaves of more than 64 codes: further rounds.
+    // NR code ranges [s, e) of the sorted codebook at once: lane `sub` takes codes sub, sub + 16, ... (CP of them per round) of each
+    // (a range's codes are contiguous; all CP x NR loads in flight together); longer ranges: further rounds.
     // EXACT = false: F and thr follow, the lane's best code and runner-up value are kept.  EXACT = true (the rare second pass of a
     // near-tie): every code with f^ >= thr receives the reference's arithmetic.
-    auto visit = [&](auto nl_tag, auto exact_tag, const int (&leaf)[decltype(nl_tag)::value], int count) {
-      constexpr int NL = decltype(nl_tag)::value;
+    auto visit = [&](auto nr_tag, auto cp_tag, auto exact_tag, const int (&s)[decltype(nr_tag)::value],
+                     const int (&e)[decltype(nr_tag)::value]) {
+      constexpr int NR = decltype(nr_tag)::value, CP = decltype(cp_tag)::value;
       constexpr bool EXACT = decltype(exact_tag)::value;
-      int s[NL], e[NL];
       int longest = 0;
 #pragma unroll
-      for (int t = 0; t < NL; ++t) {
-        s[t] = s_start[leaf[t]];
-        e[t] = t < count ? s_start[leaf[t] + 1] : s[t];
-        longest = max(longest, e[t] - s[t]);
-      }
-      for (int off = 0; off < longest; off += GROUP * CPL) {          // (group-uniform trip count: one round for 64-code leaves)
-        float f[NL][CPL];
+      for (int t = 0; t < NR; ++t) longest = max(longest, e[t] - s[t]);
+      for (int off = 0; off < longest; off += GROUP * CP) {          // (group-uniform trip count: one round for full ranges)
+        float f[NR][CP];
         {
-          float n[NL][CPL][DIM];
+          float n[NR][CP][DIM];
 #pragma unroll
-          for (int t = 0; t < NL; ++t)
+          for (int t = 0; t < NR; ++t)
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
+            for (int c = 0; c < CP; ++c) {
               const int j = s[t] + off + sub + GROUP * c;
               load_code(j < e[t] ? j : s[t], n[t][c]);
             }
 #pragma unroll
-          for (int t = 0; t < NL; ++t)
+          for (int t = 0; t < NR; ++t)
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) f[t][c] = s[t] + off + sub + GROUP * c < e[t] ? expansion(n[t][c]) : NEG_INF;
+            for (int c = 0; c < CP; ++c) f[t][c] = s[t] + off + sub + GROUP * c < e[t] ? expansion(n[t][c]) : NEG_INF;
         }
         if constexpr (!EXACT) {
 #pragma unroll
-          for (int t = 0; t < NL; ++t)
+          for (int t = 0; t < NR; ++t)
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
+            for (int c = 0; c < CP; ++c) {
               const bool better = f[t][c] > fb;
               fsecond = __builtin_fmaxf(fsecond, better ? fb : f[t][c]);
               jb = better ? s[t] + off + sub + GROUP * c : jb;
@@ -587,28 +621,28 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
         } else {
           unsigned pend = 0u;
 #pragma unroll
-          for (int t = 0; t < NL; ++t)
+          for (int t = 0; t < NR; ++t)
 #pragma unroll
-            for (int c = 0; c < CPL; ++c)
-              pend |= (f[t][c] > NEG_INF && !(f[t][c] < thr)) ? 1u << (t * CPL + c) : 0u;
+            for (int c = 0; c < CP; ++c)
+              pend |= (f[t][c] > NEG_INF && !(f[t][c] < thr)) ? 1u << (t * CP + c) : 0u;
           while (__any(pend != 0u)) {
             if (pend != 0u) {
               const int q = __builtin_ctz(pend);
               pend &= pend - 1u;
               int st = s[0];
 #pragma unroll
-              for (int t = 1; t < NL; ++t) st = q / CPL == t ? s[t] : st;
-              exact_code(st + off + sub + GROUP * (q % CPL));
+              for (int t = 1; t < NR; ++t) st = q / CP == t ? s[t] : st;
+              exact_code(st + off + sub + GROUP * (q % CP));
             }
           }
         }
       }
     };
-    using NL1 = std::integral_constant<int, 1>;
-    using NLU = std::integral_constant<int, LEAF_U>;
+    using N1T = std::integral_constant<int, 1>;
+    using NST = std::integral_constant<int, SUB_U>;
+    using CLT = std::integral_constant<int, CPL>;
+    using NFT = std::integral_constant<int, FIRST_N>;
     auto nonempty = [&](int leaf) { return s_start[leaf + 1] > s_start[leaf]; };
-    auto mark_visited = [&](int leaf) { if (sub == 0) visited[leaf >> 5] |= 1u << (leaf & 31); };
-    auto was_visited = [&](int leaf) { return (visited[leaf >> 5] >> (leaf & 31)) & 1u; };
     GQ_GRID_STAMP();   // 1: operands, bounds, margins
 
 #ifdef GQHIP_ABL
@@ -617,9 +651,16 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     constexpr bool abl_no_search = false, abl_greedy_only = false;
 #endif
     if (!bad && !abl_no_search) {
-      // ---- (1) greedy descent to ONE leaf (LDS only, then one round trip for its codes): a good F before anything is pruned
+      // ---- (1) a good F before anything is pruned (LDS only, then ONE round trip).  Concave rows (the trained operating point: the
+      //      box that holds the parabola's vertex is the best one, and its bound is tight): greedy descent to one leaf, its 64 codes.
+      //      Otherwise (sigma ~ 1: a nearly linear score reaches into the codebook's tails, where boxes are large and their bounds
+      //      loose -- the greedy leaf holds the winner for a third of such rows): a beam -- the two best L1 nodes, the four best of
+      //      their 32 L2 nodes, the FIRST_N best of those nodes' 16 leaves (lists under the resulting thr: 12 instead of 30 leaves).
+      int first_leaf[FIRST_N];
+#pragma unroll
+      for (int t = 0; t < FIRST_N; ++t) first_leaf[t] = -1;
       const float ub1 = grid_box_ub<DIM>(cA, cB, cM, s_box + sub * BOXF, concave);
-      {
+      if (concave) {
         const unsigned b1 = group_bits(ub1 == group_max(ub1) && ub1 > NEG_INF);
         if (b1 != 0u) {
           const int g1 = __builtin_ctz(b1);
@@ -631,26 +672,73 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
             const float ub3 = nonempty(lq) ? grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF, concave) : NEG_INF;
             const unsigned b3 = group_bits(ub3 == group_max(ub3) && ub3 > NEG_INF) & ((1u << LPN) - 1u);
             if (b3 != 0u) {
-              const int one[1] = {node * LPN + __builtin_ctz(b3)};
-              mark_visited(one[0]);
-              visit(NL1{}, std::false_type{}, one, 1);
-              leaves = 1;
+              first_leaf[0] = node * LPN + __builtin_ctz(b3);
+              const int s1[1] = {s_start[first_leaf[0]]}, e1[1] = {s_start[first_leaf[0] + 1]};
+              visit(N1T{}, CLT{}, std::false_type{}, s1, e1);
+              units = SPL;
             }
+          }
+        }
+      } else {
+        float u1m = ub1;
+        const unsigned ba = group_bits(u1m == group_max(u1m) && u1m > NEG_INF);
+        if (ba != 0u) {
+          const int g1a = __builtin_ctz(ba);
+          u1m = sub == g1a ? NEG_INF : u1m;
+          const unsigned bb = group_bits(u1m == group_max(u1m) && u1m > NEG_INF);
+          const int g1b = bb != 0u ? __builtin_ctz(bb) : g1a;
+          const int id2a = g1a * 16 + sub, id2b = g1b * 16 + sub;
+          float c2a = grid_box_ub<DIM>(cA, cB, cM, s_box2 + id2a * BOXF, false);
+          float c2b = bb != 0u ? grid_box_ub<DIM>(cA, cB, cM, s_box2 + id2b * BOXF, false) : NEG_INF;
+          int nd = 0;
+          bool on = false;
+#pragma unroll
+          for (int t = 0; t < GROUP / LPN; ++t) {                        // the four best of the 32 L2 nodes; lane -> (the (sub / 4)-th, leaf sub % 4)
+            const float em = __builtin_fmaxf(c2a, c2b);
+            const float gm = group_max(em);
+            const unsigned ob = group_bits(em == gm && em > NEG_INF);
+            const int owner = ob != 0u ? __builtin_ctz(ob) : 0;
+            const bool first = c2a == gm;
+            const int node = __shfl(first ? id2a : id2b, gshift + owner);
+            if (sub / LPN == t) { nd = node; on = ob != 0u; }
+            if (ob != 0u && sub == owner) { c2a = first ? NEG_INF : c2a; c2b = first ? c2b : NEG_INF; }
+          }
+          const int lq = nd * LPN + (sub & (LPN - 1));
+          float u3 = on && nonempty(lq) ? grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF, false) : NEG_INF;
+          int sf[FIRST_N], ef[FIRST_N];
+          int nfirst = 0;
+#pragma unroll
+          for (int t = 0; t < FIRST_N; ++t) {
+            const unsigned ob = group_bits(u3 == group_max(u3) && u3 > NEG_INF);
+            const int owner = ob != 0u ? __builtin_ctz(ob) : 0;
+            const int lf = __shfl(lq, gshift + owner);
+            if (ob != 0u) { first_leaf[t] = lf; nfirst = t + 1; }
+            u3 = (ob != 0u && sub == owner) ? NEG_INF : u3;
+            sf[t] = s_start[ob != 0u ? lf : 0];
+            ef[t] = ob != 0u ? s_start[lf + 1] : sf[t];
+          }
+          if (nfirst > 0) {
+            visit(NFT{}, CLT{}, std::false_type{}, sf, ef);
+            units = SPL * nfirst;
           }
         }
       }
       GQ_GRID_STAMP();   // 2: greedy descent (one round trip)
       if (abl_greedy_only) thr = __builtin_inff();
       int *list = s_leaflist[slot];
-      float *lub = s_leafub[slot];
+      float *sub_ub = s_subub[slot];
+      unsigned *sub_pk = s_subpk[slot];
+      unsigned *sel = s_sel[slot];
       const unsigned lt = (1u << sub) - 1u;
+      float eu[EPL];                                                      // this lane's entries of the sub-list: bound (-inf: visited / none)
+      unsigned ep[EPL], vis = 0u;                                         // ... packed range; bit k of vis: entry k was visited
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) { eu[k] = NEG_INF; ep[k] = 0u; }
       for (int round = 0;; ++round) {
-        wave_sync_lds();                                                  // (the visited bitmap of the previous round)
-        // ---- (2) the unvisited leaves whose bound -- and whose L1 and L2 nodes' bounds -- are within the margin of F -> a list with
-        //      their bounds (LDS / VALU only).  Per passing L1 node: its 16 L2 bounds (one per lane), then the leaves of the passing
-        //      L2 nodes four nodes at a time: lane -> (the (sub / 4)-th of them, leaf sub % 4)
+        // ---- (2) the leaves whose bound -- and whose L1 and L2 nodes' bounds -- are within the margin of F -> a list (LDS / VALU
+        //      only).  Per passing L1 node: its 16 L2 bounds (one per lane), then the leaves of the passing L2 nodes four nodes at
+        //      a time: lane -> (the (sub / 4)-th of them, leaf sub % 4)
         int nleaf = 0;
-        bool truncated = false;
         unsigned m1 = group_bits(!(ub1 < thr) && ub1 > NEG_INF);
         while (m1 != 0u) {
           const int q1 = __builtin_ctz(m1);
@@ -669,91 +757,181 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
             }
             const int lq = (q1 * 16 + nd) * LPN + (sub & (LPN - 1));
             const float ub3 = grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF, concave);
-            const bool c = on && nonempty(lq) && !(ub3 < thr) && !was_visited(lq);
+            bool c = on && nonempty(lq) && !(ub3 < thr);
+#pragma unroll
+            for (int t = 0; t < FIRST_N; ++t) c = c && lq != first_leaf[t];
             const unsigned pm = group_bits(c);
             const int pos = nleaf + __builtin_popcount(pm & lt);
-            if (c && pos < kGridLeafCap) { list[pos] = lq; lub[pos] = ub3; }
+            if (c && pos < kGridLeafCap) list[pos] = lq;
             nleaf += __builtin_popcount(pm);
           }
         }
-        truncated = truncated || nleaf > kGridLeafCap;
+        bool truncated = nleaf > kGridLeafCap;
         nleaf = min(nleaf, kGridLeafCap);
-        // a long list: 16 lanes would walk it two leaves per round trip while the wave's other three rows wait -- a whole block
-        // (gq_grid_finish_kernel) does it in a few microseconds
         if (nleaf > p.inwave_cap) { overflow = true; break; }
         wave_sync_lds();
-        GQ_GRID_STAMP();   // 3: lists (first round)
-        // ---- (3) best bound first, LEAF_U leaves per round trip, until the best remaining bound is below the threshold
-        float eu[EPL];
-        int el[EPL];
+        GQ_GRID_STAMP();   // 3: leaf list
+        // ---- (2b) the sub-leaves of the listed leaves: their boxes and code ranges come from the cache (L2), 4 leaves x 4 sub-leaves
+        //      = the group's 16 lanes per fetch, CHUNKS fetches in flight; the ones within the margin -> the sub-list (bound, range)
+        int nsub = 0;
+        bool big = false;
+        // (wave-uniform trip counts below come from __any over the ACTIVE lanes: the registers of a group that has left -- a row
+        //  with non-finite bounds, an overflowed row -- hold whatever was there)
+        auto fetch = [&](auto nc_tag, int base) {
+          constexpr int NC = decltype(nc_tag)::value;
+          float lo[NC][DIM], hi[NC][DIM];
+          int r0[NC], r1[NC];
+          bool val[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int k = base + c * (GROUP / SPL) + sub / SPL;
+            val[c] = k < nleaf;
+            const int sid = val[c] ? list[k] * SPL + (sub & (SPL - 1)) : 0;   // (a group without that many leaves: any valid address)
+            grid_load_box<DIM>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(gsbox) + (unsigned)sid * (unsigned)(BOXF * 4)),
+                               lo[c], hi[c]);
+            const int *rp = reinterpret_cast<const int *>(reinterpret_cast<const char *>(gsstart) + (unsigned)sid * 4u);
+            r0[c] = rp[0];
+            r1[c] = rp[1];
+          }
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float ubs = grid_box_ub_v<DIM>(cA, cB, cM, lo[c], hi[c], concave);
+            const int len = r1[c] - r0[c];
+            const bool cnd = val[c] && len > 0 && !(ubs < thr);
+            big = big || (cnd && len > 255);
+            const unsigned pm = group_bits(cnd);
+            const int pos = nsub + __builtin_popcount(pm & lt);
+            if (cnd && pos < kGridSubCap) { sub_ub[pos] = ubs; sub_pk[pos] = (unsigned)r0[c] | ((unsigned)min(len, 255) << 24); }
+            nsub += __builtin_popcount(pm);
+          }
+        };
+        for (int base = 0; __any(base < nleaf); base += CHUNKS * (GROUP / SPL)) {
+          if (!__any(nleaf - base > GROUP / SPL)) fetch(N1T{}, base);     // (the trained operating point: one to four listed leaves)
+          else fetch(std::integral_constant<int, CHUNKS>{}, base);
+        }
+        // (a sub-leaf of more than 255 codes -- a degenerate codebook: most of it in one cell -- is a block's work, not 16 lanes')
+        if (group_bits(big) != 0u) { overflow = true; break; }
+        truncated = truncated || nsub > kGridSubCap;
+        nsub = min(nsub, kGridSubCap);
+        wave_sync_lds();
+        vis = 0u;
+        int kmax = 0;                                                     // (uniform) list slots per lane any group of the wave uses
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) kmax += __any(nsub > GROUP * k) ? 1 : 0;
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
           const int i = sub + GROUP * k;
-          eu[k] = i < nleaf ? lub[i] : NEG_INF;
-          el[k] = i < nleaf ? list[i] : 0;
-        }
-        int budget = truncated ? 8 : kGridLeafCap;                        // a truncated list: its best leaves, then ONE rebuild with the tighter thr
-        while (budget > 0) {
-          int lf[LEAF_U];
-          int cnt = 0;
-#pragma unroll
-          for (int t = 0; t < LEAF_U; ++t) {
-            float em = eu[0];
-#pragma unroll
-            for (int k = 1; k < EPL; ++k) em = __builtin_fmaxf(em, eu[k]);
-            const float gm = group_max(em);
-            const bool go = gm > NEG_INF && !(gm < thr);
-            const unsigned ob = group_bits(em == gm);
-            const int owner = ob ? __builtin_ctz(ob) : 0;
-            int mine = el[0];
-            bool taken = false;
-#pragma unroll
-            for (int k = 0; k < EPL; ++k) {
-              const bool hit = !taken && eu[k] == gm;
-              mine = hit ? el[k] : mine;
-              if (go && sub == owner && hit) eu[k] = NEG_INF;
-              taken = taken || hit;
-            }
-            lf[t] = __shfl(mine, gshift + owner);
-            if (go) { ++cnt; mark_visited(lf[t]); } else if (t > 0) lf[t] = lf[0];
+          eu[k] = NEG_INF;
+          ep[k] = 0u;
+          if (k < kmax) {
+            eu[k] = i < nsub ? sub_ub[i] : NEG_INF;
+            ep[k] = i < nsub ? sub_pk[i] : 0u;
           }
-          if (cnt == 0) break;
-          visit(NLU{}, std::false_type{}, lf, cnt);
-          leaves += cnt;
-          budget -= cnt;
+        }
+        GQ_GRID_STAMP();   // 4: sub-list
+        // ---- (3) SUB_U sub-leaves per round trip until the best remaining bound is below the threshold.  The first batch of a long
+        //      list: the entries in the upper half of [thr, best bound] (F is probably there); afterwards, and when everything fits
+        //      one batch, whatever is still within the margin, in list order.
+        int budget = truncated ? 2 * SUB_U : kGridSubCap;                 // a truncated list: its best part, then ONE rebuild with the tighter thr
+        int remaining = nsub;
+        bool first_batch = true;
+        while (budget > 0) {
+          float em = eu[0];
+#pragma unroll
+          for (int k = 1; k < EPL; ++k)
+            if (k < kmax) em = __builtin_fmaxf(em, eu[k]);
+          const float gm = group_max(em);
+          if (!(gm > NEG_INF) || gm < thr) break;
+          float cut = thr;
+          if (first_batch && remaining > SUB_U) {
+            cut = thr > NEG_INF ? __builtin_fmaxf(thr, 0.5f * gm + 0.5f * thr) : gm;
+            cut = cut <= gm ? cut : gm;                                    // (rounding; NaN)
+          }
+          first_batch = false;
+          wave_sync_lds();                                                // (the previous batch's reads of sel)
+          int taken = 0;
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) {
+            if (k >= kmax) continue;
+            const bool c = eu[k] > NEG_INF && !(eu[k] < cut);
+            const unsigned pm = group_bits(c);
+            const int r = taken + __builtin_popcount(pm & lt);
+            if (c && r < SUB_U) { sel[r] = ep[k]; eu[k] = NEG_INF; vis |= 1u << k; }
+            taken += __builtin_popcount(pm);
+          }
+          taken = min(taken, SUB_U);
+          wave_sync_lds();
+          int s[SUB_U], e[SUB_U];
+#pragma unroll
+          for (int t = 0; t < SUB_U; ++t) {
+            const unsigned pk = sel[t < taken ? t : 0];
+            s[t] = (int)(pk & 0xffffffu);
+            e[t] = t < taken ? s[t] + (int)(pk >> 24) : s[t];
+          }
+          visit(NST{}, N1T{}, std::false_type{}, s, e);
+          units += taken;
+          budget -= taken;
+          remaining -= taken;
         }
         if (!truncated) break;
-        // still more than the list holds: a row with a long tail of loose boxes (near-linear scores reach far into the codebook's
-        // tails, where leaves are large) -- 16 lanes walking hundreds of leaves would hold up its wave for 100+ us (measured: the
-        // bench's gq_1.00 z, 330 us per launch); the whole block scans it at its end instead, two passes over the codes
-        if (round >= 1 || leaves > p.leaf_cap) { overflow = true; break; }
+        // still more than the lists hold: a row with a long tail of loose boxes (near-linear scores reach far into the codebook's
+        // tails).  ONE rebuild under the tighter threshold; every code that can still matter is in a box that is listed again, so the
+        // lanes' best codes start over (F and thr stay) and the first leaf is listed like any other.  A second truncation: the row
+        // goes to gq_grid_finish_kernel (a whole block finishes it in a few microseconds; 16 lanes would hold up their wave).
+        if (round >= 1 || units > p.leaf_cap * SPL) { overflow = true; break; }
+        fb = NEG_INF; fsecond = NEG_INF; jb = -1;
+#pragma unroll
+        for (int t = 0; t < FIRST_N; ++t) first_leaf[t] = -1;
       }
-      GQ_GRID_STAMP();   // 4: listed leaves
+      GQ_GRID_STAMP();   // 5: listed sub-leaves
       // ---- (4) the final threshold is known: the reference's arithmetic for every code within the margin
       if (!overflow) {
-        if (jb >= 0 && !(fb < thr)) exact_code(jb);
-        if (group_bits(fsecond > NEG_INF && !(fsecond < thr)) != 0u) {
-          // a lane holds a second code within the margin (a near-tie): every visited leaf again, everything within the margin exactly
-          wave_sync_lds();
-          for (int w = 0; w < kGridLeaves / 32; ++w) {
-            unsigned bits = visited[w];                                   // (group-uniform)
+        const bool cand = jb >= 0 && !(fb < thr);
+        const bool tie = group_bits(fsecond > NEG_INF && !(fsecond < thr)) != 0u;
+        if (__builtin_popcount(group_bits(cand)) == 1 && !tie) {
+          // ONE code of the row within the margin of its best expansion: every other code's reference score is provably below this
+          // code's, whatever the two are -- it is the argmax, and the reference's arithmetic (a hundred-odd instructions that the whole
+          // wave would sit through) is not needed to say so
+          if (cand) { best_i = sidx[jb]; best_s = 0.0; have = true; }
+        } else {
+        if (cand) exact_code(jb);
+        if (tie) {
+          // a lane holds a second code within the margin (a near-tie): everything visited again, every code within the margin exactly
+#pragma unroll
+          for (int t = 0; t < FIRST_N; ++t)
+            if (first_leaf[t] >= 0) {                                      // (group-uniform)
+              const int s1[1] = {s_start[first_leaf[t]]}, e1[1] = {s_start[first_leaf[t] + 1]};
+              visit(N1T{}, CLT{}, std::true_type{}, s1, e1);
+            }
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) {
+            unsigned bits = group_bits(((vis >> k) & 1u) != 0u);
             while (bits != 0u) {
-              const int one[1] = {w * 32 + __builtin_ctz(bits)};
+              const int owner = __builtin_ctz(bits);
               bits &= bits - 1u;
-              visit(NL1{}, std::true_type{}, one, 1);
+              const unsigned pk = (unsigned)__shfl((int)ep[k], gshift + owner);
+              const int s1[1] = {(int)(pk & 0xffffffu)}, e1[1] = {(int)(pk & 0xffffffu) + (int)(pk >> 24)};
+              visit(N1T{}, N1T{}, std::true_type{}, s1, e1);
             }
           }
+        }
         }
       }
     }
-    GQ_GRID_STAMP();     // 5: exact pass
-    // ---- the row's winner
+    GQ_GRID_STAMP();     // 6: exact pass
+    // ---- the row's winner: the one lane that holds a code, or the best of several (score, then the lower code)
+    const unsigned hb = group_bits(have);
+    if (__builtin_popcount(hb) == 1) {
+      best_i = __shfl(best_i, gshift + __builtin_ctz(hb));
+      have = true;
+    } else if (hb != 0u) {
 #pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) {
-      const double os = __shfl_xor(best_s, o);
-      const int oi = __shfl_xor(best_i, o);
-      const bool oh = __shfl_xor((int)have, o) != 0;
-      if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+      for (int o = GROUP / 2; o > 0; o >>= 1) {
+        const double os = __shfl_xor(best_s, o);
+        const int oi = __shfl_xor(best_i, o);
+        const bool oh = __shfl_xor((int)have, o) != 0;
+        if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+      }
     }
     const bool decided = live && !bad && !overflow && have;
     if (decided) grid_write_result(p, row, best_i, sub, DIM);
@@ -763,7 +941,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       for (int o = GROUP / 2; o > 0; o >>= 1) e += __shfl_xor(e, o);
       if (sub == 0) {
         atomicAdd(&p.hdr->reranked, (unsigned long long)e);
-        atomicAdd(&p.hdr->grid_leaves, (unsigned long long)leaves);
+        atomicAdd(&p.hdr->grid_leaves, (unsigned long long)units);
       }
     }
     // ---- an undecided row: to the call's list; gq_grid_finish_kernel (the next launch) finishes it with a whole block
@@ -775,7 +953,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       p.und_margin[pos] = margin32;
     }
 #ifdef GQHIP_CLOCK_STAMPS
-    GQ_GRID_STAMP();     // 6: reduce, stores
+    GQ_GRID_STAMP();     // 7: reduce, stores
     if (lane == 0 && first_pass_ && wave == 0 && blockIdx.x % 100 == 0 && blockIdx.x / 100 < 6) {   // six blocks' wave 0, first four rows
       for (int k = 0; k < 8; ++k) p.hdr->stamps[8 * (blockIdx.x / 100) + k] = k < nst_ ? st_[k] : 0ull;
     }

@@ -517,7 +517,9 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     gp.und_thr = reinterpret_cast<float *>(ws + w.rec) + rows;
     gp.und_margin = reinterpret_cast<float *>(ws + w.rec) + 2 * rows;
     const int64_t nsets = (rows + 31) / 32;                        // (a block's eight waves fetch four rows at a time from a counter)
-    const dim3 ggrid((unsigned)(nsets < 512 ? nsets : 512));       // two 512-thread blocks per CU: one wave of blocks
+    static const int env_blocks = getenv("GQHIP_GRID_BLOCKS") ? atoi(getenv("GQHIP_GRID_BLOCKS")) : 0;   // diagnostics
+    const int64_t max_blocks = env_blocks > 0 ? env_blocks : 512;
+    const dim3 ggrid((unsigned)(nsets < max_blocks ? nsets : max_blocks));   // two 512-thread blocks per CU: one wave of blocks
     ProfScope prof;
 #define GQ_GRID(D)                                                                                                   \
   do {                                                                                                               \

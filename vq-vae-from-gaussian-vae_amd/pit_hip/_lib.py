@@ -1102,7 +1102,8 @@ def debug_grid(ws: Workspace) -> dict:
     out = (_i64 * 4)()
     cptr = None if ws.cache_buf is None else ws.cache_buf.data_ptr()
     _check(lib().gqhip_debug_grid(ws.buf.data_ptr(), cptr, out), "gqhip_debug_grid")
-    return {"leaves": out[0], "exact_codes": out[1], "scanned_rows": out[2], "index_current": out[3]}
+    # out[0]: visited sub-leaves (1/4096 of the codebook each); "leaves": the same in leaves (four sub-leaves, 1/1024 of the codebook)
+    return {"sub_leaves": out[0], "leaves": out[0] / 4.0, "exact_codes": out[1], "scanned_rows": out[2], "index_current": out[3]}
 
 
 def debug_counters(ws: Workspace) -> Tuple[int, int]:
