@@ -356,13 +356,25 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_row_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// (Written out: from the builtins the compiler makes v_mov_b32_dpp + a canonicalising v_max + the v_max itself per step, twelve
+//  VALU instructions per reduction of a kernel that is VALU-issue bound; the fused form is four.  s_nop 1: the two wait states a
+//  DPP read needs after a VALU write of its source.  Every lane of a row is active or none is, and no source lane is invalid for
+//  these four patterns.)
 __device__ __forceinline__ float row16_max(float v) {
-  v = __builtin_fmaxf(v, dpp_row_f<0xB1>(v));
-  v = __builtin_fmaxf(v, dpp_row_f<0x4E>(v));
-  v = __builtin_fmaxf(v, dpp_row_f<0x141>(v));
-  v = __builtin_fmaxf(v, dpp_row_f<0x140>(v));
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(v));
   return v;
 }
+// max of two values that are never NaN here (rows with non-finite operands or bounds do not get this far): one v_med3_f32 instead
+// of the canonicalise-then-max pair that fmaxf becomes under IEEE mode
+__device__ __forceinline__ float fmax_nn(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 
 constexpr int kGridThreads = 512;      // 8 waves x 4 rows: 32 rows per block pass share one LDS copy of the tree; two blocks per CU
 
@@ -453,6 +465,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   __shared__ unsigned s_subpk[RPB][kGridSubCap];        // start (24 bits: n <= 2^20) | length << 24 (longer than 255: the row is handed on)
   __shared__ unsigned s_sel[RPB][SUB_U];
   __shared__ int s_next;
+  __shared__ unsigned s_stat_units, s_stat_exact;       // debug statistics of the block (one device atomic each at its end)
   const GridLayout L = grid_layout(p.n, DIM);
   const float *scb = reinterpret_cast<const float *>(p.cache + L.scb);
   const int *sidx = reinterpret_cast<const int *>(p.cache + L.sidx);
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % GROUP, grp = lane / GROUP, slot = wave * RPW + grp;
   const int gshift = grp * GROUP;
-  auto group_bits = [&](bool c) { return (unsigned)((__ballot(c) >> gshift) & 0xffffull); };
+  auto group_bits = [&](bool c) { return (unsigned)((__builtin_amdgcn_ballot_w64(c) >> gshift) & 0xffffull); };
   auto group_max = [&](float v) { return row16_max(v); };
   auto wave_sync_lds = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   const float N1f = wave_absmax(p.hdr->absmax_part, lane);
   const float NEG_INF = -__builtin_inff();
   const int nquads = (p.rows + RPW - 1) / RPW;
-  if (tid == 0) s_next = 0;
+  if (tid == 0) { s_next = 0; s_stat_units = 0u; s_stat_exact = 0u; }
   __syncthreads();
 
 #ifdef GQHIP_CLOCK_STAMPS
@@ -612,11 +625,11 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
 #pragma unroll
             for (int c = 0; c < CP; ++c) {
               const bool better = f[t][c] > fb;
-              fsecond = __builtin_fmaxf(fsecond, better ? fb : f[t][c]);
+              fsecond = fmax_nn(fsecond, better ? fb : f[t][c]);
               jb = better ? s[t] + off + sub + GROUP * c : jb;
               fb = better ? f[t][c] : fb;
             }
-          F = __builtin_fmaxf(F, group_max(fb));
+          F = fmax_nn(F, group_max(fb));
           thr = thr_of(F);
         } else {
           unsigned pend = 0u;
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
           bool on = false;
 #pragma unroll
           for (int t = 0; t < GROUP / LPN; ++t) {                        // the four best of the 32 L2 nodes; lane -> (the (sub / 4)-th, leaf sub % 4)
-            const float em = __builtin_fmaxf(c2a, c2b);
+            const float em = fmax_nn(c2a, c2b);
             const float gm = group_max(em);
             const unsigned ob = group_bits(em == gm && em > NEG_INF);
             const int owner = ob != 0u ? __builtin_ctz(ob) : 0;
@@ -839,7 +852,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
           float em = eu[0];
 #pragma unroll
           for (int k = 1; k < EPL; ++k)
-            if (k < kmax) em = __builtin_fmaxf(em, eu[k]);
+            if (k < kmax) em = fmax_nn(em, eu[k]);
           const float gm = group_max(em);
           if (!(gm > NEG_INF) || gm < thr) break;
           float cut = thr;
@@ -940,8 +953,8 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
 #pragma unroll
       for (int o = GROUP / 2; o > 0; o >>= 1) e += __shfl_xor(e, o);
       if (sub == 0) {
-        atomicAdd(&p.hdr->reranked, (unsigned long long)e);
-        atomicAdd(&p.hdr->grid_leaves, (unsigned long long)units);
+        atomicAdd(&s_stat_exact, (unsigned)e);
+        atomicAdd(&s_stat_units, (unsigned)units);
       }
     }
     // ---- an undecided row: to the call's list; gq_grid_finish_kernel (the next launch) finishes it with a whole block
@@ -960,6 +973,13 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     first_pass_ = false;
     nst_ = 8;
 #endif
+  }
+  if (p.stats) {                                         // (uniform)
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(&p.hdr->reranked, (unsigned long long)s_stat_exact);
+      atomicAdd(&p.hdr->grid_leaves, (unsigned long long)s_stat_units);
+    }
   }
 }
 
