@@ -64,6 +64,27 @@ def test_workspace_sizing_is_host_only_and_monotone():
     assert L.gqhip_workspace_bytes(16, 0, 16) == -1
 
 
+def test_codebook_cache_sizing_is_host_only_and_pins_the_index_layout():
+    """gqhip.h:gqhip_cb_cache_bytes -- dim 4 (2^14 <= n <= 2^20): the search index of csrc/gq_grid.h:grid_layout = header 4 KiB, boxes of
+    16 + 256 + 1024 nodes, leaf ranges, sub-leaf ranges, 4096 sub-leaf boxes, the codes sorted by sub-leaf, their original ids (every
+    table rounded up to 256 B); dims 8 / 16 / 32: header + the filter's fp16 operand image (32 / 64 / 128 B per code); nothing else."""
+    L = _lib().lib()
+
+    def al(v):
+        return (v + 255) // 256 * 256
+
+    for n in (16384, 65536, 70001, 1 << 20):
+        want = 4096 + (16 + 256 + 1024) * 32 + al((1024 + 16) * 4) + al((4096 + 16) * 4) + 4096 * 32 + al(n * 16) + al(n * 4)
+        assert L.gqhip_cb_cache_bytes(n, 4) == want
+        assert L.gqhip_grid_search_applies(n, 4) == 1
+    assert L.gqhip_cb_cache_bytes(65536, 4) == 1508352
+    assert L.gqhip_cb_cache_bytes(16383, 4) == 0 and L.gqhip_cb_cache_bytes((1 << 20) + 1, 4) == 0
+    assert L.gqhip_grid_search_applies(65536, 8) == 0 and L.gqhip_grid_search_applies(65536, 16) == 0
+    img = {d: L.gqhip_cb_cache_bytes(65536, d) for d in (8, 16, 32)}
+    assert img[8] > 4096 and img[16] >= 4096 + 65536 * 64 and img[32] > img[16] > img[8]
+    assert L.gqhip_cb_cache_bytes(65536, 5) == 0 and L.gqhip_cb_cache_bytes(65536, 64) == 0
+
+
 def test_invalid_arguments_return_status_not_crash():
     L = _lib().lib()
     assert L.gq_argmax_f32(None, None, None, None, None, None, 16, 4, 1024, 1.0, None, 0, None, 0, None) == 1
