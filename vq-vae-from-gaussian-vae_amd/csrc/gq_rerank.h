@@ -556,10 +556,21 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
       have = true;
     }
   };
-  if (codeb >= 0 && (keep_all || !(fb < thr32))) exact(nb, codeb);
+  const bool in_window = codeb >= 0 && (keep_all || !(fb < thr32));
+  const bool second_in_window = codeb >= 0 && (keep_all || !(fsecond < thr32)) && fsecond > NEG_INF;
+  // ONE code of the row inside the window (19 rows of 20): every other candidate code's reference score is provably below this
+  // code's (that is what the window means), so it is the arg-max whatever the two scores are -- the reference's arithmetic, a few
+  // hundred instructions that the whole wave would sit through, is only needed to decide between several (round 5; the same
+  // shortcut as gq_grid.h's)
+  const bool only_one = !keep_all && __popcll(group_bits(in_window)) == 1 && group_bits(second_in_window) == 0ull;
+  if (only_one) {
+    if (in_window) { best_s = 0.0; best_i = codeb; have = true; }
+  } else if (in_window) {
+    exact(nb, codeb);
+  }
   // a second code of the SAME lane inside the window (rare: a near-tie within one lane's few codes): go through
   // this lane's codes again
-  if (__any(codeb >= 0 && (keep_all || !(fsecond < thr32)) && fsecond > NEG_INF)) {
+  if (__any(second_in_window)) {
     for (int e = 0; e < wave_total; ++e) {
       if (e < total && (keep_all || !(fsecond < thr32))) {
         const int id = cand[slot][e];
