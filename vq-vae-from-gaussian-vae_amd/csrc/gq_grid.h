@@ -5,13 +5,14 @@
 // bound by the VALU fold of its own outputs (>= 8 v_max3 per 32-cycle MFMA), not by the matrix cores -- no schedule fixes that.
 // But 65 536 codes are DENSE in 4 dimensions: the score  f(r, j) = sum_i A_ri n_ji^2 + B_ri n_ji  is a quadratic per coordinate,
 // so its maximum over an axis-aligned BOX of codes is a closed form, and almost every box is far below the row's best code.  The
-// codebook is therefore sorted once into a two-level tree of boxes -- 16 nodes x 64 = 1024 leaves of ~64 codes, TIGHT bounding
+// codebook is therefore sorted once into a tree of boxes -- 16 -> 256 -> 1024 leaves -> 4096 sub-leaves of ~16 codes, TIGHT bounding
 // boxes of their actual members (the quantile cells themselves are useless in the near-linear regime of sigma ~ 1:
-// profiles/r05/grid_prune_study.txt) -- and a row first walks greedily to its most promising leaf (a good F), then visits every
-// leaf whose upper bound is not below  F - margin.  ALL boxes and code ranges sit in LDS (37 KiB at dim 4), so the only global
-// reads of a row are its own operands and the codes of the leaves it visits: the search is a chain of dependent round trips of
-// ~1 us each on a busy chip, and the variants with a tree level in global memory spent their time exactly there
-// (profiles/r05/grid_search_variants.txt).
+// profiles/r05/grid_prune_study.txt).  Three levels of boxes and the leaves' code ranges sit in LDS (46 KiB at dim 4); the sub-leaf
+// boxes and ranges are fetched from the cache (L2) for the leaves a row lists.  A row first spends ONE round trip on a good F
+// (greedy descent to a leaf, or a beam to two leaves when its score is not concave), lists the leaves, then the sub-leaves, whose
+// upper bound is not below  F - margin, and visits those six per round trip, F tightening.  The kernel is bound by VALU issue
+// (~1500 instructions per four rows, three quarters of them bookkeeping of the 16-lane groups) with 5-7 dependent round trips of
+// ~1.5 us on top; every variant that was built and timed on the way: profiles/r05/grid_search_variants.txt.
 //
 // Exactness is unchanged -- the reference's own arithmetic still decides (gq_common.h:ref_term / gq_rerank.h:ref_score_lds):
 //   * f^(j) = the fp32 FMA expansion of f (pass 1 of the re-rank: |f^ - f| <= E32 = (2 dim + 4) u T);  E_r bounds the reference
@@ -20,7 +21,7 @@
 //     f(j*) >= F - E32 - 2 E_r.  Every box that contains j* has a true upper bound >= f(j*); its computed bound U^ is below the true
 //     one by at most (dim + 1) u T <= E32 (one FMA pair per axis evaluated at a point of the box, dim - 1 additions), so
 //     U^ >= F - 2 E32 - 2 E_r >= F - margin32: the box is visited, at either level, whatever F was at the time (F only grows).
-//   * Inside a leaf, j* has f^(j*) >= F - 2 E32 - 2 E_r >= F - margin32 as well, so it receives the reference's arithmetic; the
+//   * Inside a sub-leaf, j* has f^(j*) >= F - 2 E32 - 2 E_r >= F - margin32 as well, so it receives the reference's arithmetic; the
 //     winner among everything that did is taken in torch.argmax order (score, then lowest index; NaN first).
 //   * Rows the search does not decide go to a list and are finished by gq_grid_finish_kernel (the launch after the search; it exits
 //     at once when the list is empty), a block per row: a row whose leaf list does not fit even after one rebuild (a long tail of
@@ -299,8 +300,8 @@ struct GridParams {
   WsHeader *hdr;
   int rows, n;
   float beta;
-  int leaf_cap;                    // leaves a row may visit before it is handed to the block-wide scan
-  int inwave_cap;                  // listed leaves a row's 16 lanes walk themselves; a longer list goes to gq_grid_finish_kernel
+  int leaf_cap;                    // leaves' worth of codes a row may visit before a truncated list sends it to gq_grid_finish_kernel
+  int inwave_cap;                  // listed leaves a row's 16 lanes go through themselves (diagnostics: default = the list's capacity)
   int stats;
   int *und_row;                    // [rows] undecided rows, appended by the search ((row << 1) | keep_all), finished by gq_grid_finish_kernel
   float *und_thr, *und_margin;     // [rows] their threshold so far and margin32
@@ -352,10 +353,6 @@ __device__ __forceinline__ float grid_box_ub(const float (&A)[DIM], const float 
 
 // Reductions over the 16 lanes of a DPP row (= one search group) without an LDS round trip: quad_perm [1,0,3,2], [2,3,0,1],
 // row_half_mirror, row_mirror -- afterwards every lane of the row holds the result.
-template <int CTRL>
-__device__ __forceinline__ float dpp_row_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
 // (Written out: from the builtins the compiler makes v_mov_b32_dpp + a canonicalising v_max + the v_max itself per step, twelve
 //  VALU instructions per reduction of a kernel that is VALU-issue bound; the fused form is four.  s_nop 1: the two wait states a
 //  DPP read needs after a VALU write of its source.  Every lane of a row is active or none is, and no source lane is invalid for
