@@ -375,20 +375,23 @@ __device__ __forceinline__ float fmax_nn(float a, float b) { return __builtin_am
 
 constexpr int kGridThreads = 512;      // 8 waves x 4 rows: 32 rows per block pass share one LDS copy of the tree; two blocks per CU
 
-// 16 lanes per row, 4 rows per wave; every wave walks its own share of the rows (no block barrier inside the loop: a
-// row's search is a chain of dependent steps of very uneven length, and waiting for the slowest of 32 rows at every pass cost a
-// third of the kernel: profiles/r05/grid_search_variants.txt).  The whole tree (three levels of boxes, the code ranges of the
-// leaves) sits in LDS.  A row:
-//   (1) greedy descent to ONE leaf -> F;
-//   (2) the L2 nodes, then the leaves, whose bound is within the margin of F go to a list with their bounds (LDS / VALU only);
-//   (3) best bound first, two leaves per round trip, until the best remaining bound is below the threshold (F and thr tighten with
-//       every batch): fp32 expansions; every lane keeps its own best code and its runner-up value (the re-rank's pass-1 scheme);
-//       a list that did not fit is rebuilt with the tighter threshold (visited leaves are remembered in a bitmap);
-//   (4) with the FINAL threshold, the lanes whose best code is within the margin give it the reference's arithmetic -- ONE instance
-//       of that long, divergent code per row; a lane with a SECOND code within the margin (a near-tie) sends the row through all
-//       its visited leaves again with the exact score for everything within the margin.
-// Undecided rows (non-finite operands or bounds, a non-finite codebook, a list that does not fit after one rebuild) go to the call's
-// list and are finished by gq_grid_finish_kernel, the next launch.
+// 16 lanes per row, 4 rows per wave; a block's eight waves draw row sets from a counter in LDS (no block barrier inside the loop: a
+// row's search is a chain of dependent steps of very uneven length; waiting for the slowest of 32 rows at every pass cost a third of
+// the kernel, a static split of the row sets ended at twice the mean: profiles/r05/grid_search_variants.txt).  Three levels of
+// boxes and the code ranges of the leaves sit in LDS.  A row:
+//   (1) ONE round trip for a first F: concave rows -- greedy descent to one leaf, its 64 codes; otherwise a beam to two leaves;
+//   (2) the leaves whose bound (and whose L1 / L2 nodes' bounds) is within the margin of F -> a list (LDS / VALU only);
+//   (3) their sub-leaves' boxes and code ranges from the cache, twelve leaves per round trip; those within the margin -> the
+//       sub-list (bound, packed range);
+//   (4) six sub-leaves per round trip (one code per lane and sub-leaf) until the best remaining bound is below the threshold (F and
+//       thr tighten with every batch): fp32 expansions; every lane keeps its own best code and its runner-up value (the re-rank's
+//       pass-1 scheme); lists that did not fit: their best part is visited, then ONE rebuild under the tighter threshold;
+//   (5) with the FINAL threshold: a row with one code within the margin is decided (no reference arithmetic needed to name the
+//       arg-max); otherwise the lanes whose best code is within the margin give it the reference's arithmetic -- ONE instance of
+//       that long, divergent code per row -- and a lane with a SECOND code within the margin (a near-tie) sends the row through
+//       everything it visited again with the exact score for everything within the margin.
+// Undecided rows (non-finite operands or bounds, a non-finite codebook, lists that do not fit after one rebuild, a sub-leaf of more
+// than 255 codes) go to the call's list and are finished by gq_grid_finish_kernel, the next launch.
 
 template <int MODE, int DIM>
 __device__ __forceinline__ void grid_scan_accumulate(const GridParams &p, const float (&cA)[DIM], const float (&cB)[DIM], const float *ops,
