@@ -531,7 +531,8 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     rc = check_launch();
     if (rc != GQHIP_OK) return rc;
     // launch 4: the rows the search left undecided, a block per row (exits at once when there are none)
-    const dim3 fgrid(256);
+    static const int env_fblocks = getenv("GQHIP_FINISH_BLOCKS") ? atoi(getenv("GQHIP_FINISH_BLOCKS")) : 0;   // diagnostics
+    const dim3 fgrid((unsigned)(env_fblocks > 0 ? env_fblocks : 256));
     if (dim == 4) hipLaunchKernelGGL((gq_grid_finish_kernel<MODE, 4>), fgrid, dim3(kGridThreads), 0, st, gp);
     else hipLaunchKernelGGL((gq_grid_finish_kernel<MODE, 8>), fgrid, dim3(kGridThreads), 0, st, gp);
     return check_launch();
