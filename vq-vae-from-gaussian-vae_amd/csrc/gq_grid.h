@@ -47,7 +47,7 @@ constexpr int kGridL1 = 16, kGridL2 = 256, kGridLeaves = 1024;    // 16 nodes x 
 constexpr int kGridFan2 = kGridLeaves / kGridL1;                    // leaves under an L1 node
 constexpr int kGridSubPerLeaf = 4, kGridSubs = kGridLeaves * kGridSubPerLeaf;   // sub-leaves (boxes in the cache, not in LDS): 4096
 constexpr int kGridBuildThreads = 1024;
-constexpr int kGridLeafCap = 48;                   // leaf-list capacity of the search
+constexpr int kGridLeafCap = 128;                  // leaf-list capacity of the search (16-bit ids; 48 / 64 / 96 were measured: grid_search_variants.txt)
 constexpr int kGridSubCap = 96;                    // sub-leaf list capacity (a longer list: its best part is visited, then ONE rebuild)
 
 struct GridHdr {                                   // first 4 KiB of the codebook cache
@@ -380,7 +380,7 @@ constexpr int kGridThreads = 512;      // 8 waves x 4 rows: 32 rows per block pa
 // the kernel, a static split of the row sets ended at twice the mean: profiles/r05/grid_search_variants.txt).  Three levels of
 // boxes and the code ranges of the leaves sit in LDS.  A row:
 //   (1) ONE round trip for a first F: concave rows -- greedy descent to one leaf, its 64 codes; otherwise a beam to two leaves;
-//   (2) the leaves whose bound (and whose L1 / L2 nodes' bounds) is within the margin of F -> a list (LDS / VALU only);
+//   (2) the leaves whose bound (and whose L1 / L2 nodes' bounds) is within the margin of F -> a list of up to 128 (LDS / VALU only);
 //   (3) their sub-leaves' boxes and code ranges from the cache, twelve leaves per round trip; those within the margin -> the
 //       sub-list (bound, packed range);
 //   (4) six sub-leaves per round trip (one code per lane and sub-leaf) until the best remaining bound is below the threshold (F and
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   __shared__ __attribute__((aligned(16))) float s_box[TREE_F];
   __shared__ __attribute__((aligned(16))) int s_start[START_N];
   __shared__ float s_ops[RPB][3 * DIM + 1];
-  __shared__ int s_leaflist[RPB][kGridLeafCap];
+  __shared__ unsigned short s_leaflist[RPB][kGridLeafCap];   // (leaf ids < 1024)
   __shared__ float s_subub[RPB][kGridSubCap];
   __shared__ unsigned s_subpk[RPB][kGridSubCap];        // start (24 bits: n <= 2^20) | length << 24 (longer than 255: the row is handed on)
   __shared__ unsigned s_sel[RPB][SUB_U];
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       }
       GQ_GRID_STAMP();   // 2: greedy descent (one round trip)
       if (abl_greedy_only) thr = __builtin_inff();
-      int *list = s_leaflist[slot];
+      unsigned short *list = s_leaflist[slot];
       float *sub_ub = s_subub[slot];
       unsigned *sub_pk = s_subpk[slot];
       unsigned *sel = s_sel[slot];
@@ -749,35 +749,34 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       for (int k = 0; k < EPL; ++k) { eu[k] = NEG_INF; ep[k] = 0u; }
       for (int round = 0;; ++round) {
         // ---- (2) the leaves whose bound -- and whose L1 and L2 nodes' bounds -- are within the margin of F -> a list (LDS / VALU
-        //      only).  Per passing L1 node: its 16 L2 bounds (one per lane), then the leaves of the passing L2 nodes four nodes at
-        //      a time: lane -> (the (sub / 4)-th of them, leaf sub % 4)
-        int nleaf = 0;
+        //      only).  Per passing L1 node: its 16 L2 bounds (one per lane) -> the passing L2 nodes, as bytes; then their leaves four
+        //      nodes at a time: lane -> (the (sub / 4)-th of them, leaf sub % 4).  (Going from each L1 node straight to its own L2
+        //      nodes' leaves left three of four lanes idle in most passes: 7 passes instead of 4 on sigma ~ 1 rows.)
+        int nleaf = 0, nl2 = 0;
+        unsigned char *l2l = reinterpret_cast<unsigned char *>(sub_ub);     // (the sub-list's LDS is free until the fetches below)
         unsigned m1 = group_bits(!(ub1 < thr) && ub1 > NEG_INF);
-        while (m1 != 0u) {
+        while (m1 != 0u) {                                                 // the passing L2 nodes of the passing L1 nodes -> a byte list
           const int q1 = __builtin_ctz(m1);
           m1 &= m1 - 1u;
           const float ub2 = grid_box_ub<DIM>(cA, cB, cM, s_box2 + (q1 * 16 + sub) * BOXF, concave);
-          unsigned pm2 = group_bits(!(ub2 < thr) && ub2 > NEG_INF);
-          while (pm2 != 0u) {
-            int nd = 0;
-            bool on = false;
+          const bool c2 = !(ub2 < thr) && ub2 > NEG_INF;
+          const unsigned pm2 = group_bits(c2);
+          if (c2) l2l[nl2 + __builtin_popcount(pm2 & lt)] = (unsigned char)(q1 * 16 + sub);
+          nl2 += __builtin_popcount(pm2);
+        }
+        wave_sync_lds();
+        for (int i0 = 0; i0 < nl2; i0 += GROUP / LPN) {                    // their leaves, four nodes at a time whatever L1 node they hang under
+          const int k = i0 + sub / LPN;
+          const bool on = k < nl2;
+          const int lq = (int)l2l[on ? k : 0] * LPN + (sub & (LPN - 1));
+          const float ub3 = grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF, concave);
+          bool c = on && nonempty(lq) && !(ub3 < thr);
 #pragma unroll
-            for (int t = 0; t < GROUP / LPN; ++t) {
-              const bool here = pm2 != 0u;
-              const int c2 = here ? __builtin_ctz(pm2) : 0;
-              pm2 &= pm2 - 1u;                                            // (0 stays 0)
-              if (sub / LPN == t) { nd = c2; on = here; }
-            }
-            const int lq = (q1 * 16 + nd) * LPN + (sub & (LPN - 1));
-            const float ub3 = grid_box_ub<DIM>(cA, cB, cM, s_box3 + lq * BOXF, concave);
-            bool c = on && nonempty(lq) && !(ub3 < thr);
-#pragma unroll
-            for (int t = 0; t < FIRST_N; ++t) c = c && lq != first_leaf[t];
-            const unsigned pm = group_bits(c);
-            const int pos = nleaf + __builtin_popcount(pm & lt);
-            if (c && pos < kGridLeafCap) list[pos] = lq;
-            nleaf += __builtin_popcount(pm);
-          }
+          for (int t = 0; t < FIRST_N; ++t) c = c && lq != first_leaf[t];
+          const unsigned pm = group_bits(c);
+          const int pos = nleaf + __builtin_popcount(pm & lt);
+          if (c && pos < kGridLeafCap) list[pos] = (unsigned short)lq;
+          nleaf += __builtin_popcount(pm);
         }
         bool truncated = nleaf > kGridLeafCap;
         nleaf = min(nleaf, kGridLeafCap);
@@ -799,7 +798,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
           for (int c = 0; c < NC; ++c) {
             const int k = base + c * (GROUP / SPL) + sub / SPL;
             val[c] = k < nleaf;
-            const int sid = val[c] ? list[k] * SPL + (sub & (SPL - 1)) : 0;   // (a group without that many leaves: any valid address)
+            const int sid = val[c] ? (int)list[k] * SPL + (sub & (SPL - 1)) : 0;   // (a group without that many leaves: any valid address)
             grid_load_box<DIM>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(gsbox) + (unsigned)sid * (unsigned)(BOXF * 4)),
                                lo[c], hi[c]);
             const int *rp = reinterpret_cast<const int *>(reinterpret_cast<const char *>(gsstart) + (unsigned)sid * 4u);
