@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   constexpr int CPL = 4;                                // codes per lane and LEAF in one round (64-code leaves: one round)
   constexpr int SUB_U = 6;                              // sub-leaves per round trip (16-code sub-leaves: one code per lane each)
   constexpr int FIRST_N = 2;                            // leaves of the first round trip of a non-concave row (a beam; concave rows: one)
-  constexpr int CHUNKS = 3;                             // sub-box fetches in flight: 3 x (4 leaves x 4 sub-leaves = the 16 lanes)
+  constexpr int CHUNKS = 4;                             // sub-box fetches in flight: 3 x (4 leaves x 4 sub-leaves = the 16 lanes)
   constexpr int EPL = kGridSubCap / GROUP;              // sub-list entries per lane: 6
   static_assert(SPL * (GROUP / SPL) == GROUP && kGridSubCap % GROUP == 0, "lane -> (leaf of the chunk, sub-leaf) mapping");
   __shared__ __attribute__((aligned(16))) float s_box[TREE_F];
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     float fb = NEG_INF, fsecond = NEG_INF;         // this lane's best code (value, sorted position) and its runner-up value
     int jb = -1;
     double best_s = 0.0;
-    int best_i = 0x7fffffff;
+    int best_i = 0x7fffffff, best_j = 0;           // the winner so far: original code id (ties: the lower one wins), position in the sorted codebook
     bool have = false;
     int units = 0, exact_n = 0;                    // units: visited sub-leaves (a whole leaf counts SPL)
     bool overflow = false;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       double sc;
       if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(nn, ops, p.beta);
       else sc = vq_neg_dist(nn, ops, DIM);
-      if (!have || better_d(sc, code, best_s, best_i)) { best_s = sc; best_i = code; have = true; }
+      if (!have || better_d(sc, code, best_s, best_i)) { best_s = sc; best_i = code; best_j = j; have = true; }
       ++exact_n;
     };
     // NR code ranges [s, e) of the sorted codebook at once: lane `sub` takes codes sub, sub + 16, ... (CP of them per round) of each
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
           // ONE code of the row within the margin of its best expansion: every other code's reference score is provably below this
           // code's, whatever the two are -- it is the argmax, and the reference's arithmetic (a hundred-odd instructions that the whole
           // wave would sit through) is not needed to say so
-          if (cand) { best_i = sidx[jb]; best_s = 0.0; have = true; }
+          if (cand) { best_j = jb; best_s = 0.0; have = true; }        // (its original id: fetched with the result, below)
         } else {
         if (cand) exact_code(jb);
         if (tie) {
@@ -934,19 +934,24 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     // ---- the row's winner: the one lane that holds a code, or the best of several (score, then the lower code)
     const unsigned hb = group_bits(have);
     if (__builtin_popcount(hb) == 1) {
-      best_i = __shfl(best_i, gshift + __builtin_ctz(hb));
+      best_j = __shfl(best_j, gshift + __builtin_ctz(hb));
       have = true;
     } else if (hb != 0u) {
 #pragma unroll
       for (int o = GROUP / 2; o > 0; o >>= 1) {
         const double os = __shfl_xor(best_s, o);
-        const int oi = __shfl_xor(best_i, o);
+        const int oi = __shfl_xor(best_i, o), oj = __shfl_xor(best_j, o);
         const bool oh = __shfl_xor((int)have, o) != 0;
-        if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; have = true; }
+        if (oh && (!have || better_d(os, oi, best_s, best_i))) { best_s = os; best_i = oi; best_j = oj; have = true; }
       }
     }
     const bool decided = live && !bad && !overflow && have;
-    if (decided) grid_write_result(p, row, best_i, sub, DIM);
+    if (decided) {
+      // the winner's original id and its code row come from the SORTED tables at the same position: two independent loads, one round
+      // trip (through cb[sidx[j]] it was two; the sorted row is a bit copy of the caller's, and the cache was validated by this call)
+      if (sub == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)sidx[best_j];
+      if (p.zhat && sub < DIM) p.zhat[out_zhat_offset(p.omap, row, sub, DIM)] = scb[(long)best_j * DIM + sub];
+    }
     if (p.stats && live) {
       int e = exact_n;
 #pragma unroll
