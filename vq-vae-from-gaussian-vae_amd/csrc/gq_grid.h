@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
   constexpr int CPL = 4;                                // codes per lane and LEAF in one round (64-code leaves: one round)
   constexpr int SUB_U = 6;                              // sub-leaves per round trip (16-code sub-leaves: one code per lane each)
   constexpr int FIRST_N = 2;                            // leaves of the first round trip of a non-concave row (a beam; concave rows: one)
-  constexpr int CHUNKS = 4;                             // sub-box fetches in flight: 3 x (4 leaves x 4 sub-leaves = the 16 lanes)
+  constexpr int CHUNKS = 3;                             // sub-box fetches in flight: 3 x (4 leaves x 4 sub-leaves = the 16 lanes)
   constexpr int EPL = kGridSubCap / GROUP;              // sub-list entries per lane: 6
   static_assert(SPL * (GROUP / SPL) == GROUP && kGridSubCap % GROUP == 0, "lane -> (leaf of the chunk, sub-leaf) mapping");
   __shared__ __attribute__((aligned(16))) float s_box[TREE_F];
