@@ -22,7 +22,9 @@
  *                    :273-331 (GQ2.quant_vq) -- also folds the chunk/clamp/exp
  *                    and the group permutes into the kernels.
  *   gq_dequant_f32   pit/quantization/gaussian.py:162-178, :347-362.
+ *   gq_quantize_z_gauss_f32  pit/quantization/gaussian.py:211-271,273-345 (GaussianQuantRegularizer2.forward, eval).
  *   vq_argmin_f32    pit/quantization/vq.py:58-73.
+ *   vq_quantize_z_f32 pit/quantization/vq.py:39-96 (VQQuantizer.forward, eval).
  *   lfq_pack_f32     pit/quantization/lfq.py:147-158.
  *   lfq_unpack_f32   pit/quantization/lfq.py:210-228 (also BSQ: pit/quantization/bsq.py:85-156).
  *   fsq_quantize_f32 / fsq_dequant_f32  pit/quantization/fsq.py:29-89.
@@ -38,14 +40,18 @@
 extern "C" {
 #endif
 
-#define GQHIP_ABI_VERSION 7   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
+#define GQHIP_ABI_VERSION 8   /* 2: filter selection, debug plan, NHWC upsample; 3: Winograd / sub-pixel conv transforms, gn_stats, add_bias_stats;
                                * 4: four-launch fused arg-max (no caller-cached max|cb|; noise / zhat_noquant in gq_quantize_z_f32), profile_reserve;
                                * 5: GroupNorm statistics as order-independent fixed-point records (gqhip_gnstat_t), conv3x3_f32 (fp32 matrix
                                *    cores: conv_in / conv_out of the encoder and decoder), gqhip_debug_barrier / gqhip_debug_tail;
                                * 6: three-launch fused arg-max -- undecided rows are finished inside the re-rank, the tail kernel with its grid
                                *    barriers is gone and gqhip_debug_barrier / gqhip_debug_tail with it; gq_step_record_f32, conv3x3_cin_small_f32;
                                * 7: codebook cache (gqhip_cb_cache_bytes; cb_cache arguments of gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32):
-                               *    dims 4 / 8 run a pruned exact search over a cached spatial index of the codebook (csrc/gq_grid.h) */
+                               *    dim 4 runs a pruned exact search over a cached spatial index of the codebook (csrc/gq_grid.h), dims 8 / 16 /
+                               *    32 keep the filter's fp16 codebook image there;
+                               * 8: module-level eval forwards of GaussianQuantRegularizer2 (gq_quantize_z_gauss_f32: the Gaussian branch's
+                               *    statistics and lambda state on the device) and VQQuantizer (vq_quantize_z_f32: layouts, straight-through
+                               *    value and codebook loss inside the launches) */
 
 /* GroupNorm statistics of one (image, group): GQHIP_GNSTAT_WORDS int64 words = {sum: 3 limbs, sum of squares: 3 limbs, poison,
  * unused}; value = q0 2^-56 + q1 2^-16 + q2 2^24.  Every kernel that leaves statistics behind adds its threads' fp32 partial
@@ -172,6 +178,31 @@ int gq_quantize_z_f32(const float *z, const float *noise_or_null, const float *c
                       void *workspace, int64_t workspace_bytes,
                       void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream);
 
+/* ---- GaussianQuantRegularizer2.forward in eval (pit/quantization/gaussian.py:211-271 quant_gaussian, :273-331 quant_vq,
+ * :333-345 forward) as ONE call: gq_quantize_z_f32's launches + one one-block launch.  On top of gq_quantize_z_f32:
+ *   zhat_noquant = mu + noise * sd (required here: it is the Gaussian branch's sample), sd_out_or_null = sd in the layout of zhat
+ *   (info["std"]); use_ste != 0: zhat = (zhat_noquant - zhat_noquant) + code, the value of `zhat_g - zhat_g.detach() + zhat_v`
+ *   (gaussian.py:337-338) in the reference's fp32 op order (a non-finite zhat_noquant makes it NaN there too), and
+ *   zhat_quant_or_null (layout of zhat) then receives the codewords themselves (info["zhat_quant"]); without use_ste zhat holds them;
+ *   per row (= per group) kl2 = sum_i 1.4426 * 0.5 * (mu^2 + var - 1 - logvar) (gaussian.py:225-229; the element in the
+ *   reference's fp32 op order with var = float(exp(double(logvar))), the row sum in fp64 rounded once), reduced in a fixed order
+ *   (bit-reproducible) to
+ *   scalars_out (64 bytes of device memory, 8-byte aligned): float[0..3] = { kl_loss, bits-mean, bits-min, bits-max }
+ *       (kl_loss = mean(ge kl2 + eq kl2 + le kl2) * lam with lam / lam_min / lam_max as they were BEFORE this call, gaussian.py:233-241);
+ *       double[0..2] at byte 32 = { lam, lam_min, lam_max } AFTER this call's update (what info["lam"], ["lam-min"], ["lam-max"] report).
+ *   lam_state (device, double[3] = { lam, lam_min, lam_max }, in / out): the adaptive lambda state machine of gaussian.py:243-257
+ *       advanced on the device in fp64 (the same IEEE operations as the reference's Python floats), so the forward reads nothing
+ *       back -- the reference pays three host syncs per forward for it.  log2n = int(log2(n_samples)); thresholds are compared as
+ *       torch does (the scalar cast to fp32); lam_max_decreases: 1 = gaussian.py:109-112 (GQ1's train branch), 0 = GQ2, whose
+ *       decrease at gaussian.py:251 is an expression without effect; clamps: lam_max to [1, lam_hi], lam_min to [lam_lo, 1].
+ * Workspace / codebook cache / stream: as gq_quantize_z_f32. */
+int gq_quantize_z_gauss_f32(const float *z, const float *noise, const float *cb, int64_t *idx, float *zhat,
+                            float *zhat_quant_or_null, float *zhat_noquant, float *sd_out_or_null, void *scalars_out, double *lam_state, int64_t B,
+                            int64_t L, int64_t c, int64_t dim, int64_t n, int layout, int grouping, double lv_min,
+                            double lv_max, double beta, int use_ste, double log2n, double tolerance, double lam_factor,
+                            double lam_lo, double lam_hi, int lam_max_decreases, void *workspace, int64_t workspace_bytes,
+                            void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream);
+
 /* zhat from indices (same layouts as above). */
 int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B,
                    int64_t L, int64_t K, int64_t dim, int64_t n, int layout,
@@ -182,6 +213,18 @@ int vq_argmin_f32(const float *z, const float *emb, int64_t *idx,
                   float *zq_or_null, int64_t dim, int64_t rows, int64_t n,
                   void *workspace, int64_t workspace_bytes,
                   void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream);
+
+/* ---- VQQuantizer.forward in eval (pit/quantization/vq.py:39-96) as ONE call: the permutes, the per-sub-codebook slices, the
+ * embedding lookup, the straight-through value and the two MSE means are inside vq_argmin_f32's launches + one small launch.
+ *   z [B, c, L] (GQHIP_LAYOUT_BCHW) or [B, L, c] (GQHIP_LAYOUT_BLC), c = dim * K; sub-codebook k, column d <- channel d * K + k
+ *   (vq.py:53), every sub-codebook against the same `emb` [n, dim];
+ *   idx [B, K, L] / [B, L, K];  zq (layout of z) = z + (e - z), e = emb[idx], in the reference's fp32 op order (vq.py:89);
+ *   loss2_or_null (device float[2]): [0] = codebook_loss = mean + beta * mean (legacy != 0) | beta * mean + mean (vq.py:78-86) in
+ *   fp32, [1] = mean = sum((e - z)^2) / (rows * dim): squared differences formed in fp32, summed in fp64 in a fixed order
+ *   (bit-reproducible; torch's fp32 mean agrees to rounding).  Arg-min: vq_argmin_f32's (fp64 arbiter, first minimum wins). */
+int vq_quantize_z_f32(const float *z, const float *emb, int64_t *idx, float *zq, float *loss2_or_null, int64_t B, int64_t L,
+                      int64_t c, int64_t dim, int64_t n, int layout, double beta, int legacy, void *workspace,
+                      int64_t workspace_bytes, void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream);
 
 /* ---- LFQ: sign quantisation + big-endian bit pack -------------------------- */
 int lfq_pack_f32(const float *x, int64_t *idx, float *q_or_null, int64_t rows,

@@ -233,6 +233,42 @@ def gq2_quant_vq(z: np.ndarray, cb: np.ndarray, dim: int, dim_idx: int = 1, beta
             np.ascontiguousarray(np.moveaxis(indices, -1, dim_idx)))
 
 
+def gq2_quant_gaussian_stats(z: np.ndarray, dim: int, n_samples: int, lam_state, dim_idx: int = 1, tolerance: float = 0.5,
+                             lam_factor: float = 1.01, lam_range=(1e-7, 1e7), logvar_range=(-30.0, 20.0)):
+    """The deterministic part of GaussianQuantRegularizer2.quant_gaussian (gaussian.py:211-257): KL bits per group, their
+    mean / min / max, the re-weighted loss with the lambdas as they are on entry, and the lambda update -- incl. the decrease of
+    lam_max that the reference spells as an expression without effect (gaussian.py:251).  lam_state = (lam, lam_min, lam_max)
+    Python floats; returns ({"kl_loss", "bits-mean", "bits-min", "bits-max"} as float32 scalars, new lam_state).  fp32 element
+    arithmetic in the reference's op order; the reductions are numpy's (the reference's are torch's: equal to rounding)."""
+    import math
+
+    lam, lam_min, lam_max = (float(v) for v in lam_state)
+    log2n = int(math.log(n_samples, 2))
+    zf = np.moveaxis(_f32(z), dim_idx, -1)
+    zf = np.ascontiguousarray(zf).reshape(-1, zf.shape[-1])
+    knum = zf.shape[-1] // (2 * dim)
+    mu, logvar = np.split(zf, 2, axis=-1)
+    logvar = np.clip(logvar, np.float32(logvar_range[0]), np.float32(logvar_range[1]))
+    var = np.exp(logvar.astype(np.float64)).astype(np.float32)
+    kl2 = np.float32(1.4426 * 0.5) * (((mu * mu + var) - np.float32(1.0)) - logvar)
+    kl2 = kl2.reshape(-1, knum, dim).astype(np.float64).sum(-1).astype(np.float32)
+    mean, kmin, kmax = np.float32(kl2.astype(np.float64).mean()), kl2.min(), kl2.max()
+    hi, lo = np.float32(log2n + tolerance), np.float32(log2n - tolerance)
+    ge = (kl2 > hi).astype(np.float32) * np.float32(lam_max)
+    eq = (kl2 <= hi).astype(np.float32) * (kl2 >= lo).astype(np.float32)
+    le = (kl2 < lo).astype(np.float32) * np.float32(lam_min)
+    w = ge * kl2 + eq * kl2 + le * kl2
+    kl_loss = np.float32(w.astype(np.float64).mean()) * np.float32(lam)
+    lam = lam * lam_factor if mean > log2n else lam / lam_factor
+    if kmax > hi:
+        lam_max = lam_max * lam_factor
+    lam_max = max(min(lam_max, lam_range[1]), 1.0)
+    lam_min = lam_min / lam_factor if kmin < lo else lam_min * lam_factor
+    lam_min = max(min(lam_min, 1.0), lam_range[0])
+    return ({"kl_loss": np.float32(kl_loss), "bits-mean": mean, "bits-min": np.float32(kmin), "bits-max": np.float32(kmax)},
+            (lam, lam_min, lam_max))
+
+
 def gq2_dequant(indices: np.ndarray, cb: np.ndarray, dim: int, dim_idx: int = 1) -> np.ndarray:
     """GaussianQuantRegularizer2.dequant (gaussian.py:347-362)."""
     ind = np.moveaxis(indices, dim_idx, -1)
@@ -283,6 +319,18 @@ def vq_forward(z: np.ndarray, emb: np.ndarray, codebook_num: int = 1, fmt: str =
         zq, indices, gap = zq.reshape(b, h * w, c), indices.reshape(b, h * w, -1), gap.reshape(b, h * w, -1)
     out = (np.ascontiguousarray(zq), np.ascontiguousarray(indices))
     return out + (np.ascontiguousarray(gap),) if with_gap else out
+
+
+def vq_forward_eval(z: np.ndarray, emb: np.ndarray, codebook_num: int = 1, fmt: str = "bchw", beta: float = 0.25,
+                    legacy: bool = True, threads: int = 0):
+    """What VQQuantizer.forward returns (vq.py:76-98): the straight-through VALUE z + (z_q - z) in fp32, the indices, the
+    codebook loss (fp32 squares, mean, beta on the reference's side of the sum) and the oracle's top-2 gaps."""
+    zq, ind, gap = vq_forward(z, emb, codebook_num, fmt, threads, with_gap=True)
+    z = _f32(z)
+    d = zq - z
+    m = np.float32((d * d).astype(np.float64).mean())
+    loss = m + np.float32(beta) * m if legacy else np.float32(beta) * m + m
+    return np.ascontiguousarray(z + d), ind, np.float32(loss), gap
 
 
 def vq_dequant(indices: np.ndarray, emb: np.ndarray, codebook_num: int = 1, fmt: str = "bchw") -> np.ndarray:

@@ -1,0 +1,202 @@
+"""-m gpu: the module-level eval forwards that run as ONE library call (ABI 8) -- GaussianQuantRegularizer2.forward
+(gq_quantize_z_gauss_f32: pit/quantization/gaussian.py:211-271, 273-345) and VQQuantizer.forward (vq_quantize_z_f32:
+pit/quantization/vq.py:39-96) -- against goldens captured from the reference (g19, g20: tests/golden/make_golden_r6.py), the oracle,
+and the torch-glue path of the same modules (what runs when autograd is on)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gq_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+REF_INFO_KEYS = {"kl_loss", "bits-mean", "bits-min", "bits-max", "lam-min", "lam-max", "lam", "mu", "std", "zhat_noquant",
+                 "indices", "zhat_quant"}          # gaussian.py:268-269, :329, :344
+
+
+def _close(a, b, rel=2e-5):
+    return abs(float(a) - float(b)) <= rel * max(1.0, abs(float(b)))
+
+
+# ------------------------------------------------------------------------------------------ GQ2
+@pytest.mark.parametrize("tag,dim,n,dim_idx", [("a", 4, 1024, 1), ("b", 16, 4096, -1)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_g19_gq2_eval_forward_vs_reference_golden(tag, dim, n, dim_idx, channels_last):
+    """Three consecutive eval forwards (the lambda state machine moves): scalars of info within 2e-5, the lambdas EXACTLY the
+    reference's Python floats, indices / zhat / zhat_quant bit-equal, std within an ulp (libm), every info key present."""
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
+
+    d = np.load(os.path.join(G, "g19_gq2_eval_forward.npz"))
+    z = torch.from_numpy(d[f"{tag}_z"]).to(DEV)
+    if channels_last:
+        if z.dim() != 4:
+            pytest.skip("channels_last is a 4-d layout")
+        z = z.contiguous(memory_format=torch.channels_last)
+    m = GaussianQuantRegularizer2(dim, n, dim_idx=dim_idx).eval().to(DEV)
+    with torch.no_grad():
+        for it in range(3):
+            zi = z + 0.1 * it
+            zhat, info = m(zi)
+            assert set(info) == REF_INFO_KEYS
+            for k, want in zip(("kl_loss", "bits-mean", "bits-min", "bits-max"), d[f"{tag}_scalars_{it}"]):
+                assert _close(info[k], want), (it, k, float(info[k]), want)
+                assert info[k].dim() == 0 and info[k].dtype == torch.float32
+            lams = [float(info["lam"]), float(info["lam-min"]), float(info["lam-max"])]
+            assert lams == list(d[f"{tag}_lams_{it}"]), (it, lams)
+            assert np.array_equal(info["indices"].cpu().numpy(), d[f"{tag}_indices_{it}"])
+            assert np.array_equal(info["zhat_quant"].cpu().numpy(), d[f"{tag}_zhat_quant_{it}"])
+            assert torch.equal(zhat, info["zhat_quant"])                 # finite zhat_noquant: (g - g) + v == v
+            np.testing.assert_allclose(info["std"].cpu().numpy(), d[f"{tag}_std_{it}"], rtol=2.4e-7)
+            c = z.shape[dim_idx] // 2
+            assert torch.equal(info["mu"], zi.narrow(dim_idx % z.dim(), 0, c))
+            assert info["zhat_noquant"].shape == zhat.shape == info["mu"].shape
+    assert [m.lam, m.lam_min, m.lam_max] == list(d[f"{tag}_lams_2"])       # the attributes pull the device state
+
+
+def test_gq2_fused_forward_equals_the_torch_glue_path_at_config_shape():
+    """BASELINE configs[3]'s gq2_0.25 shape (dim 16, n 65536, bs 4): fused call vs quant_gaussian + quant_vq of the same module
+    (autograd path): same indices, same statistics, same lambda trajectory; zhat_noquant = mu + noise * std for the noise the
+    fused path drew from torch's generator."""
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
+
+    g = torch.Generator().manual_seed(3)
+    z = torch.cat([0.9 * torch.randn(4, 16, 32, 32, generator=g), -1.5 + 0.3 * torch.randn(4, 16, 32, 32, generator=g)], 1).to(DEV)
+    fused = GaussianQuantRegularizer2(16, 65536).eval().to(DEV)
+    glue = copy.deepcopy(fused)
+    for it in range(3):
+        zi = z * (1.0 + 0.2 * it)
+        with torch.no_grad():
+            torch.manual_seed(11 + it)
+            zf, inf = fused(zi)
+            torch.manual_seed(11 + it)
+            noise = torch.randn(4, 16, 32 * 32, device=DEV).view(4, 16, 32, 32)     # the draw of _forward_fused ("bchw": [outer, C, inner])
+        zg, ing = glue(zi.clone().requires_grad_(True))
+        assert torch.equal(inf["indices"], ing["indices"]) and torch.equal(zf, zg.detach())
+        for k in ("kl_loss", "bits-mean", "bits-min", "bits-max"):
+            assert _close(inf[k], ing[k], 1e-5), (it, k, float(inf[k]), float(ing[k]))
+        assert [float(inf[k]) for k in ("lam", "lam-min", "lam-max")] == [ing["lam"], ing["lam-min"], ing["lam-max"]]
+        want = inf["mu"] + noise * inf["std"]
+        assert torch.equal(inf["zhat_noquant"], want)
+        np.testing.assert_allclose(inf["std"].cpu().numpy(), ing["std"].detach().cpu().numpy(), rtol=2.4e-7)
+    assert (fused.lam, fused.lam_min, fused.lam_max) == (glue.lam, glue.lam_min, glue.lam_max)
+
+
+def test_gq2_lambda_state_moves_between_host_and_device():
+    """Writing an attribute makes the host copy authoritative (the next fused forward uploads it); the torch-glue path (train /
+    autograd) continues from where the device left off; use_ste False returns the codes in eval."""
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
+
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(2, 32, 8, 8, generator=g).to(DEV)
+    m = GaussianQuantRegularizer2(4, 1024).eval().to(DEV)
+    with torch.no_grad():
+        _, i0 = m(z)
+        m.lam = 2.0
+        assert (m.lam, m.lam_min, m.lam_max) == (2.0, float(i0["lam-min"]), float(i0["lam-max"]))
+        _, i1 = m(z)
+    st, _ = O.gq2_quant_gaussian_stats(z.cpu().numpy(), 4, 1024, (2.0, float(i0["lam-min"]), float(i0["lam-max"])))
+    assert _close(i1["kl_loss"], st["kl_loss"])
+    host = (m.lam, m.lam_min, m.lam_max)
+    m.train()
+    _, i2 = m.quant_gaussian(z)                                   # torch glue: starts from the pulled device state
+    _, want = O.gq2_quant_gaussian_stats(z.cpu().numpy(), 4, 1024, host)
+    assert (m.lam, m.lam_min, m.lam_max) == want
+    m2 = GaussianQuantRegularizer2(4, 1024, use_ste=False).eval().to(DEV)
+    with torch.no_grad():
+        zh, inf = m2(z)
+    assert torch.equal(zh, inf["zhat_quant"]) and torch.equal(zh, m2.dequant(inf["indices"]))
+
+
+def test_gq2_straight_through_value_is_nan_where_the_sample_is_not_finite():
+    """zhat = zhat_g - zhat_g.detach() + zhat_v (gaussian.py:337-338): inf - inf = NaN in the reference; zhat_quant stays the code."""
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
+
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 32, 4, 4, generator=g)
+    z[0, 3, 1, 2] = float("inf")
+    m = GaussianQuantRegularizer2(16, 1024).eval().to(DEV)
+    with torch.no_grad():
+        zh, inf = m(z.to(DEV))
+    bad = torch.zeros(1, 16, 4, 4, dtype=torch.bool)
+    bad[0, 3, 1, 2] = True
+    assert torch.isnan(zh.cpu()[bad]).all() and torch.isfinite(zh.cpu()[~bad]).all()
+    assert torch.isfinite(inf["zhat_quant"]).all() and torch.equal(inf["zhat_quant"], m.dequant(inf["indices"]))
+
+
+# ------------------------------------------------------------------------------------------ VQ
+@pytest.mark.parametrize("tag,n,dim,K,legacy", [("k1", 4096, 16, 1, True), ("k2", 1024, 8, 2, True), ("nl", 2048, 8, 2, False)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_g20_vq_eval_forward_vs_reference_golden(tag, n, dim, K, legacy, channels_last):
+    from pit_hip.quantization.vq import VQQuantizer
+
+    d = np.load(os.path.join(G, "g20_vq_eval_forward.npz"))
+    vq = VQQuantizer("bchw", n, dim, codebook_num=K, legacy=legacy).eval().to(DEV)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.from_numpy(d[f"{tag}_emb"]))
+        z = torch.from_numpy(d[f"{tag}_z"]).to(DEV)
+        if channels_last:
+            z = z.contiguous(memory_format=torch.channels_last)
+        zq, info = vq(z)
+    ind = info["indices"].cpu().numpy()
+    clear = d[f"{tag}_gap"] > 1e-4
+    assert ind.dtype == np.int64 and ind.shape == d[f"{tag}_indices"].shape
+    assert np.array_equal(ind[clear], d[f"{tag}_indices"][clear])
+    assert np.array_equal(ind, d[f"{tag}_indices"])                        # (no near-tie rows in these fixtures)
+    assert np.array_equal(zq.cpu().numpy(), d[f"{tag}_zq"])                # z + (e - z), bit for bit
+    assert _close(info["codebook_loss"], d[f"{tag}_loss"], 2e-6) and info["codebook_loss"].dim() == 0
+    assert np.array_equal(vq.dequant(info["indices"]).cpu().numpy(), O.vq_dequant(ind, d[f"{tag}_emb"], K))
+
+
+@pytest.mark.parametrize("fmt,K,dim,n", [("bchw", 1, 16, 65536), ("blc", 2, 8, 4096), ("bchw", 4, 4, 65536), ("bchw", 1, 6, 512)])
+def test_vq_fused_forward_equals_the_autograd_path_and_the_oracle(fmt, K, dim, n):
+    """Fused call (no_grad) vs the torch-glue path (autograd on) of the same module, and both vs the oracle's restatement of
+    vq.py:39-96 (fp64 arbiter): the MFMA filter dims, the dim-4 search, a dim without a filter (6: exhaustive kernel), "blc"
+    (which the reference itself cannot run: its rearrange pattern is rejected by einops, vq.py:49)."""
+    from pit_hip.quantization.vq import VQQuantizer
+
+    g = torch.Generator().manual_seed(21 + dim)
+    c = dim * K
+    z = torch.randn(2, c, 16, 16, generator=g) if fmt == "bchw" else torch.randn(2, 256, c, generator=g)
+    vq = VQQuantizer(fmt, n, dim, codebook_num=K).to(DEV)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.randn(n, dim, generator=g))
+        zq, info = vq(z.to(DEV))
+    zq_a, info_a = vq(z.to(DEV).requires_grad_(True))
+    ozq, oind, oloss, gap = O.vq_forward_eval(z.numpy(), vq.embedding.weight.detach().cpu().numpy(), K, fmt, vq.beta, True)
+    assert np.array_equal(info["indices"].cpu().numpy(), oind), f"min gap {gap.min():.2e}"
+    assert torch.equal(info["indices"], info_a["indices"])
+    assert np.array_equal(zq.cpu().numpy(), ozq) and torch.equal(zq, zq_a.detach())
+    assert _close(info["codebook_loss"], oloss, 2e-6) and _close(info_a["codebook_loss"], oloss, 2e-6)
+    assert zq_a.requires_grad and not zq.requires_grad
+
+
+def test_vq_fused_forward_is_bit_reproducible_and_graph_capturable():
+    """The loss is summed in a fixed order (ticketed partials): five runs, one value; the whole forward replays from a HIP graph."""
+    from pit_hip.quantization.vq import VQQuantizer
+
+    g = torch.Generator().manual_seed(33)
+    z = torch.randn(4, 16, 64, 64, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    vq = VQQuantizer("bchw", 65536, 16).eval().to(DEV)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.randn(65536, 16, generator=g))
+        zq0, i0 = vq(z)
+        for _ in range(4):
+            zq, i = vq(z)
+            assert torch.equal(i["codebook_loss"], i0["codebook_loss"]) and torch.equal(zq, zq0) and torch.equal(i["indices"], i0["indices"])
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            vq(z)
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            zq_g, i_g = vq(z)
+        z.mul_(-1.0)
+        gr.replay()
+        zq1, i1 = vq(z)
+    assert torch.equal(zq_g, zq1) and torch.equal(i_g["indices"], i1["indices"]) and torch.equal(i_g["codebook_loss"], i1["codebook_loss"])
+    assert not torch.equal(i1["indices"], i0["indices"])

@@ -38,7 +38,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(dll, name), f"libgqhip.so does not export {name}"
     assert declared == set(L.EXPORTED_SYMBOLS), "python binding and header disagree"
-    assert L.lib().gqhip_abi_version() == L.ABI_VERSION == 7
+    assert L.lib().gqhip_abi_version() == L.ABI_VERSION == 8
     assert L.lib().gqhip_status_string(2) == b"workspace missing or too small"
 
 

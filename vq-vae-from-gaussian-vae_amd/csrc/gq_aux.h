@@ -307,4 +307,134 @@ __global__ __launch_bounds__(256) void step_record_kernel(const StepRecordParams
   p.ticket[b] = 0;                             // ready for the next call on this workspace
 }
 
+// ---- GQ2's Gaussian branch in eval (pit/quantization/gaussian.py:211-271): statistics of the per-row KL bits + the lambda state ----
+// The first launch of the fused call (gq_prep.h) leaves kl2row [rows]; this ONE block reduces it in a fixed order (thread t takes
+// rows t, t + 1024, ...; then a tree in LDS: bit-reproducible) to mean / min / max and the re-weighted loss, and advances the
+// adaptive lambda state exactly as the reference's Python does -- in fp64, on the device, so the forward needs no host read at all
+// (the reference pays three bool(tensor) syncs per forward, gaussian.py:243-253).
+//   scalars (64 B, 8-byte aligned): float[0..3] = { kl_loss, bits-mean, bits-min, bits-max };
+//                                   double at byte 32: { lam, lam_min, lam_max } AFTER the update (what info["lam"...] reports).
+struct GaussStatsParams {
+  const float *kl2row;
+  long rows;
+  double *lam_state;        // [3] in / out: lam, lam_min, lam_max
+  void *scalars;
+  float thr_hi, thr_lo, log2n;      // float(n + tol), float(n - tol), float(n): torch compares the fp32 tensor with the scalar cast to fp32
+  double lam_factor, lam_lo, lam_hi;
+  int lam_max_decreases;    // 1: gaussian.py:109-112 (GQ1); 0: GQ2, whose decrease is a no-op expression (gaussian.py:251)
+};
+
+__global__ __launch_bounds__(1024) void gauss_stats_finalize_kernel(const GaussStatsParams p) {
+#pragma clang fp contract(off)
+  const int tid = threadIdx.x;
+  const double lam = p.lam_state[0], lam_min = p.lam_state[1], lam_max = p.lam_state[2];
+  const float w_ge = (float)lam_max, w_le = (float)lam_min;
+  double sum = 0.0, wsum = 0.0;
+  float mn = __builtin_inff(), mx = -__builtin_inff();
+  bool nan = false;
+  for (long r = tid; r < p.rows; r += 1024) {
+    const float k = p.kl2row[r];
+    nan = nan || (k != k);
+    sum += (double)k;
+    mn = __builtin_fminf(mn, k);
+    mx = __builtin_fmaxf(mx, k);
+    // ge * kl2 + eq * kl2 + le * kl2 with the reference's fp32 products (gaussian.py:233-240)
+    const float ge = (k > p.thr_hi ? 1.0f : 0.0f) * w_ge;
+    const float eq = (k <= p.thr_hi ? 1.0f : 0.0f) * (k >= p.thr_lo ? 1.0f : 0.0f);
+    const float le = (k < p.thr_lo ? 1.0f : 0.0f) * w_le;
+    float e = ge * k;
+    e = e + eq * k;
+    e = e + le * k;
+    wsum += (double)e;
+  }
+  __shared__ double s_a[1024], s_b[1024];
+  __shared__ float s_mn[1024], s_mx[1024];
+  __shared__ int s_nan[1024];
+  s_a[tid] = sum; s_b[tid] = wsum; s_mn[tid] = mn; s_mx[tid] = mx; s_nan[tid] = nan ? 1 : 0;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) {
+      s_a[tid] += s_a[tid + o];
+      s_b[tid] += s_b[tid + o];
+      s_mn[tid] = __builtin_fminf(s_mn[tid], s_mn[tid + o]);
+      s_mx[tid] = __builtin_fmaxf(s_mx[tid], s_mx[tid + o]);
+      s_nan[tid] |= s_nan[tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  const float qnan = __builtin_nanf("");
+  const float mean = (float)(s_a[0] / (double)p.rows);
+  const float kmin = s_nan[0] ? qnan : s_mn[0], kmax = s_nan[0] ? qnan : s_mx[0];      // torch.min / max propagate NaN
+  const float wmean = (float)(s_b[0] / (double)p.rows);
+  const float kl_loss = wmean * (float)lam;                                             // torch.mean(kl_loss) * self.lam
+  double l = lam, lmin = lam_min, lmax = lam_max;
+  const double f = p.lam_factor;
+  l = mean > p.log2n ? l * f : l / f;
+  if (kmax > p.thr_hi) lmax = lmax * f;
+  else if (p.lam_max_decreases) lmax = lmax / f;
+  lmax = lmax < p.lam_hi ? lmax : p.lam_hi;       // max(min(lam_max, hi), 1.0)
+  lmax = lmax > 1.0 ? lmax : 1.0;
+  lmin = kmin < p.thr_lo ? lmin / f : lmin * f;
+  lmin = lmin < 1.0 ? lmin : 1.0;                 // max(min(lam_min, 1.0), lo)
+  lmin = lmin > p.lam_lo ? lmin : p.lam_lo;
+  float *fo = static_cast<float *>(p.scalars);
+  fo[0] = kl_loss; fo[1] = mean; fo[2] = kmin; fo[3] = kmax;
+  double *d = reinterpret_cast<double *>(static_cast<char *>(p.scalars) + 32);
+  d[0] = l; d[1] = lmin; d[2] = lmax;
+  p.lam_state[0] = l; p.lam_state[1] = lmin; p.lam_state[2] = lmax;
+}
+
+// ---- VQ's codebook loss in eval (pit/quantization/vq.py:78-86): mean((z_q - z)^2) over every element --------------------------
+// After the arg-min has left its indices: element (row, g) contributes (emb[idx[row]][g] - z[row][g])^2 formed in fp32 like the
+// reference, summed in fp64 -- per thread in a fixed assignment, per block by a fixed tree, and the LAST block (a ticket in the
+// workspace header, reset by the call's first launch) adds the block sums in block order: bit-reproducible.
+//   loss[0] = mean + beta * mean (legacy) | beta * mean + mean, in fp32 like the reference;  loss[1] = mean.
+struct VqLossParams {
+  const float *zrows;       // [rows, dim] the row operands gq_prep_kernel left in the workspace
+  const int64_t *idx;       // module layout
+  const float *emb;         // [n, dim]
+  float *loss;              // [2]
+  WsHeader *hdr;
+  long rows;
+  int dim, n;
+  float beta;
+  int legacy;
+  OutMap omap;
+};
+
+__global__ __launch_bounds__(256) void vq_loss_kernel(const VqLossParams p) {
+#pragma clang fp contract(off)
+  const int tid = threadIdx.x;
+  const long total = p.rows * p.dim;
+  double acc = 0.0;
+  for (long t = (long)blockIdx.x * 256 + tid; t < total; t += (long)gridDim.x * 256) {
+    const long row = t / p.dim;
+    const int g = (int)(t % p.dim);
+    const long j = p.idx[out_idx_offset(p.omap, row)];
+    const float e = (j >= 0 && j < p.n) ? p.emb[j * p.dim + g] : __builtin_nanf("");
+    const float d = e - p.zrows[t];
+    acc += (double)(d * d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ double sh[4];
+  __shared__ int sh_last;
+  if ((tid & 63) == 0) sh[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    p.hdr->loss_part[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __threadfence();
+    sh_last = atomicAdd(&p.hdr->loss_ticket, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!sh_last || tid != 0) return;
+  __threadfence();
+  double sum = 0.0;
+  for (int k = 0; k < (int)gridDim.x; ++k) sum += __hip_atomic_load(&p.hdr->loss_part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float m = (float)(sum / (double)total);
+  p.loss[0] = p.legacy ? m + p.beta * m : p.beta * m + m;
+  p.loss[1] = m;
+}
+
 }  // namespace gqhip

@@ -73,7 +73,8 @@ struct WsHeader {
   unsigned long long reranked;        // half-pairs (32 codes each) evaluated exactly (grid search: codes given the reference's arithmetic)
   unsigned long long grid_leaves;     // grid search (gq_grid.h), debug statistics: leaves visited, summed over the rows
   int grid_next;                      // grid search: the next group of four rows a wave fetches
-  int pad1[25];
+  int loss_ticket;                    // vq_loss_kernel (gq_aux.h): blocks that have left their partial sum (reset by the first launch)
+  int pad1[24];
   float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
   int pad2[128];
@@ -81,7 +82,7 @@ struct WsHeader {
   int pad3[256];
   unsigned long long cbsum[kAbsmaxParts];   // content hash of the codebook slice each code block of gq_prep_kernel read in THIS call
                                             // (what the codebook cache is validated against and stamped with: gq_grid.h, gq_prep.h)
-  int pad4[512];
+  double loss_part[256];              // vq_loss_kernel: one partial sum of (e - z)^2 per block
 };
 static_assert(sizeof(WsHeader) == 8192, "header is 8 KiB");
 

@@ -439,7 +439,10 @@ __device__ __forceinline__ void grid_load_coef(const GridParams &p, long row, fl
 
 __device__ __forceinline__ void grid_write_result(const GridParams &p, long row, int best, int who, int dim) {
   if (who == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best;
-  if (p.zhat && who < dim) p.zhat[out_zhat_offset(p.omap, row, who, dim)] = p.cb[(long)best * dim + who];
+  if (p.zhat && who < dim) {
+    const long o = out_zhat_offset(p.omap, row, who, dim);
+    p.zhat[o] = ste_mix(p.omap, o, p.cb[(long)best * dim + who]);
+  }
 }
 
 template <int MODE, int DIM>
@@ -950,7 +953,10 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       // the winner's original id and its code row come from the SORTED tables at the same position: two independent loads, one round
       // trip (through cb[sidx[j]] it was two; the sorted row is a bit copy of the caller's, and the cache was validated by this call)
       if (sub == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)sidx[best_j];
-      if (p.zhat && sub < DIM) p.zhat[out_zhat_offset(p.omap, row, sub, DIM)] = scb[(long)best_j * DIM + sub];
+      if (p.zhat && sub < DIM) {
+        const long o = out_zhat_offset(p.omap, row, sub, DIM);
+        p.zhat[o] = ste_mix(p.omap, o, scb[(long)best_j * DIM + sub]);
+      }
     }
     if (p.stats && live) {
       int e = exact_n;

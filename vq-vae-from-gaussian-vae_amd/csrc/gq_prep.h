@@ -29,6 +29,8 @@ struct PrepParams {
   const float *z;            // [B, 2c, L] (BCHW) or [B, L, 2c] (BLC)
   const float *noise;        // module layout of zhat_noquant, or NULL
   float *zhat_noquant;       // [B, c, L] / [B, L, c], or NULL
+  float *sd_layout;          // FROM_Z, optional: sd in the layout of zhat (GQ2's info["std"], gaussian.py:263-264)
+  float *kl2row;             // FROM_Z, optional: [rows] KL divergence of the row's Gaussian to N(0, 1) in bits (gaussian.py:225-229)
   float lv_min, lv_max;
   // rows: outputs when FROM_Z, inputs otherwise (lsd may then be NULL: lsd_out receives float(log(double(sd))))
   float *mu, *sd, *lsd;      // [rows, dim]
@@ -76,6 +78,18 @@ __device__ __forceinline__ float mixed_row_scale(const float *coef, int n) {
 // fp64 -> fp32, never below the argument (bound inputs are rounded up)
 __device__ __forceinline__ float f32_up(double v) { return (float)(v * 1.0000002384185791); }   // (1 + 2^-22): covers the RNE error
 
+// one element of kl2 = 1.4426 * 0.5 * (mu^2 + var - 1 - logvar) in the reference's fp32 op order (gaussian.py:225), lv already
+// clamped; var = float(exp(double(lv))); 1.4426 * 0.5 is formed in Python first (a double), then cast to the tensor's dtype
+__device__ __forceinline__ float kl_bits_term(float m, float lv) {
+#pragma clang fp contract(off)
+  const float var = (float)exp((double)lv);
+  float t = m * m;
+  t = t + var;
+  t = t - 1.0f;
+  t = t - lv;
+  return (float)0.7213 * t;
+}
+
 // FK (filter kind): 0 = the split-bf16 images; 1 = MIXED (DIM 16, GQ only): the operand images of the fp16 + fp8 filter;
 // 2 = F16: the fp16 images of the main-product-only filter (gq_filter_bf16.h), every MFMA dim, GQ and VQ.
 template <int MODE, int DIM, bool FROM_Z, int FK = 0>
@@ -94,6 +108,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     p.hdr->reranked = 0ull;
     p.hdr->grid_leaves = 0ull;
     p.hdr->grid_next = 0;
+    p.hdr->loss_ticket = 0;
   }
 
 #if defined(GQHIP_ABL) && (GQHIP_ABL & 1024)   // diagnostic build (tools/abl_prep.sh): the code blocks do nothing
@@ -284,7 +299,8 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   // -------------------------------------------------------------------- rows
   __shared__ __attribute__((aligned(16))) float s_mu[256], s_sd[256], s_lsd[256];
   __shared__ __attribute__((aligned(16))) unsigned short s_hi[RB][2 * DIM], s_lo[RB][2 * DIM];
-  __shared__ double s_sum[256][F16 ? 9 : 4];     // per-element terms of the row sums (F16: + the five sums of the data-dependent bound)
+  constexpr int KLC = F16 ? 9 : 4;               // column of the KL term
+  __shared__ double s_sum[256][KLC + 1];         // per-element terms of the row sums (F16: + the five sums of the data-dependent bound; last: KL bits)
   __shared__ float s_scale[RB];                  // MIXED / F16: the row's power-of-two normalisation (NaN: none usable)
   __shared__ __attribute__((aligned(16))) float s_coef[RB][2 * DIM];
   const long row0 = (long)blockIdx.x * RB;
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   const long row = row0 + lr;
   const bool live = row < p.rows;
   float m = 0.0f, s = 1.0f, ls = 0.0f;
+  double klt = 0.0;
   if (live) {
     if constexpr (FROM_Z) {
       // row = pos * K + k; channel of (k, g): strided g*K + k (GQ1), contiguous k*dim + g (GQ2)
@@ -312,6 +329,10 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
         zo_lv = zo_mu + om.c;
         oo = pos * om.c + ch;
       }
+      if constexpr (MODE == kModeVQ) {
+        // VQ (pit/quantization/vq.py:39-53): z holds c channels, no logvar half -- the row operand is z itself
+        m = p.z[oo];
+      } else {
       m = p.z[zo_mu];
       float lv = p.z[zo_lv];
       // torch.clamp propagates NaN; min/max with explicit compares keeps that.
@@ -329,6 +350,13 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
 #pragma clang fp contract(off)
         const float e = p.noise[oo] * s;
         p.zhat_noquant[oo] = m + e;
+      }
+      if (p.sd_layout) p.sd_layout[oo] = s;
+      if (p.kl2row) {
+        // one element of kl2 = 1.4426 * 0.5 * (mu^2 + var - 1 - logvar) in the reference's fp32 op order (gaussian.py:225), var =
+        // float(exp(double(logvar)))
+        klt = (double)kl_bits_term(m, lv);
+      }
       }
     } else {
       m = p.mu[row * DIM + g];
@@ -373,6 +401,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   s_sum[lr * DIM + g][1] = t1;
   s_sum[lr * DIM + g][2] = t2;
   s_sum[lr * DIM + g][3] = t3;
+  s_sum[lr * DIM + g][KLC] = klt;
   if constexpr (F16) {
     // This element's terms of the data-dependent bound (gq_rerank.h:f16_bound), from the fp32 coefficients the filter multiplies.
     // A coordinate is a "well" when A < 0 and the vertex mu' = B / (2 |A|) of its parabola lies within |mu'| <= 6 (any
@@ -420,6 +449,14 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
       if (sc != sc) acc = __builtin_nan("");     // no usable normalisation: the row's bound is NaN -> undecided
     }
     p.rowsum[(row0 + r) * 4 + q] = acc;
+  }
+  if constexpr (FROM_Z) {
+    if (p.kl2row && tid < RB && row0 + tid < p.rows) {     // the row's KL bits: ascending dim order in fp64, rounded once
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) acc += s_sum[tid * DIM + i][KLC];
+      p.kl2row[row0 + tid] = (float)acc;
+    }
   }
   if constexpr (F16) {
     // The sums of the data-dependent bound, ascending dim order (deterministic), each rounded UP to fp32: thread (row, q) adds the
@@ -521,12 +558,15 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
 struct PrepPlainParams {
   const float *z, *noise;
   float *zhat_noquant;
+  float *sd_layout, *kl2row;   // optional (see PrepParams)
   float *mu, *sd, *lsd;   // [rows, dim]
   long rows;
   int dim;
+  int vq;                 // z holds c channels and no logvar half (pit/quantization/vq.py:39-53)
   float lv_min, lv_max;
   OutMap omap;
 };
+
 
 __global__ __launch_bounds__(256) void prep_plain_kernel(const PrepPlainParams p) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -552,13 +592,18 @@ __global__ __launch_bounds__(256) void prep_plain_kernel(const PrepPlainParams p
   long zo, oo;
   if (om.mode == 1) { zo = (b * 2 * om.c + ch) * om.L + l; oo = (b * om.c + ch) * om.L + l; }
   else { zo = pos * 2 * om.c + ch; oo = pos * om.c + ch; }
+  const long o = row * p.dim + g;
+  if (p.vq) {
+    p.mu[o] = p.z[oo];
+    return;
+  }
+  const long lv_off = om.mode == 1 ? (long)om.c * om.L : (long)om.c;
   const float m = p.z[zo];
-  float lv = p.z[zo + (om.mode == 1 ? (long)om.c * om.L : (long)om.c)];
+  float lv = p.z[zo + lv_off];
   lv = lv < p.lv_min ? p.lv_min : lv;
   lv = lv > p.lv_max ? p.lv_max : lv;
   const float half = 0.5f * lv;
   const float s = (float)exp((double)half);
-  const long o = row * p.dim + g;
   p.mu[o] = m;
   p.sd[o] = s;
   p.lsd[o] = (float)log((double)s);
@@ -566,6 +611,19 @@ __global__ __launch_bounds__(256) void prep_plain_kernel(const PrepPlainParams p
 #pragma clang fp contract(off)
     const float e = p.noise[oo] * s;
     p.zhat_noquant[oo] = m + e;
+  }
+  if (p.sd_layout) p.sd_layout[oo] = s;
+  if (p.kl2row && g == 0) {      // this (cold) path: the row's first element walks the row (ascending dim order, fp64 sum, rounded once)
+    double acc = 0.0;
+    for (int i = 0; i < p.dim; ++i) {
+      const long chi = om.grouping == 0 ? (long)i * om.K + k : (long)k * p.dim + i;
+      const long zi = om.mode == 1 ? (b * 2 * om.c + chi) * om.L + l : pos * 2 * om.c + chi;
+      float lvi = p.z[zi + lv_off];
+      lvi = lvi < p.lv_min ? p.lv_min : lvi;
+      lvi = lvi > p.lv_max ? p.lv_max : lvi;
+      acc += (double)kl_bits_term(p.z[zi], lvi);
+    }
+    p.kl2row[row] = (float)acc;
   }
 }
 

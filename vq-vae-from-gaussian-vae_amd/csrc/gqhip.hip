@@ -181,7 +181,7 @@ int64_t image_cache_bytes(int64_t n, int64_t dim) {
 }
 
 struct WsLayout {
-  int64_t hdr, rec, fb, dbg, mu, sd, lsd, rowsum, coef, cbimg, rowimg, rowscale, rowaux, total;
+  int64_t hdr, rec, fb, dbg, mu, sd, lsd, rowsum, coef, cbimg, rowimg, rowscale, rowaux, kl2, total;
 };
 
 WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
@@ -203,6 +203,7 @@ WsLayout ws_layout(int64_t rows, int64_t n, int64_t dim) {
   w.rowimg = off; off += pl.bf16 ? align256(rows * nvec * 2 * 16) : 0;
   w.rowscale = off; off += (pl.mixed || pl.f16) ? align256(4 * rows) : 0;
   w.rowaux = off; off += pl.f16 ? align256(32 * rows) : 0;
+  w.kl2 = off; off += align256(4 * rows);       // per-row KL bits of gq_quantize_z_gauss_f32
   w.total = off;
   return w;
 }
@@ -375,6 +376,8 @@ struct PrepInput {
   float *zhat_noquant = nullptr;
   float lv_min = 0.f, lv_max = 0.f;
   float *mu_out = nullptr, *sd_out = nullptr;   // FROM_Z: optional copies of the row operands for the caller
+  float *sd_layout = nullptr;                   // FROM_Z: optional sd in the layout of zhat
+  bool want_kl2 = false;                        // FROM_Z: leave the per-row KL bits in the workspace (ws_layout().kl2)
 };
 
 template <int MODE, bool FROM_Z>
@@ -458,6 +461,8 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
     if (from_z) {
       PrepPlainParams pq{};
       pq.z = in.z; pq.noise = in.noise; pq.zhat_noquant = in.zhat_noquant;
+      pq.sd_layout = in.sd_layout; pq.kl2row = in.want_kl2 ? reinterpret_cast<float *>(ws + w.kl2) : nullptr;
+      pq.vq = MODE == kModeVQ ? 1 : 0;
       pq.mu = const_cast<float *>(r_mu); pq.sd = const_cast<float *>(r_sd); pq.lsd = ws_lsd;
       pq.rows = rows; pq.dim = (int)dim; pq.lv_min = in.lv_min; pq.lv_max = in.lv_max; pq.omap = omap;
       hipLaunchKernelGGL(prep_plain_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, st, pq);
@@ -473,6 +478,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   // ---- launch 1: rows (+ zhat_noquant), operand images, bound sums, max|cb| partials, header -------------------
   PrepParams pp{};
   pp.z = in.z; pp.noise = in.noise; pp.zhat_noquant = in.zhat_noquant; pp.lv_min = in.lv_min; pp.lv_max = in.lv_max;
+  pp.sd_layout = in.sd_layout; pp.kl2row = in.want_kl2 ? reinterpret_cast<float *>(ws + w.kl2) : nullptr;
   pp.mu = const_cast<float *>(r_mu); pp.sd = const_cast<float *>(r_sd);
   pp.lsd = const_cast<float *>(from_z ? ws_lsd : lsd);
   pp.lsd_out = (!from_z && MODE == kModeGQ && !lsd) ? ws_lsd : nullptr;
@@ -733,6 +739,74 @@ int gq_quantize_z_f32(const float *z, const float *noise_or_null, const float *c
   om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = grouping;
   return run_argmax<kModeGQ>(in, nullptr, nullptr, nullptr, cb, idx, zhat_or_null, dim, rows, n, beta, workspace,
                              workspace_bytes, cb_cache_or_null, cb_cache_bytes, om, static_cast<hipStream_t>(stream));
+}
+
+int gq_quantize_z_gauss_f32(const float *z, const float *noise, const float *cb, int64_t *idx, float *zhat,
+                            float *zhat_quant_or_null, float *zhat_noquant, float *sd_out_or_null, void *scalars_out, double *lam_state, int64_t B,
+                            int64_t L, int64_t c, int64_t dim, int64_t n, int layout, int grouping, double lv_min,
+                            double lv_max, double beta, int use_ste, double log2n, double tolerance, double lam_factor,
+                            double lam_lo, double lam_hi, int lam_max_decreases, void *workspace, int64_t workspace_bytes,
+                            void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream) {
+  if (!z || !noise || !cb || !idx || !zhat || !zhat_noquant || !scalars_out || !lam_state || B < 0 || L < 1 || c < 1 ||
+      dim < 1 || dim > kMaxDim || c % dim != 0)
+    return GQHIP_ERR_INVALID_ARG;
+  if ((layout != GQHIP_LAYOUT_BCHW && layout != GQHIP_LAYOUT_BLC) ||
+      (grouping != GQHIP_GROUP_STRIDED && grouping != GQHIP_GROUP_CONTIGUOUS))
+    return GQHIP_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(scalars_out) & 7u) || (reinterpret_cast<uintptr_t>(lam_state) & 7u)) return GQHIP_ERR_INVALID_ARG;
+  const int64_t K = c / dim, rows = B * L * K;
+  if (rows == 0) return GQHIP_OK;      // (the reference's means of an empty tensor are NaN; nothing is written here)
+  if (rows > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PrepInput in;
+  in.z = z; in.noise = noise; in.zhat_noquant = zhat_noquant;
+  in.lv_min = (float)lv_min; in.lv_max = (float)lv_max;
+  in.sd_layout = sd_out_or_null; in.want_kl2 = true;
+  OutMap om{};
+  om.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
+  om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = grouping;
+  if (use_ste) { om.ste_kind = 1; om.ste = zhat_noquant; om.pure = zhat_quant_or_null; }
+  int rc = run_argmax<kModeGQ>(in, nullptr, nullptr, nullptr, cb, idx, zhat, dim, rows, n, beta, workspace, workspace_bytes,
+                               cb_cache_or_null, cb_cache_bytes, om, st);
+  if (rc != GQHIP_OK) return rc;
+  GaussStatsParams gp{};
+  gp.kl2row = reinterpret_cast<const float *>(static_cast<char *>(workspace) + ws_layout(rows, n, dim).kl2);
+  gp.rows = (long)rows; gp.lam_state = lam_state; gp.scalars = scalars_out;
+  gp.thr_hi = (float)(log2n + tolerance); gp.thr_lo = (float)(log2n - tolerance); gp.log2n = (float)log2n;
+  gp.lam_factor = lam_factor; gp.lam_lo = lam_lo; gp.lam_hi = lam_hi; gp.lam_max_decreases = lam_max_decreases;
+  hipLaunchKernelGGL(gauss_stats_finalize_kernel, dim3(1), dim3(1024), 0, st, gp);
+  return check_launch();
+}
+
+int vq_quantize_z_f32(const float *z, const float *emb, int64_t *idx, float *zq, float *loss2_or_null, int64_t B, int64_t L,
+                      int64_t c, int64_t dim, int64_t n, int layout, double beta, int legacy, void *workspace,
+                      int64_t workspace_bytes, void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream) {
+  if (!z || !emb || !idx || !zq || B < 0 || L < 1 || c < 1 || dim < 1 || dim > kMaxDim || c % dim != 0)
+    return GQHIP_ERR_INVALID_ARG;
+  if (layout != GQHIP_LAYOUT_BCHW && layout != GQHIP_LAYOUT_BLC) return GQHIP_ERR_INVALID_ARG;
+  const int64_t K = c / dim, rows = B * L * K;
+  if (rows == 0) return GQHIP_OK;
+  if (rows > 0x3fffffff) return GQHIP_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PrepInput in;
+  in.z = z;
+  OutMap om{};
+  om.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
+  om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = GQHIP_GROUP_STRIDED;     // channel = d * K + k (vq.py:53)
+  om.ste_kind = 2; om.ste = z;                                                        // z_q = z + (z_q - z) (vq.py:89)
+  int rc = run_argmax<kModeVQ>(in, nullptr, nullptr, nullptr, emb, idx, zq, dim, rows, n, 0.0, workspace, workspace_bytes,
+                               cb_cache_or_null, cb_cache_bytes, om, st);
+  if (rc != GQHIP_OK || !loss2_or_null) return rc;
+  const WsLayout w = ws_layout(rows, n, dim);
+  VqLossParams lp{};
+  lp.zrows = reinterpret_cast<const float *>(static_cast<char *>(workspace) + w.mu);
+  lp.idx = idx; lp.emb = emb; lp.loss = loss2_or_null;
+  lp.hdr = reinterpret_cast<WsHeader *>(static_cast<char *>(workspace) + w.hdr);
+  lp.rows = (long)rows; lp.dim = (int)dim; lp.n = (int)n; lp.beta = (float)beta; lp.legacy = legacy; lp.omap = om;
+  int64_t blocks = (rows * dim + 256 * 16 - 1) / (256 * 16);
+  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+  hipLaunchKernelGGL(vq_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, lp);
+  return check_launch();
 }
 
 int gq_dequant_f32(const int64_t *idx, const float *cb, float *zhat, int64_t B, int64_t L, int64_t K,

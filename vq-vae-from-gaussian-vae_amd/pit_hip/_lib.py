@@ -19,7 +19,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
 LIB_PATH = os.environ.get("GQHIP_LIB", os.path.join(_CSRC, "libgqhip.so"))  # GQHIP_LIB: diagnostic builds
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 GNSTAT_WORDS = 8     # int64 words per (image, group) statistics record (gqhip.h: gqhip_gnstat_t)
 GQHIP_LAYOUT = {"bchw": 0, "blc": 1}
 GQHIP_GROUP_STRIDED = 0
@@ -46,6 +46,12 @@ _SIGNATURES = {
     "gq_quantize_z_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                          ctypes.c_double, _vp, _i64, _vp, _i64, _vp]),
+    "gq_quantize_z_gauss_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                               ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                               ctypes.c_double, ctypes.c_int, _vp, _i64, _vp, _i64, _vp]),
+    "vq_quantize_z_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_double,
+                                         ctypes.c_int, _vp, _i64, _vp, _i64, _vp]),
     "gq_dequant_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
                                       ctypes.c_int, _vp]),
     "vq_argmin_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
@@ -291,6 +297,78 @@ def gq_quantize_z(z, cb, dim: int, layout: str, grouping: int, lv_range=(-30.0, 
     if noise is not None:
         out = out + (noquant,)
     return out
+
+
+def gq_quantize_z_gauss(z, cb, dim: int, layout: str, grouping: int, noise, lam_state, log2n: int, tolerance: float,
+                        lam_factor: float, lam_range, lam_max_decreases: bool, use_ste: bool = True, lv_range=(-30.0, 20.0),
+                        beta: float = 1.0, ws: Optional[Workspace] = None, want_std: bool = True):
+    """GaussianQuantRegularizer2's eval forward in one call (gqhip.h: gq_quantize_z_gauss_f32).  ``lam_state``: float64 [3] device
+    tensor {lam, lam_min, lam_max}, advanced in place.  Returns (idx, zhat, zhat_noquant, std or None, scalars) with ``scalars`` a
+    fresh 64-byte device buffer: float32 view [0:4] = kl_loss, bits-mean, bits-min, bits-max; float64 view of bytes 32..56 = the
+    lambdas after the update."""
+    z, cb, noise = _dev(z, torch.float32, "z"), _dev(cb, torch.float32, "codebook"), _dev(noise, torch.float32, "noise")
+    if not (lam_state.is_cuda and lam_state.dtype == torch.float64 and lam_state.numel() == 3 and lam_state.is_contiguous()):
+        raise GqHipError("lam_state must be a contiguous float64 [3] tensor on the HIP device")
+    n = cb.shape[0]
+    if layout == "bchw":
+        B, c2, L = z.shape[0], z.shape[1], int(z[0, 0].numel())
+        tail = tuple(z.shape[2:])
+    else:
+        B, L, c2 = z.shape
+    c = c2 // 2
+    K = c // dim
+    rows = B * L * K
+    ws = ws or Workspace()
+    dev = z.device
+    if layout == "bchw":
+        idx = torch.empty((B, K) + tail, dtype=torch.int64, device=dev)
+        zhat = torch.empty((B, c) + tail, dtype=torch.float32, device=dev)
+    else:
+        idx = torch.empty((B, L, K), dtype=torch.int64, device=dev)
+        zhat = torch.empty((B, L, c), dtype=torch.float32, device=dev)
+    if tuple(noise.shape) != tuple(zhat.shape):
+        raise GqHipError(f"noise must have the shape of zhat {tuple(zhat.shape)}, got {tuple(noise.shape)}")
+    noquant = torch.empty_like(zhat)
+    pure = torch.empty_like(zhat) if use_ste else None
+    std = torch.empty_like(zhat) if want_std else None
+    scalars = torch.empty(64, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        wptr, wbytes = ws.get(max(rows, 1), n, dim, dev)
+        cptr, cbytes = ws.cache(n, dim, dev)
+        _check(lib().gq_quantize_z_gauss_f32(z.data_ptr(), noise.data_ptr(), cb.data_ptr(), idx.data_ptr(), zhat.data_ptr(),
+                                             _ptr(pure), noquant.data_ptr(), _ptr(std), scalars.data_ptr(), lam_state.data_ptr(), B, L, c, dim,
+                                             n, GQHIP_LAYOUT[layout], grouping, float(lv_range[0]), float(lv_range[1]),
+                                             float(beta), 1 if use_ste else 0, float(log2n), float(tolerance), float(lam_factor),
+                                             float(lam_range[0]), float(lam_range[1]), 1 if lam_max_decreases else 0,
+                                             wptr, wbytes, cptr, cbytes, _stream()), "gq_quantize_z_gauss_f32")
+    return idx, zhat, (pure if use_ste else zhat), noquant, std, scalars
+
+
+def vq_quantize_z(z, emb, dim: int, layout: str, beta: float, legacy: bool, ws: Optional[Workspace] = None):
+    """VQQuantizer's eval forward in one call (gqhip.h: vq_quantize_z_f32): z [B, c, ...] ("bchw") or [B, L, c] ("blc") ->
+    (idx [B, K, ...] / [B, L, K], z_q in the layout of z, loss float32 [2] = {codebook_loss, mean((e - z)^2)})."""
+    z, emb = _dev(z, torch.float32, "z"), _dev(emb, torch.float32, "embedding")
+    n = emb.shape[0]
+    if layout == "bchw":
+        B, c, L = z.shape[0], z.shape[1], int(z[0, 0].numel())
+    else:
+        B, L, c = z.shape
+    if c % dim or emb.shape[1] != dim:
+        raise GqHipError("shape mismatch in vq_quantize_z")
+    K = c // dim
+    rows = B * L * K
+    ws = ws or Workspace()
+    dev = z.device
+    idx = torch.empty(((B, K) + tuple(z.shape[2:])) if layout == "bchw" else (B, L, K), dtype=torch.int64, device=dev)
+    zq = torch.empty_like(z)
+    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        wptr, wbytes = ws.get(max(rows, 1), n, dim, dev)
+        cptr, cbytes = ws.cache(n, dim, dev)
+        _check(lib().vq_quantize_z_f32(z.data_ptr(), emb.data_ptr(), idx.data_ptr(), zq.data_ptr(), loss.data_ptr(), B, L, c, dim,
+                                       n, GQHIP_LAYOUT[layout], float(beta), 1 if legacy else 0, wptr, wbytes, cptr, cbytes,
+                                       _stream()), "vq_quantize_z_f32")
+    return idx, zq, loss
 
 
 def gq_dequant(idx, cb, dim: int, layout: str, grouping: int):

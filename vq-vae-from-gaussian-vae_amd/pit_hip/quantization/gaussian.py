@@ -65,7 +65,12 @@ class _GaussianQuantBase(nn.Module):
         self.log_n_samples = int(math.log(n_samples, 2))
         self.logvar_range = logvar_range
         self.lam_factor, self.tolerance = lam_factor, tolerance
-        self.lam = self.lam_min = self.lam_max = 1.0
+        # lam / lam_min / lam_max (gaussian.py:41-43): Python floats in the reference.  Here properties over a host copy AND a
+        # float64 [3] device copy: the fused eval forward of GaussianQuantRegularizer2 advances the device copy inside its launches
+        # (no host read per forward); reading an attribute pulls the device copy once, writing one makes the host copy authoritative.
+        self._lam_host = [1.0, 1.0, 1.0]
+        self._lam_dev = None          # float64 [3] on the module's device, or None
+        self._lam_dev_newer = False   # the device copy has advanced past the host copy
         self.lam_range = lam_range
         self.beta, self.seed = beta, seed
         self.register_buffer("prior_samples", prior_samples(n_samples, dim, seed).float(), persistent=False)
@@ -76,7 +81,34 @@ class _GaussianQuantBase(nn.Module):
         if backend not in ("hip", "cuda", "cuda-compat", "torch"):
             raise ValueError(f"unknown backend {backend!r}")
         self.backend = backend
-        self._ws = _lib.Workspace()   # scratch only: every call rebuilds what it derives from the codebook
+        self._ws = _lib.Workspace()   # scratch + the codebook cache (validated by the library against the codebook's content hash on every call)
+
+    # ---- the adaptive lambda state --------------------------------------------------------------------------------------
+    def _lam_pull(self) -> None:
+        if self._lam_dev_newer:
+            self._lam_host = [float(v) for v in self._lam_dev.cpu().tolist()]     # the one host read, only when somebody looks
+            self._lam_dev_newer = False
+
+    def _lam_get(self, i: int) -> float:
+        self._lam_pull()
+        return self._lam_host[i]
+
+    def _lam_set(self, i: int, v) -> None:
+        self._lam_pull()
+        self._lam_host[i] = float(v)
+        self._lam_dev = None          # re-uploaded by the next fused forward
+
+    lam = property(lambda self: self._lam_get(0), lambda self, v: self._lam_set(0, v))
+    lam_min = property(lambda self: self._lam_get(1), lambda self, v: self._lam_set(1, v))
+    lam_max = property(lambda self: self._lam_get(2), lambda self, v: self._lam_set(2, v))
+
+    def _lam_state_on(self, device) -> torch.Tensor:
+        """The device copy of (lam, lam_min, lam_max), current; the caller's launch advances it in place."""
+        if self._lam_dev is None or self._lam_dev.device != device:
+            self._lam_pull()
+            self._lam_dev = torch.tensor(self._lam_host, dtype=torch.float64, device=device)
+        self._lam_dev_newer = True
+        return self._lam_dev
 
     def _compat(self) -> bool:
         """True when the caller asked for the score-matrix call sequence instead of the fused kernels."""
@@ -251,7 +283,54 @@ class GaussianQuantRegularizer2(_GaussianQuantBase):
         indices = self._restore(indices, z_shape)
         return zhat, {"indices": indices, "zhat_quant": zhat}
 
+    def _fused_view(self, z):
+        """z as (tensor, layout, restore) for the module-level kernels without a copy where its memory allows: a contiguous z is
+        [outer, 2C, inner] = the "bchw" layout for any dim_idx; a channels_last 4-d z with dim_idx 1 is the "blc" layout."""
+        d = self.dim_idx % z.dim()
+        if z.is_contiguous():
+            outer = int(math.prod(z.shape[:d]))
+            inner = int(math.prod(z.shape[d + 1:]))
+            if inner == 1:
+                zv = z.reshape(1, outer, z.shape[d])
+                return zv, "blc", lambda t: t.reshape(*z.shape[:d], -1, *z.shape[d + 1:])
+            zv = z.reshape(outer, z.shape[d], inner)
+            return zv, "bchw", lambda t: t.reshape(*z.shape[:d], -1, *z.shape[d + 1:])
+        zl = torch.movedim(z, d, -1)
+        if not zl.is_contiguous():
+            zl = zl.contiguous()
+        lead = zl.shape[:-1]
+        zv = zl.reshape(1, -1, zl.shape[-1])
+        return zv, "blc", lambda t: torch.movedim(t.reshape(*lead, -1), -1, d)
+
+    def _forward_fused(self, z):
+        """Eval forward (gaussian.py:333-345) as ONE library call: quant_gaussian's sample, statistics, re-weighted loss and lambda
+        update, quant_vq's arg-max and gather, and the straight-through mix all happen in gq_quantize_z_gauss_f32's launches.  The
+        lambda state advances on the device: info["lam"], ["lam-min"], ["lam-max"] are 0-d float64 device tensors (float(...) gives
+        the reference's Python floats) and nothing is read back unless an attribute is inspected."""
+        z = z.float()
+        assert z.shape[self.dim_idx] % (self.dim * 2) == 0
+        zv, layout, restore = self._fused_view(z)
+        c = zv.shape[1 if layout == "bchw" else 2] // 2
+        shape_n = (zv.shape[0], c, zv.shape[2]) if layout == "bchw" else (zv.shape[0], zv.shape[1], c)
+        noise = torch.randn(shape_n, dtype=torch.float32, device=z.device)     # one draw of the size of mu (gaussian.py:222)
+        ind, zhat, zq, noq, std, sc = _lib.gq_quantize_z_gauss(
+            zv, self.prior_samples, self.dim, layout, _lib.GQHIP_GROUP_CONTIGUOUS, noise, self._lam_state_on(z.device),
+            self.log_n_samples, self.tolerance, self.lam_factor, self.lam_range, lam_max_decreases=False, use_ste=self.use_ste,
+            lv_range=self.logvar_range, beta=self.beta, ws=self._ws)
+        f32, f64 = sc[:16].view(torch.float32), sc[32:56].view(torch.float64)
+        zhat_o = restore(zhat)                    # with use_ste the kernels stored (zhat_g - zhat_g) + zhat_v here
+        d = self.dim_idx % z.dim()
+        info = {"kl_loss": f32[0], "bits-mean": f32[1], "bits-min": f32[2], "bits-max": f32[3],
+                "lam-min": f64[1], "lam-max": f64[2], "lam": f64[0],
+                "mu": z.narrow(d, 0, z.shape[d] // 2), "std": restore(std), "zhat_noquant": restore(noq),
+                "indices": restore(ind), "zhat_quant": restore(zq)}
+        if not self.use_ste and self.training:
+            return info["zhat_noquant"], info
+        return zhat_o, info
+
     def forward(self, z):
+        if z.is_cuda and not self._compat() and not (torch.is_grad_enabled() and z.requires_grad):
+            return self._forward_fused(z)
         zhat_g, info_g = self.quant_gaussian(z)
         with torch.no_grad():
             zhat_v, info_v = self.quant_vq(z)

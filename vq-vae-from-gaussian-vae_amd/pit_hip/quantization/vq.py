@@ -3,8 +3,11 @@
 Same constructor, same ``embedding.weight`` parameter (so checkpoints load), same
 ``forward -> (z_q, {"indices", "codebook_loss"})`` / ``dequant`` contracts.  The
 ``[rows, n]`` distance matrix of vq.py:58-69 is never built: the nearest code is
-found by the MFMA filter (``-|e|^2 + 2 z.e``) + an fp64 re-rank of its candidates
-(``vq_argmin_f32``)."""
+found by the MFMA filter (``-|e|^2 + 2 z.e``) + an fp64 re-rank of its candidates.
+Without autograd (eval under ``torch.no_grad()``) the whole forward -- permutes,
+per-sub-codebook slices, embedding lookup, straight-through value, the two MSE
+means -- is ONE library call (``vq_quantize_z_f32``); with autograd the arg-min
+runs in the library (``vq_argmin_f32``) and the differentiable glue in torch."""
 from __future__ import annotations
 
 import numpy as np
@@ -40,7 +43,30 @@ class VQQuantizer(nn.Module):
         b, h, w, c = t.shape
         return t.reshape(b, h * w, c).contiguous()
 
+    def _forward_fused(self, z):
+        """vq.py:39-96 as one call.  A channels_last z (what the NHWC conv stack hands over) is read, and z_q / indices are written,
+        in that memory layout: NHWC memory of [B, c, h, w] IS the "blc" layout."""
+        z = z.float()
+        w = self.embedding.weight.detach().float()
+        if self.format == "bchw":
+            b, c, h, wd = z.shape
+            assert self.dim * self.codebook_num == c
+            if not z.is_contiguous() and z.is_contiguous(memory_format=torch.channels_last):
+                zmem = z.permute(0, 2, 3, 1).reshape(b, h * wd, c)          # a view of the same memory
+                ind, zq, loss = _lib.vq_quantize_z(zmem, w, self.dim, "blc", self.beta, self.legacy, self._ws)
+                as_bchw = lambda t: t.view(b, h, wd, -1).permute(0, 3, 1, 2)
+                return as_bchw(zq), {"indices": as_bchw(ind), "codebook_loss": loss[0]}
+        else:
+            b, l, c = z.shape
+            h = int(np.sqrt(l))
+            assert h * h == l, "Input length must be a perfect square for blc format"
+            assert self.dim * self.codebook_num == c
+        ind, zq, loss = _lib.vq_quantize_z(z, w, self.dim, self.format, self.beta, self.legacy, self._ws)
+        return zq, {"indices": ind, "codebook_loss": loss[0]}
+
     def forward(self, z):
+        if z.is_cuda and not (torch.is_grad_enabled() and (z.requires_grad or self.embedding.weight.requires_grad)):
+            return self._forward_fused(z)
         z = self._to_bhwc(z)
         assert self.dim * self.codebook_num == z.shape[-1]
         zf = z.reshape(-1, self.dim, self.codebook_num)  # channel = d*K + k (vq.py:53)
