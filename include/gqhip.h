@@ -101,20 +101,26 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8);
  * Bytes of scratch gq_argmax_f32 / gq_quantize_z_f32 / vq_argmin_f32 need for
  * `rows` rows against `n` codes of width `dim`.  The caller allocates once
  * (device memory, 256-B aligned) and reuses it; contents are don't-care: every call
- * rebuilds what it needs (codebook image, max|cb|, counters) from its arguments, so
- * nothing derived from a codebook or from rows is ever reused across calls. */
+ * rebuilds what it keeps there (row operands, bound sums, candidate records, max|cb|,
+ * counters) from its arguments.  What is derived from the CODEBOOK and worth keeping
+ * across calls lives in the separate codebook cache below, which the library validates
+ * against the codebook's content on every call. */
 int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim);
 
 /* ---- codebook cache ---------------------------------------------------------
  * Bytes of PERSISTENT device memory (256-B aligned) in which the fused arg-max keeps what it derives from a codebook of `n` codes
- * of width `dim` across calls; 0 when this shape keeps nothing (then pass NULL / 0).  Today: dims 4 and 8 with 2^14 <= n <= 2^20
+ * of width `dim` across calls; 0 when this shape keeps nothing (then pass NULL / 0).  Today: dim 4 with 2^14 <= n <= 2^20
  * -- the codes sorted into 4096 sub-leaves under a tree of bounding boxes (16 -> 256 -> 1024 -> 4096), which lets dim 4 run a pruned
- * exact search (~8 sub-leaves of ~16 codes per row instead of all n codes; csrc/gq_grid.h) in place of filter + re-rank.
+ * exact search (~8 sub-leaves of ~16 codes per row instead of all n codes; csrc/gq_grid.h) in place of filter + re-rank --; dims
+ * 8 / 16 / 32: the fp16 operand image of the codebook that the MFMA filter reads (each 1/256 slice stamped with its content hash).
  * Contract: the caller owns the buffer, hands the SAME buffer to every call that uses the same codebook, and never writes it;
  * its initial contents are don't-care.  The library validates it on EVERY call -- the first launch hashes the codebook it is
  * given (it reads it anyway) and compares with the hashes the cache was stamped with -- and rebuilds it in-stream (one extra
  * one-block kernel that otherwise exits at once) when they differ: a codebook edited in place by any route, a different
- * codebook, a fresh or clobbered buffer all cost one rebuild and never a wrong index.  One cache serves one stream at a time.
+ * codebook, a fresh buffer or one overwritten as a whole all cost one rebuild and never a wrong index.  What the validation does NOT
+ * cover is a write into the BODY of a cache whose 4-KiB header (the stamps) is left intact -- the "never writes it" above is the
+ * caller's half of the contract; the dim-4 search still bounds every offset and index it reads from the body by the codebook size,
+ * so such a write can cost a wrong index but never an out-of-range access (csrc/gq_grid.h).  One cache serves one stream at a time.
  * Without a cache (NULL) every shape runs the filter + re-rank path.  (No reference counterpart: the reference recomputes
  * everything per call, pit/quantization/gaussian.py:136-150.) */
 int64_t gqhip_cb_cache_bytes(int64_t n, int64_t dim);
@@ -482,7 +488,7 @@ int gqhip_profile_collect(int *launches_host, double *total_ms_host);
 int gqhip_debug_enable(int on);
 int gqhip_debug_counters(const void *workspace, int64_t *fallback_rows_host,
                          int64_t *reranked_halftiles_host);
-/* Grid search (dims 4 / 8 with a codebook cache), last call on `workspace`, synchronous copy: out4 = { sub-leaves visited summed
+/* Grid search (dim 4 with a codebook cache), last call on `workspace`, synchronous copy: out4 = { sub-leaves visited summed
  * over the rows (counted only after gqhip_debug_enable(1); a sub-leaf is ~n / 4096 codes, a whole leaf counts four), codes that
  * received the reference's arithmetic (likewise; a row with ONE code within the margin needs none), rows handed to
  * gq_grid_finish_kernel, 1 if `cb_cache_or_null` holds a current index / 0 if not / -1 without a cache }. */

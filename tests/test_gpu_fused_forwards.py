@@ -19,7 +19,8 @@ REF_INFO_KEYS = {"kl_loss", "bits-mean", "bits-min", "bits-max", "lam-min", "lam
 
 
 def _close(a, b, rel=2e-5):
-    return abs(float(a) - float(b)) <= rel * max(1.0, abs(float(b)))
+    a, b = (float(v.detach()) if isinstance(v, torch.Tensor) else float(v) for v in (a, b))
+    return abs(a - b) <= rel * max(1.0, abs(b))
 
 
 # ------------------------------------------------------------------------------------------ GQ2
@@ -148,7 +149,7 @@ def test_g20_vq_eval_forward_vs_reference_golden(tag, n, dim, K, legacy, channel
     assert np.array_equal(ind, d[f"{tag}_indices"])                        # (no near-tie rows in these fixtures)
     assert np.array_equal(zq.cpu().numpy(), d[f"{tag}_zq"])                # z + (e - z), bit for bit
     assert _close(info["codebook_loss"], d[f"{tag}_loss"], 2e-6) and info["codebook_loss"].dim() == 0
-    assert np.array_equal(vq.dequant(info["indices"]).cpu().numpy(), O.vq_dequant(ind, d[f"{tag}_emb"], K))
+    assert np.array_equal(vq.dequant(info["indices"]).detach().cpu().numpy(), O.vq_dequant(ind, d[f"{tag}_emb"], K))
 
 
 @pytest.mark.parametrize("fmt,K,dim,n", [("bchw", 1, 16, 65536), ("blc", 2, 8, 4096), ("bchw", 4, 4, 65536), ("bchw", 1, 6, 512)])

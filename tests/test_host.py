@@ -436,3 +436,16 @@ def test_fp16_fp8_filter_representation_error_is_inside_the_charged_bound():
         err = worst_error(A, B, cb)
         print(f"fp16 + fp8 representation error, {name}: {err:.0f} u T")
         assert err < 2450 - 256, (name, err)
+
+
+def test_gq_cuda_package_has_the_reference_layout():
+    """gq_cuda_extension/gq_cuda/__init__.py:3 does `from . import _C, ops`: both names import here too, and the op is registered
+    with the reference's schema (csrc/gq_cuda.cpp:29-31)."""
+    import importlib
+
+    import torch
+
+    gq_cuda = importlib.import_module("gq_cuda")
+    assert importlib.import_module("gq_cuda._C") is gq_cuda._C and gq_cuda.ops is importlib.import_module("gq_cuda.ops")
+    schema = str(torch.ops.extension_cpp.gq.default._schema)
+    assert "Tensor a, Tensor b, Tensor c, Tensor(a!) out, int d, int e, int f, float g" in schema

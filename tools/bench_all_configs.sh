@@ -9,7 +9,7 @@ run() { name=$1; shift; python bench.py "$@" 2>/dev/null | grep '^{' | tail -1 >
 import json, sys
 l = json.loads(open(sys.argv[1]).read()); r = l["roofline"]
 print(sys.argv[1].split("/")[-1], l["value"], l["unit"], "vs_baseline", l.get("vs_baseline"), "frac", r.get("frac"), "filter us", r.get("avg_launch_us"),
-      "within_gates", l.get("parity", {}).get("within_gates"))
+      "cpu_baseline", (l.get("cpu_baseline") or {}).get("value"), "within_gates", l.get("parity", {}).get("within_gates"))
 PY
 }
 run gq_0.25

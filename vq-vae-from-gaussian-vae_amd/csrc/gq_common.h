@@ -74,7 +74,13 @@ struct WsHeader {
   unsigned long long grid_leaves;     // grid search (gq_grid.h), debug statistics: leaves visited, summed over the rows
   int grid_next;                      // grid search: the next group of four rows a wave fetches
   int loss_ticket;                    // vq_loss_kernel (gq_aux.h): blocks that have left their partial sum (reset by the first launch)
-  int pad1[24];
+  // straight-through mix where zhat is stored (gq_rerank.h:ste_mix), written by the call's first launch:
+  int ste_kind;                       // 0: zhat = code;  1: (g - g) + code, g = ste[o] = zhat_noquant (GQ2, pit/quantization/gaussian.py:337-338);
+                                      // 2: g + (code - g), g = ste[o] = z (VQ, pit/quantization/vq.py:89)
+  int pad1a;
+  const float *ste;                   // [the layout of zhat] or NULL
+  float *pure;                        // optional second output in the layout of zhat: the codeword itself (GQ2's info["zhat_quant"])
+  int pad1[18];
   float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
   int pad2[128];

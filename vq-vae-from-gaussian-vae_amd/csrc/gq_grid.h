@@ -441,7 +441,7 @@ __device__ __forceinline__ void grid_write_result(const GridParams &p, long row,
   if (who == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best;
   if (p.zhat && who < dim) {
     const long o = out_zhat_offset(p.omap, row, who, dim);
-    p.zhat[o] = ste_mix(p.omap, o, p.cb[(long)best * dim + who]);
+    p.zhat[o] = ste_mix(p.hdr, o, p.cb[(long)best * dim + who]);
   }
 }
 
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
       if (sub == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)sidx[best_j];
       if (p.zhat && sub < DIM) {
         const long o = out_zhat_offset(p.omap, row, sub, DIM);
-        p.zhat[o] = ste_mix(p.omap, o, scb[(long)best_j * DIM + sub]);
+        p.zhat[o] = ste_mix(p.hdr, o, scb[(long)best_j * DIM + sub]);
       }
     }
     if (p.stats && live) {

@@ -31,6 +31,9 @@ struct PrepParams {
   float *zhat_noquant;       // [B, c, L] / [B, L, c], or NULL
   float *sd_layout;          // FROM_Z, optional: sd in the layout of zhat (GQ2's info["std"], gaussian.py:263-264)
   float *kl2row;             // FROM_Z, optional: [rows] KL divergence of the row's Gaussian to N(0, 1) in bits (gaussian.py:225-229)
+  int ste_kind;              // -> header: the straight-through mix applied where zhat is stored (gq_common.h:WsHeader)
+  const float *ste;
+  float *pure;
   float lv_min, lv_max;
   // rows: outputs when FROM_Z, inputs otherwise (lsd may then be NULL: lsd_out receives float(log(double(sd))))
   float *mu, *sd, *lsd;      // [rows, dim]
@@ -109,6 +112,9 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     p.hdr->grid_leaves = 0ull;
     p.hdr->grid_next = 0;
     p.hdr->loss_ticket = 0;
+    p.hdr->ste_kind = p.ste_kind;
+    p.hdr->ste = p.ste;
+    p.hdr->pure = p.pure;
   }
 
 #if defined(GQHIP_ABL) && (GQHIP_ABL & 1024)   // diagnostic build (tools/abl_prep.sh): the code blocks do nothing
@@ -299,8 +305,8 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   // -------------------------------------------------------------------- rows
   __shared__ __attribute__((aligned(16))) float s_mu[256], s_sd[256], s_lsd[256];
   __shared__ __attribute__((aligned(16))) unsigned short s_hi[RB][2 * DIM], s_lo[RB][2 * DIM];
-  constexpr int KLC = F16 ? 9 : 4;               // column of the KL term
-  __shared__ double s_sum[256][KLC + 1];         // per-element terms of the row sums (F16: + the five sums of the data-dependent bound; last: KL bits)
+  __shared__ double s_sum[256][F16 ? 9 : 4];     // per-element terms of the row sums (F16: + the five sums of the data-dependent bound)
+  __shared__ float s_kl[(FROM_Z && MODE == kModeGQ) ? 256 : 1];   // per-element KL bits (gq_quantize_z_gauss_f32)
   __shared__ float s_scale[RB];                  // MIXED / F16: the row's power-of-two normalisation (NaN: none usable)
   __shared__ __attribute__((aligned(16))) float s_coef[RB][2 * DIM];
   const long row0 = (long)blockIdx.x * RB;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   const long row = row0 + lr;
   const bool live = row < p.rows;
   float m = 0.0f, s = 1.0f, ls = 0.0f;
-  double klt = 0.0;
+  float klt = 0.0f;
   if (live) {
     if constexpr (FROM_Z) {
       // row = pos * K + k; channel of (k, g): strided g*K + k (GQ1), contiguous k*dim + g (GQ2)
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
       if (p.kl2row) {
         // one element of kl2 = 1.4426 * 0.5 * (mu^2 + var - 1 - logvar) in the reference's fp32 op order (gaussian.py:225), var =
         // float(exp(double(logvar)))
-        klt = (double)kl_bits_term(m, lv);
+        klt = kl_bits_term(m, lv);
       }
       }
     } else {
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   s_sum[lr * DIM + g][1] = t1;
   s_sum[lr * DIM + g][2] = t2;
   s_sum[lr * DIM + g][3] = t3;
-  s_sum[lr * DIM + g][KLC] = klt;
+  if constexpr (FROM_Z && MODE == kModeGQ) s_kl[lr * DIM + g] = klt;
   if constexpr (F16) {
     // This element's terms of the data-dependent bound (gq_rerank.h:f16_bound), from the fp32 coefficients the filter multiplies.
     // A coordinate is a "well" when A < 0 and the vertex mu' = B / (2 |A|) of its parabola lies within |mu'| <= 6 (any
@@ -450,11 +456,11 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     }
     p.rowsum[(row0 + r) * 4 + q] = acc;
   }
-  if constexpr (FROM_Z) {
+  if constexpr (FROM_Z && MODE == kModeGQ) {
     if (p.kl2row && tid < RB && row0 + tid < p.rows) {     // the row's KL bits: ascending dim order in fp64, rounded once
       double acc = 0.0;
 #pragma unroll
-      for (int i = 0; i < DIM; ++i) acc += s_sum[tid * DIM + i][KLC];
+      for (int i = 0; i < DIM; ++i) acc += (double)s_kl[tid * DIM + i];
       p.kl2row[row0 + tid] = (float)acc;
     }
   }
@@ -563,6 +569,10 @@ struct PrepPlainParams {
   long rows;
   int dim;
   int vq;                 // z holds c channels and no logvar half (pit/quantization/vq.py:39-53)
+  WsHeader *hdr;          // already zeroed on the stream: thread 0 leaves the straight-through words
+  int ste_kind;
+  const float *ste;
+  float *pure;
   float lv_min, lv_max;
   OutMap omap;
 };
@@ -570,6 +580,7 @@ struct PrepPlainParams {
 
 __global__ __launch_bounds__(256) void prep_plain_kernel(const PrepPlainParams p) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) { p.hdr->ste_kind = p.ste_kind; p.hdr->ste = p.ste; p.hdr->pure = p.pure; }
   if (t >= p.rows * p.dim) return;
   const OutMap &om = p.omap;
   // BCHW reads are coalesced along l when consecutive threads walk l: threads are (b, ch, l) for BCHW, (pos, ch) for BLC

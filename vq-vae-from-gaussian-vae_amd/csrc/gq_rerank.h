@@ -30,11 +30,6 @@ struct OutMap {
   int mode;      // 0: idx[row], zhat[row*dim + g];  1: BCHW;  2: BLC
   int K, L, c;   // sub-codebooks per position, positions per image, channels
   int grouping;  // 0 strided (GQ1), 1 contiguous (GQ2)
-  int ste_kind;  // straight-through mix of the module's eval forward, evaluated as the reference's fp32 ops where zhat is stored:
-                 // 0: zhat = code;  1: (g - g) + code, g = ste[o] = zhat_noquant (GQ2, pit/quantization/gaussian.py:337-338);
-                 // 2: g + (code - g), g = ste[o] = z (VQ, pit/quantization/vq.py:89)
-  const float *ste;   // [the layout of zhat] or NULL
-  float *pure;        // optional second output in the layout of zhat: the codeword itself (GQ2's info["zhat_quant"])
 };
 
 __device__ __forceinline__ long out_idx_offset(const OutMap &m, long row) {
@@ -55,13 +50,18 @@ __device__ __forceinline__ long out_zhat_offset(const OutMap &m, long row, int g
   }
   return pos * m.c + ch;
 }
-// the value stored at offset o of zhat for codeword element v (also stores v itself to `pure` when that is given)
-__device__ __forceinline__ float ste_mix(const OutMap &m, long o, float v) {
+// The value stored at offset o of zhat for codeword element v: the straight-through mix of the module's eval forward, in the
+// reference's fp32 op order (also stores v itself to `pure` when that is given).  The three words live in the workspace HEADER (written
+// by the call's first launch), not in the kernel arguments: they are read here, at the very end of a row's life, and cost the hot
+// loops no scalar registers (as kernel arguments they spilled 6-10 SGPRs in every re-rank / search kernel).
+__device__ __forceinline__ float ste_mix(const WsHeader *h, long o, float v) {
 #pragma clang fp contract(off)
-  if (m.pure) m.pure[o] = v;
-  if (m.ste_kind == 0) return v;
-  const float g = m.ste[o];
-  if (m.ste_kind == 1) return (g - g) + v;     // finite g: + 0 + v; inf / NaN: NaN, as in the reference
+  const int kind = h->ste_kind;
+  float *pure = h->pure;
+  if (pure) pure[o] = v;
+  if (kind == 0) return v;
+  const float g = h->ste[o];
+  if (kind == 1) return (g - g) + v;     // finite g: + 0 + v; inf / NaN: NaN, as in the reference
   const float d = v - g;
   return g + d;
 }
@@ -165,7 +165,7 @@ __device__ __forceinline__ void write_result(const RerankParams &p, long row, in
   if (lane == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)best;
   if (p.zhat && lane < p.dim) {
     const long o = out_zhat_offset(p.omap, row, lane, p.dim);
-    p.zhat[o] = ste_mix(p.omap, o, p.cb[(long)best * p.dim + lane]);
+    p.zhat[o] = ste_mix(p.hdr, o, p.cb[(long)best * p.dim + lane]);
   }
 }
 
@@ -644,7 +644,7 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
       if (p.omap.mode == 1) { lr = j % RPB; g = j / RPB; } else { lr = j / DIM; g = j % DIM; }
       if (s_best[lr] >= 0) {
         const long o = out_zhat_offset(p.omap, row0 + lr, g, DIM);
-        p.zhat[o] = ste_mix(p.omap, o, s_zhat[lr][g]);
+        p.zhat[o] = ste_mix(p.hdr, o, s_zhat[lr][g]);
       }
     }
   }

@@ -378,6 +378,9 @@ struct PrepInput {
   float *mu_out = nullptr, *sd_out = nullptr;   // FROM_Z: optional copies of the row operands for the caller
   float *sd_layout = nullptr;                   // FROM_Z: optional sd in the layout of zhat
   bool want_kl2 = false;                        // FROM_Z: leave the per-row KL bits in the workspace (ws_layout().kl2)
+  int ste_kind = 0;                             // straight-through mix where zhat is stored (gq_common.h:WsHeader)
+  const float *ste = nullptr;
+  float *pure = nullptr;
 };
 
 template <int MODE, bool FROM_Z>
@@ -458,18 +461,19 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
 
   if (!pl.mfma) {
     // dims outside {4, 8, 16, 32}: exact score of every code (gq_exhaustive_kernel)
+    if (hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
     if (from_z) {
       PrepPlainParams pq{};
       pq.z = in.z; pq.noise = in.noise; pq.zhat_noquant = in.zhat_noquant;
       pq.sd_layout = in.sd_layout; pq.kl2row = in.want_kl2 ? reinterpret_cast<float *>(ws + w.kl2) : nullptr;
       pq.vq = MODE == kModeVQ ? 1 : 0;
+      pq.hdr = hdr; pq.ste_kind = in.ste_kind; pq.ste = in.ste; pq.pure = in.pure;
       pq.mu = const_cast<float *>(r_mu); pq.sd = const_cast<float *>(r_sd); pq.lsd = ws_lsd;
       pq.rows = rows; pq.dim = (int)dim; pq.lv_min = in.lv_min; pq.lv_max = in.lv_max; pq.omap = omap;
       hipLaunchKernelGGL(prep_plain_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, st, pq);
       const int rc = check_launch();
       if (rc != GQHIP_OK) return rc;
     }
-    if (hipMemsetAsync(hdr, 0, sizeof(WsHeader), st) != hipSuccess) return check_launch();
     const int ex_blocks = (int)(rows < 4096 ? rows : 4096);
     hipLaunchKernelGGL((gq_exhaustive_kernel<MODE>), dim3((unsigned)ex_blocks), dim3(256), 0, st, rp);
     return check_launch();
@@ -479,6 +483,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   PrepParams pp{};
   pp.z = in.z; pp.noise = in.noise; pp.zhat_noquant = in.zhat_noquant; pp.lv_min = in.lv_min; pp.lv_max = in.lv_max;
   pp.sd_layout = in.sd_layout; pp.kl2row = in.want_kl2 ? reinterpret_cast<float *>(ws + w.kl2) : nullptr;
+  pp.ste_kind = in.ste_kind; pp.ste = in.ste; pp.pure = in.pure;
   pp.mu = const_cast<float *>(r_mu); pp.sd = const_cast<float *>(r_sd);
   pp.lsd = const_cast<float *>(from_z ? ws_lsd : lsd);
   pp.lsd_out = (!from_z && MODE == kModeGQ && !lsd) ? ws_lsd : nullptr;
@@ -765,7 +770,7 @@ int gq_quantize_z_gauss_f32(const float *z, const float *noise, const float *cb,
   OutMap om{};
   om.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
   om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = grouping;
-  if (use_ste) { om.ste_kind = 1; om.ste = zhat_noquant; om.pure = zhat_quant_or_null; }
+  if (use_ste) { in.ste_kind = 1; in.ste = zhat_noquant; in.pure = zhat_quant_or_null; }
   int rc = run_argmax<kModeGQ>(in, nullptr, nullptr, nullptr, cb, idx, zhat, dim, rows, n, beta, workspace, workspace_bytes,
                                cb_cache_or_null, cb_cache_bytes, om, st);
   if (rc != GQHIP_OK) return rc;
@@ -793,7 +798,7 @@ int vq_quantize_z_f32(const float *z, const float *emb, int64_t *idx, float *zq,
   OutMap om{};
   om.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
   om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = GQHIP_GROUP_STRIDED;     // channel = d * K + k (vq.py:53)
-  om.ste_kind = 2; om.ste = z;                                                        // z_q = z + (z_q - z) (vq.py:89)
+  in.ste_kind = 2; in.ste = z;                                                        // z_q = z + (z_q - z) (vq.py:89)
   int rc = run_argmax<kModeVQ>(in, nullptr, nullptr, nullptr, emb, idx, zq, dim, rows, n, 0.0, workspace, workspace_bytes,
                                cb_cache_or_null, cb_cache_bytes, om, st);
   if (rc != GQHIP_OK || !loss2_or_null) return rc;
