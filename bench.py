@@ -215,7 +215,7 @@ def pmc_traffic(kernel, config="gq_0.25"):
 
 
 # End-to-end parity gates (GPU encoder -> GPU quantiser -> GPU decoder against the reference's CPU path on the same input).
-# ONE definition: tests/test_gpu_modules.py, tests/test_gpu_round2.py and tests/test_gpu_round3.py gate on these numbers,
+# ONE definition: tests/test_gpu_modules.py, tests/test_gpu_e2e_goldens.py gate on these numbers,
 # bench.py prints them beside what it measured, BASELINE.md / DESIGN.md quote them.
 GATES = {
     "z_enc_max_abs": 5e-5,               # |z_gpu - z_cpu| at 256^2 (measured 3-5e-6)
@@ -915,7 +915,7 @@ def main():
                               "Winograd GEMM at the 256-channel level; ONE fp16 hipBLASLt GEMM over a K axis of split products for the "
                               "other Winograd / sub-pixel GEMMs and for the two attention GEMMs.  Measured error 1.8-2.9e-7 of sum|a||b| "
                               "vs 2.6-3.5e-7 for hipBLASLt's own fp32 GEMM, which on gfx950 is itself a split-bf16 emulation "
-                              "(tools/conv3_bench.py, tools/bmm_bf16x3.py, tools/wino_gemm2_bench.py, tests/test_gpu_round2.py); "
+                              "(tools/conv3_bench.py, tools/bmm_bf16x3.py, tools/wino_gemm2_bench.py, tests/test_gpu_convstack_kernels.py); "
                               "the decoder's conv_out (128 -> 3): fp32 FMAs; the encoder's conv_out (the layer that produces z) and the decoder's conv_in: "
                               "libgqhip's conv3x3_f32 on the fp32 matrix cores in a fixed summation order (bit-reproducible); the "
                               "encoder's conv_in (3 -> 128): libgqhip's conv3x3_cin_small_f32, fp32 FMAs in a fixed order (no library "

@@ -128,7 +128,7 @@ def test_odd_batches_and_non_square_sizes_meet_the_contract(B, H, W):
     """Batch sizes and image sizes that the conv-stack kernels' tiles do not divide (every size is a multiple of 8, as the reference
     requires): the channels_last product path -- whatever mix of own kernels and library fallbacks the route logic picks per
     layer -- against the fp64 twin: z within the contract, tokens equal to the tokens of the twin's z except at near-ties (the
-    end-to-end gate of bench.GATES), reconstruction of the SAME zhat within the contract.  (Bit-reproducibility is claimed -- and tested, test_gpu_round3.py -- for the
+    end-to-end gate of bench.GATES), reconstruction of the SAME zhat within the contract.  (Bit-reproducibility is claimed -- and tested, test_gpu_e2e_goldens.py -- for the
     shapes the own kernels tile; here some layers fall back to library convolutions.)"""
     from bench import GATES
     from pit_hip.models.autoencoder import AutoencodingEngine

@@ -152,6 +152,41 @@ def test_grid_non_finite_codebook_means_every_row_is_scanned():
     assert (idx == 777).all()                     # NaN score counts as the maximum (torch.argmax)
 
 
+def test_cache_body_clobbered_behind_an_intact_header_stays_in_bounds():
+    """the validation covers the header's stamps, not the body.  A body overwritten with garbage while the 4-KiB
+    header is intact (an aliased allocation, a stray write -- a breach of the caller's half of the contract, gqhip.h) may cost wrong
+    indices, but every offset and code id read from the body is bounded by the codebook size: the call completes, every index is
+    in [0, n), zhat is a row of the codebook for it; forcing a rebuild (zeroed stamp) gives the oracle's answer again."""
+    from pit_hip import _lib
+
+    dim, n, rows = 4, 65536, 2048
+    cb0 = O.codebook(n, dim, 42)
+    cbt = torch.from_numpy(cb0.copy()).to(DEV)
+    mu, sd = _rows(rows, dim, 23)
+    ws = _lib.Workspace()
+    idx0, zhat0, lsd, _ = _gq(mu, sd, cbt, ws=ws)
+    ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb0, 1.0, logstd=lsd)
+    assert np.array_equal(idx0, ref_idx)
+    g = torch.Generator().manual_seed(5)
+    for kind in ("random bytes", "huge ints", "negative ints", "zeros"):
+        body = ws.cache_buf[4096:]
+        if kind == "random bytes":
+            body.copy_(torch.randint(0, 256, body.shape, dtype=torch.uint8, generator=g).to(DEV))
+        elif kind == "huge ints":
+            body.view(torch.int32).fill_(0x7fffffff)
+        elif kind == "negative ints":
+            body.view(torch.int32).fill_(-5)
+        else:
+            body.zero_()
+        idx, zhat, _, _ = _gq(mu, sd, cbt, ws=ws)               # header intact: no rebuild, garbage index
+        torch.cuda.synchronize()
+        assert idx.min() >= 0 and idx.max() < n, kind
+        assert np.isfinite(zhat).all() or kind == "random bytes"    # zhat comes from the (garbage) sorted copy: any bits, but it was readable
+        ws.cache_buf[:4096].zero_()                              # what a caller does to force a rebuild
+        idx, zhat, _, _ = _gq(mu, sd, cbt, ws=ws)
+        assert np.array_equal(idx, ref_idx) and np.array_equal(zhat, ref_zhat), kind
+
+
 def test_codebook_cache_validates_itself():
     """The cache is keyed on nothing the caller tells us: a codebook edited in place through .data (no version bump), another
     codebook through the same Workspace, and a cache buffer overwritten with garbage all give the right answer on the very next

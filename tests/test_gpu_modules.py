@@ -548,7 +548,7 @@ def test_add_bias_stats_and_gn_apply_match_the_unfused_pair():
 def test_upsample_fallback_route_matches_upsample_then_conv():
     """Upsample at shapes the direct sub-pixel kernel does not tile (H % 8, W % 32, or no statistics on the input): libgqhip's
     NHWC upsample copy + the ordinary convolution routes == interpolate followed by the 3x3 conv.  (The tiled shapes:
-    tests/test_gpu_round2.py::test_upconv2x_direct_matches_fp64.)"""
+    tests/test_gpu_convstack_kernels.py::test_upconv2x_direct_matches_fp64.)"""
     import torch.nn.functional as F
     from pit_hip.modules import unet as U
 

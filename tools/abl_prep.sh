@@ -14,7 +14,7 @@ for a in 0 1024 2048 4096 3072; do
     if [ $mode = rows ]; then
       rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ablp -- python3 $REPO/tools/kbench.py --iters 20 > /dev/null 2>&1
     else
-      rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ablp -- python3 $REPO/tools/conditioning.py > /dev/null 2>&1
+      rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ablp -- python3 $REPO/tools/mbench.py --module gq --iters 20 > /dev/null 2>&1
     fi
     f=$(find /tmp/ablp -name '*kernel_stats.csv' | head -1)
     echo "abl=$a ($mode): $(grep gq_prep_kernel $f | awk -F, '{printf "%s calls, avg %.2f us, min %.2f us; ", $(NF-6), $(NF-4)/1000, $(NF-2)/1000}')"

@@ -8,6 +8,7 @@ namespace gqhip {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kTileCodes = 32;     // codes per MFMA 32x32 tile

@@ -488,9 +488,15 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cache + L.box1);
     f32x4 *dst = reinterpret_cast<f32x4 *>(s_box);
     for (int k = tid; k < TREE_F / 4; k += kGridThreads) dst[k] = src[k];
-    const f32x4 *src2 = reinterpret_cast<const f32x4 *>(p.cache + L.start);
-    f32x4 *dst2 = reinterpret_cast<f32x4 *>(s_start);
-    for (int k = tid; k < START_N / 4; k += kGridThreads) dst2[k] = src2[k];
+    // (leaf ranges are clamped to [0, n] on their way into LDS: a cache body that was written behind the library's back -- the header's
+    //  stamps cannot see that -- may then cost a wrong index, never an out-of-range read; gqhip.h, codebook cache)
+    const i32x4 *src2 = reinterpret_cast<const i32x4 *>(p.cache + L.start);
+    i32x4 *dst2 = reinterpret_cast<i32x4 *>(s_start);
+    for (int k = tid; k < START_N / 4; k += kGridThreads) {
+      i32x4 v = src2[k];
+      v.x = min(max(v.x, 0), p.n); v.y = min(max(v.y, 0), p.n); v.z = min(max(v.z, 0), p.n); v.w = min(max(v.w, 0), p.n);
+      dst2[k] = v;
+    }
   }
   const float *s_box2 = s_box + kGridL1 * BOXF, *s_box3 = s_box + (kGridL1 + kGridL2) * BOXF;
   const float N1f = wave_absmax(p.hdr->absmax_part, lane);
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     auto exact_code = [&](int j) {
       float nn[DIM];
       load_code(j, nn);
-      const int code = sidx[j];
+      const int code = (int)min((unsigned)sidx[j], (unsigned)(p.n - 1));
       double sc;
       if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(nn, ops, p.beta);
       else sc = vq_neg_dist(nn, ops, DIM);
@@ -805,8 +811,8 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
             grid_load_box<DIM>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(gsbox) + (unsigned)sid * (unsigned)(BOXF * 4)),
                                lo[c], hi[c]);
             const int *rp = reinterpret_cast<const int *>(reinterpret_cast<const char *>(gsstart) + (unsigned)sid * 4u);
-            r0[c] = rp[0];
-            r1[c] = rp[1];
+            r0[c] = min(max(rp[0], 0), p.n);          // (bounded by the codebook size: see the copy of `start` above)
+            r1[c] = min(max(rp[1], r0[c]), p.n);
           }
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
@@ -952,7 +958,7 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
     if (decided) {
       // the winner's original id and its code row come from the SORTED tables at the same position: two independent loads, one round
       // trip (through cb[sidx[j]] it was two; the sorted row is a bit copy of the caller's, and the cache was validated by this call)
-      if (sub == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)sidx[best_j];
+      if (sub == 0) p.idx[out_idx_offset(p.omap, row)] = (int64_t)min((unsigned)sidx[best_j], (unsigned)(p.n - 1));
       if (p.zhat && sub < DIM) {
         const long o = out_zhat_offset(p.omap, row, sub, DIM);
         p.zhat[o] = ste_mix(p.hdr, o, scb[(long)best_j * DIM + sub]);
@@ -1018,9 +1024,15 @@ __global__ __launch_bounds__(kGridThreads, 2) void gq_grid_finish_kernel(const G
     const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cache + L.box3);
     f32x4 *dst = reinterpret_cast<f32x4 *>(s_box3f);
     for (int k = tid; k < kGridLeaves * BOXF / 4; k += kGridThreads) dst[k] = src[k];
-    const f32x4 *src2 = reinterpret_cast<const f32x4 *>(p.cache + L.start);
-    f32x4 *dst2 = reinterpret_cast<f32x4 *>(s_start);
-    for (int k = tid; k < START_N / 4; k += kGridThreads) dst2[k] = src2[k];
+    // (leaf ranges are clamped to [0, n] on their way into LDS: a cache body that was written behind the library's back -- the header's
+    //  stamps cannot see that -- may then cost a wrong index, never an out-of-range read; gqhip.h, codebook cache)
+    const i32x4 *src2 = reinterpret_cast<const i32x4 *>(p.cache + L.start);
+    i32x4 *dst2 = reinterpret_cast<i32x4 *>(s_start);
+    for (int k = tid; k < START_N / 4; k += kGridThreads) {
+      i32x4 v = src2[k];
+      v.x = min(max(v.x, 0), p.n); v.y = min(max(v.y, 0), p.n); v.z = min(max(v.z, 0), p.n); v.w = min(max(v.w, 0), p.n);
+      dst2[k] = v;
+    }
   }
   const float *s_box3 = s_box3f;
   // ---- the block's undecided rows, one after the other, all 512 threads.  A row with a finite threshold (a list that did not fit:
@@ -1095,7 +1107,7 @@ __global__ __launch_bounds__(kGridThreads, 2) void gq_grid_finish_kernel(const G
       const float thr2 = t2 > thr ? t2 : thr;             // (the row's own F was found among these leaves' codes or earlier: fm >= it)
       leaf_codes([&](int j, const float (&n)[DIM], float f) {
         if (!(f < thr2)) {
-          const int code = sidx[j];
+          const int code = (int)min((unsigned)sidx[j], (unsigned)(p.n - 1));
           double sc;
           if constexpr (MODE == kModeGQ) sc = (double)ref_score_lds<DIM>(n, s_sops, p.beta);
           else sc = vq_neg_dist(n, s_sops, DIM);
@@ -1116,8 +1128,10 @@ __global__ __launch_bounds__(kGridThreads, 2) void gq_grid_finish_kernel(const G
       }
       __syncthreads();
     }
-    const int best = sh_i[0];
-    if (best != 0x7fffffff) grid_write_result(p, row, best, tid, DIM);
+    // (no code at all can only come out of a cache body that was overwritten behind an intact header -- every range empty --: the
+    //  row still gets a defined, in-range result)
+    const int best = sh_i[0] != 0x7fffffff ? sh_i[0] : 0;
+    grid_write_result(p, row, best, tid, DIM);
     __syncthreads();
   }
 }

@@ -67,7 +67,7 @@ __device__ __forceinline__ void stat_add(int64_t *rec, double s, double ss) {
 // The same for a thread's fp32 partial sums (the common case), by integer arithmetic on the fp32 bits: the 24-bit
 // significand m of v = m 2^(e - 150) lands at bit (e - 94) of the fixed-point number, i.e. in limb k = (e - 94) / 40 and,
 // when it straddles, limb k + 1 -- two shifts and at most two atomics instead of ~80 fp64 instructions.  Bit-identical
-// to stat_split((double)v) (tests/test_gpu_round3.py compares the kernels that use either form).
+// to stat_split((double)v) (tests/test_gpu_convstack_kernels.py compares the kernels that use either form).
 __device__ __forceinline__ void stat_add_one_f32(int64_t *limbs, int64_t *poison, float v) {
   const unsigned bits = __float_as_uint(v);
   const int e = (int)((bits >> 23) & 0xffu);

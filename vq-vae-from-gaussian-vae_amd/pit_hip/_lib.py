@@ -385,7 +385,9 @@ def gq_dequant(idx, cb, dim: int, layout: str, grouping: int):
     return zhat
 
 
-def vq_argmin(z, emb, ws: Optional[Workspace] = None):
+def vq_argmin(z, emb, ws: Optional[Workspace] = None, use_cache: bool = True):
+    """``use_cache=False``: no codebook cache in this call -- the dense filter + re-rank path whatever the shape.  For codebooks
+    that change every step (training): a dim-4 index would be rebuilt by one block on every call."""
     z, emb = _dev(z, torch.float32, "z"), _dev(emb, torch.float32, "embedding")
     rows, dim = z.shape
     n = emb.shape[0]
@@ -394,7 +396,7 @@ def vq_argmin(z, emb, ws: Optional[Workspace] = None):
     zq = torch.empty(rows, dim, dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
         wptr, wbytes = ws.get(max(rows, 1), n, dim, z.device)
-        cptr, cbytes = ws.cache(n, dim, z.device)
+        cptr, cbytes = ws.cache(n, dim, z.device) if use_cache else (None, 0)
         _check(lib().vq_argmin_f32(z.data_ptr(), emb.data_ptr(), idx.data_ptr(), zq.data_ptr(), dim, rows, n,
                                    wptr, wbytes, cptr, cbytes, _stream()), "vq_argmin_f32")
     return idx, zq

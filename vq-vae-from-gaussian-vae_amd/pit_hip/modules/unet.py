@@ -423,12 +423,21 @@ def _with_stats_arena(module: nn.Module, run, x: torch.Tensor):
 
     key = (threading.get_ident(), torch.cuda.current_stream(x.device).cuda_stream)
     arenas = module.__dict__.setdefault("_gq_stats_arenas", {})
-    arena = arenas.get(key)
+    arena = arenas.pop(key, None)
     if arena is None:
-        arena = arenas[key] = _lib.StatsArena()
+        arena = _lib.StatsArena()
         module.__dict__.setdefault("_gq_stats_arena", arena)      # (the first one: what tests / tools look at)
+        # bounded: workloads that churn threads or streams would otherwise keep one device arena per (thread, stream)
+        # they ever used; the least recently used one goes (dicts keep insertion order; a hit re-inserts below).  The device
+        # memory of an evicted arena is released stream-ordered by the caching allocator, so a forward still in flight on it is safe.
+        while len(arenas) >= _MAX_STATS_ARENAS:
+            arenas.pop(next(iter(arenas)))
+    arenas[key] = arena
     with _lib.stats_arena(arena, x.device):
         return run(x)
+
+
+_MAX_STATS_ARENAS = 8
 
 
 def _guarded(module: nn.Module, run0, x: torch.Tensor):

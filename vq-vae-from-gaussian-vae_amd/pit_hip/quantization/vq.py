@@ -74,7 +74,10 @@ class VQQuantizer(nn.Module):
         z_q, indices = [], []
         for k in range(self.codebook_num):
             with torch.no_grad():
-                idx, _ = _lib.vq_argmin(zf[:, :, k].detach().float().contiguous(), w.detach().float(), ws=self._ws)
+                # a learned codebook moves every optimizer step: no per-codebook cache while training (the dim-4 search index would
+                # be rebuilt by one block per call); eval with autograd on keeps it
+                idx, _ = _lib.vq_argmin(zf[:, :, k].detach().float().contiguous(), w.detach().float(), ws=self._ws,
+                                        use_cache=not self.training)
             z_q.append(self.embedding(idx)[:, :, None])
             indices.append(idx[:, None])
         z_q = torch.cat(z_q, dim=2).view(z.shape)
