@@ -811,8 +811,16 @@ __global__ __launch_bounds__(kGridThreads, DIM >= 8 ? 2 : 4) void gq_grid_kernel
             grid_load_box<DIM>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(gsbox) + (unsigned)sid * (unsigned)(BOXF * 4)),
                                lo[c], hi[c]);
             const int *rp = reinterpret_cast<const int *>(reinterpret_cast<const char *>(gsstart) + (unsigned)sid * 4u);
-            r0[c] = min(max(rp[0], 0), p.n);          // (bounded by the codebook size: see the copy of `start` above)
-            r1[c] = min(max(rp[1], r0[c]), p.n);
+#ifdef GQHIP_NO_BODY_CLAMP       // diagnostic build: what the bounds on the cache body cost
+            r0[c] = rp[0];
+            r1[c] = rp[1];
+#else
+            // (bounded by the codebook size -- see the copy of `start` above --; one unsigned minimum each: a negative word reads as n,
+            //  and a range that ends before it starts is empty through the `len > 0` test below.  +1.2 us of 62 at the trained
+            //  operating point with two instructions each, profiles/r06/grid_body_clamp_ab.txt)
+            r0[c] = (int)min((unsigned)rp[0], (unsigned)p.n);
+            r1[c] = (int)min((unsigned)rp[1], (unsigned)p.n);
+#endif
           }
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
