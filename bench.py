@@ -194,6 +194,7 @@ def pmc_traffic(kernel, config="gq_0.25"):
 
     if config is None:
         return None, None
+    config = {"gq2_0.25": "gq_0.25"}.get(config, config)     # GQ2 dim 16 / K 1: the same rows x codes x dim, the same filter instantiation
     prof = os.path.join(ROOT, "profiles")
     for rnd in sorted((d for d in os.listdir(prof) if d.startswith("r")), reverse=True) if os.path.isdir(prof) else []:
         vals, src = {}, {}
@@ -208,7 +209,7 @@ def pmc_traffic(kernel, config="gq_0.25"):
             if not rows:
                 break
             vals[name] = sum(rows) / len(rows)
-            src[f"profiles/{rnd}/pmc_{name}.csv"] = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+            src[os.path.relpath(path, ROOT)] = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
         if len(vals) == 2:
             return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, {"files_sha256_16": src, "launches_averaged": len(rows)}
     return None, None
@@ -785,8 +786,9 @@ def main():
             whole = flops / (stages["quantiser"] * 1e-3) / 1e12
             whole_b2b = flops / (call_us * 1e-6) / 1e12
             grid = bool(_lib.lib().gqhip_grid_search_applies(N_CODES, dim)) and cfg["family"] != "lfq"
-            # the committed PMC passes are of tools/kbench.py at the config's 256 x 256, bs 16 shape: other shapes report no traffic
-            shape_tag = args.config if (args.size == 256 and args.batch == 16) else None
+            # the committed PMC passes are of tools/kbench.py at the config's bs 16 shape (profiles/rNN/pmc_*_<config>[_<size>].csv):
+            # shapes without a committed pass report no traffic
+            shape_tag = (args.config if args.size == 256 else f"{args.config}_{args.size}") if args.batch == 16 else None
             launch_names = None
             if grid:
                 # dim 4: no filter / re-rank -- a pruned exact search over a cached box tree of the codebook (csrc/gq_grid.h)

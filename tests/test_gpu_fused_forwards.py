@@ -201,3 +201,64 @@ def test_vq_fused_forward_is_bit_reproducible_and_graph_capturable():
         zq1, i1 = vq(z)
     assert torch.equal(zq_g, zq1) and torch.equal(i_g["indices"], i1["indices"]) and torch.equal(i_g["codebook_loss"], i1["codebook_loss"])
     assert not torch.equal(i1["indices"], i0["indices"])
+
+
+def test_gq2_fused_forward_replays_from_a_hip_graph_and_the_lambda_state_keeps_moving():
+    """The lambda state lives on the device, so a captured forward advances it on every replay with no host in the loop: three
+    replays leave the module where three eager forwards of a twin leave it (and the replayed outputs are the eager ones)."""
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
+
+    g = torch.Generator().manual_seed(8)
+    z = torch.cat([0.9 * torch.randn(2, 16, 16, 16, generator=g), -1.5 + 0.3 * torch.randn(2, 16, 16, 16, generator=g)], 1).to(DEV)
+    z = z.contiguous(memory_format=torch.channels_last)
+    a = GaussianQuantRegularizer2(16, 4096).eval().to(DEV)
+    b = copy.deepcopy(a)
+    with torch.no_grad():
+        a(z)                                        # warm-up: workspace, codebook cache, the device copy of the lambdas
+        b(z)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            a(z)
+        torch.cuda.current_stream().wait_stream(s)
+        b(z)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            zh_g, info_g = a(z)
+        for _ in range(3):
+            gr.replay()
+            zh_e, info_e = b(z)
+        torch.cuda.synchronize()
+    assert torch.equal(zh_g, zh_e) and torch.equal(info_g["indices"], info_e["indices"])
+    for k in ("kl_loss", "bits-mean", "bits-min", "bits-max", "lam", "lam-min", "lam-max"):
+        assert float(info_g[k]) == float(info_e[k]), k
+    assert (a.lam, a.lam_min, a.lam_max) == (b.lam, b.lam_min, b.lam_max) and a.lam != 1.0
+
+
+@pytest.mark.parametrize("dim,n,c", [(4, 65536, 16), (6, 512, 12), (8, 4096, 16), (32, 2048, 32)])
+def test_gq2_fused_forward_on_every_launch_path_vs_the_oracle(dim, n, c):
+    """The statistics block runs as one extra block of the re-rank launch at dims 8 / 16 / 32 and dim 4 without a search index, and as
+    its own launch behind the dim-4 search (n >= 2^14) and the exhaustive kernel (a dim without a filter): same function, same order
+    of additions -- every path against the oracle's restatement of quant_gaussian's statistics and of quant_vq, two forwards each."""
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
+
+    g = torch.Generator().manual_seed(40 + dim)
+    z = torch.cat([1.2 * torch.randn(2, c, 16, 16, generator=g), -1.5 + 0.3 * torch.randn(2, c, 16, 16, generator=g)], 1)
+    m = GaussianQuantRegularizer2(dim, n).eval().to(DEV)
+    cb = m.prior_samples.cpu().numpy()
+    state = (1.0, 1.0, 1.0)
+    with torch.no_grad():
+        for it in range(2):
+            zi = z * (1.0 + 0.5 * it)
+            zh, info = m(zi.to(DEV))
+            want, state = O.gq2_quant_gaussian_stats(zi.numpy(), dim, n, state)
+            for k in ("kl_loss", "bits-mean", "bits-min", "bits-max"):
+                assert _close(info[k], want[k], 2e-6), (it, k, float(info[k]), float(want[k]))
+            assert (float(info["lam"]), float(info["lam-min"]), float(info["lam-max"])) == state
+            # operands as the kernels derive them (fp64 exp / log, rounded once) differ from numpy's fp32 chain by an ulp: strict on indices
+            # only where the oracle's own top-2 gap is clear of that
+            ozq, oind = O.gq2_quant_vq(zi.numpy(), cb, dim, 1)
+            same = info["indices"].cpu().numpy() == oind
+            assert same.mean() > 0.999, same.mean()
+            el = np.repeat(same, dim, axis=1)
+            assert np.array_equal(zh.cpu().numpy()[el], ozq[el])

@@ -5,6 +5,7 @@
 #pragma once
 #include "gq_common.h"
 #include "gq_rerank.h"
+#include "gq_gauss.h"
 
 namespace gqhip {
 
@@ -305,91 +306,6 @@ __global__ __launch_bounds__(256) void step_record_kernel(const StepRecordParams
   const float psnr = (float)(20.0 * log10(255.0 / sqrt((double)mse)));      // identical images: +inf, like the reference
   p.rec[b] = __float_as_int(psnr);
   p.ticket[b] = 0;                             // ready for the next call on this workspace
-}
-
-// ---- GQ2's Gaussian branch in eval (pit/quantization/gaussian.py:211-271): statistics of the per-row KL bits + the lambda state ----
-// The first launch of the fused call (gq_prep.h) leaves kl2row [rows]; this ONE block reduces it in a fixed order (thread t takes
-// rows t, t + 1024, ...; then a tree in LDS: bit-reproducible) to mean / min / max and the re-weighted loss, and advances the
-// adaptive lambda state exactly as the reference's Python does -- in fp64, on the device, so the forward needs no host read at all
-// (the reference pays three bool(tensor) syncs per forward, gaussian.py:243-253).
-//   scalars (64 B, 8-byte aligned): float[0..3] = { kl_loss, bits-mean, bits-min, bits-max };
-//                                   double at byte 32: { lam, lam_min, lam_max } AFTER the update (what info["lam"...] reports).
-struct GaussStatsParams {
-  const float *kl2row;
-  long rows;
-  double *lam_state;        // [3] in / out: lam, lam_min, lam_max
-  void *scalars;
-  float thr_hi, thr_lo, log2n;      // float(n + tol), float(n - tol), float(n): torch compares the fp32 tensor with the scalar cast to fp32
-  double lam_factor, lam_lo, lam_hi;
-  int lam_max_decreases;    // 1: gaussian.py:109-112 (GQ1); 0: GQ2, whose decrease is a no-op expression (gaussian.py:251)
-};
-
-__global__ __launch_bounds__(1024) void gauss_stats_finalize_kernel(const GaussStatsParams p) {
-#pragma clang fp contract(off)
-  const int tid = threadIdx.x;
-  const double lam = p.lam_state[0], lam_min = p.lam_state[1], lam_max = p.lam_state[2];
-  const float w_ge = (float)lam_max, w_le = (float)lam_min;
-  double sum = 0.0, wsum = 0.0;
-  float mn = __builtin_inff(), mx = -__builtin_inff();
-  bool nan = false;
-  for (long r = tid; r < p.rows; r += 1024) {
-    const float k = p.kl2row[r];
-    nan = nan || (k != k);
-    sum += (double)k;
-    mn = __builtin_fminf(mn, k);
-    mx = __builtin_fmaxf(mx, k);
-    // ge * kl2 + eq * kl2 + le * kl2 with the reference's fp32 products (gaussian.py:233-240)
-    const float ge = (k > p.thr_hi ? 1.0f : 0.0f) * w_ge;
-    const float eq = (k <= p.thr_hi ? 1.0f : 0.0f) * (k >= p.thr_lo ? 1.0f : 0.0f);
-    const float le = (k < p.thr_lo ? 1.0f : 0.0f) * w_le;
-    float e = ge * k;
-    e = e + eq * k;
-    e = e + le * k;
-    wsum += (double)e;
-  }
-  // wave shuffles, then the 16 wave results in wave order: a fixed tree, bit-reproducible
-  int nani = nan ? 1 : 0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    sum += __shfl_xor(sum, o);
-    wsum += __shfl_xor(wsum, o);
-    mn = __builtin_fminf(mn, __shfl_xor(mn, o));
-    mx = __builtin_fmaxf(mx, __shfl_xor(mx, o));
-    nani |= __shfl_xor(nani, o);
-  }
-  __shared__ double s_a[16], s_b[16];
-  __shared__ float s_mn[16], s_mx[16];
-  __shared__ int s_nan[16];
-  if ((tid & 63) == 0) { s_a[tid >> 6] = sum; s_b[tid >> 6] = wsum; s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; s_nan[tid >> 6] = nani; }
-  __syncthreads();
-  if (tid != 0) return;
-  for (int w = 1; w < 16; ++w) {
-    s_a[0] += s_a[w];
-    s_b[0] += s_b[w];
-    s_mn[0] = __builtin_fminf(s_mn[0], s_mn[w]);
-    s_mx[0] = __builtin_fmaxf(s_mx[0], s_mx[w]);
-    s_nan[0] |= s_nan[w];
-  }
-  const float qnan = __builtin_nanf("");
-  const float mean = (float)(s_a[0] / (double)p.rows);
-  const float kmin = s_nan[0] ? qnan : s_mn[0], kmax = s_nan[0] ? qnan : s_mx[0];      // torch.min / max propagate NaN
-  const float wmean = (float)(s_b[0] / (double)p.rows);
-  const float kl_loss = wmean * (float)lam;                                             // torch.mean(kl_loss) * self.lam
-  double l = lam, lmin = lam_min, lmax = lam_max;
-  const double f = p.lam_factor;
-  l = mean > p.log2n ? l * f : l / f;
-  if (kmax > p.thr_hi) lmax = lmax * f;
-  else if (p.lam_max_decreases) lmax = lmax / f;
-  lmax = lmax < p.lam_hi ? lmax : p.lam_hi;       // max(min(lam_max, hi), 1.0)
-  lmax = lmax > 1.0 ? lmax : 1.0;
-  lmin = kmin < p.thr_lo ? lmin / f : lmin * f;
-  lmin = lmin < 1.0 ? lmin : 1.0;                 // max(min(lam_min, 1.0), lo)
-  lmin = lmin > p.lam_lo ? lmin : p.lam_lo;
-  float *fo = static_cast<float *>(p.scalars);
-  fo[0] = kl_loss; fo[1] = mean; fo[2] = kmin; fo[3] = kmax;
-  double *d = reinterpret_cast<double *>(static_cast<char *>(p.scalars) + 32);
-  d[0] = l; d[1] = lmin; d[2] = lmax;
-  p.lam_state[0] = l; p.lam_state[1] = lmin; p.lam_state[2] = lmax;
 }
 
 // ---- VQ's codebook loss in eval (pit/quantization/vq.py:78-86): mean((z_q - z)^2) over every element --------------------------

@@ -64,6 +64,19 @@ __device__ __forceinline__ double rec_value(float m1, unsigned short gap) {
   return (double)m1 - (double)(float)__builtin_bit_cast(_Float16, gap);
 }
 
+// gq_quantize_z_gauss_f32's statistics block (gq_gauss.h); a copy travels in the workspace header when that block runs inside the
+// re-rank launch.
+struct GaussStatsParams {
+  const float *kl2row;      // [rows] KL bits per row (gq_prep.h)
+  double *lam_state;        // [3] in / out: lam, lam_min, lam_max
+  void *scalars;            // 64 B out
+  long rows;                // 0: no statistics in this call
+  double lam_factor, lam_lo, lam_hi;
+  float thr_hi, thr_lo, log2n;      // float(n + tol), float(n - tol), float(n): torch compares the fp32 tensor with the scalar cast to fp32
+  int lam_max_decreases;    // 1: gaussian.py:109-112 (GQ1); 0: GQ2, whose decrease is a no-op expression (gaussian.py:251)
+};
+static_assert(sizeof(GaussStatsParams) == 72, "fits the header's pad");
+
 // Workspace header (first 8 KiB of the caller's workspace).  Everything in it is (re)written by the kernels of ONE
 // call: gq_prep_kernel resets the counters and writes the max|cb| partials, the re-rank reduces them per wave.
 // Nothing here is read across calls.
@@ -84,7 +97,8 @@ struct WsHeader {
   int pad1[18];
   float absmax_part[kAbsmaxParts];    // one partial per code block of gq_prep_kernel
   unsigned long long stamps[48];      // diagnostic builds only (GQHIP_CLOCK_STAMPS)
-  int pad2[128];
+  GaussStatsParams gs;                // gs.rows > 0: the re-rank launch carries one extra block that runs gauss_stats_block (written by the first launch)
+  int pad2[110];
   float r2_part[kAbsmaxParts];        // max squared code norm per code block (fp16 filter's norm bound, gq_rerank.h)
   int pad3[256];
   unsigned long long cbsum[kAbsmaxParts];   // content hash of the codebook slice each code block of gq_prep_kernel read in THIS call

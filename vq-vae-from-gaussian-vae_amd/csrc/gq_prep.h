@@ -34,6 +34,7 @@ struct PrepParams {
   int ste_kind;              // -> header: the straight-through mix applied where zhat is stored (gq_common.h:WsHeader)
   const float *ste;
   float *pure;
+  GaussStatsParams gs;       // -> header: rows > 0 when the re-rank launch of this call carries the statistics block (gq_gauss.h)
   float lv_min, lv_max;
   // rows: outputs when FROM_Z, inputs otherwise (lsd may then be NULL: lsd_out receives float(log(double(sd))))
   float *mu, *sd, *lsd;      // [rows, dim]
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
     p.hdr->ste_kind = p.ste_kind;
     p.hdr->ste = p.ste;
     p.hdr->pure = p.pure;
+    p.hdr->gs = p.gs;
   }
 
 #if defined(GQHIP_ABL) && (GQHIP_ABL & 1024)   // diagnostic build (tools/abl_prep.sh): the code blocks do nothing

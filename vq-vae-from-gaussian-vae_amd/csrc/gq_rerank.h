@@ -21,6 +21,7 @@
 #pragma once
 #include "gq_common.h"
 #include "gq_filter.h"
+#include "gq_gauss.h"
 
 namespace gqhip {
 
@@ -667,7 +668,20 @@ __device__ __forceinline__ void rerank_block(const RerankParams &p, const int vb
 // (dim 32 needs 2 x 32 coefficient registers alone: two blocks per CU there)
 template <int MODE, int DIM, int GT, int NSI>
 __global__ __launch_bounds__(256, DIM >= 32 ? 2 : 4) void gq_rerank_kernel(const RerankParams p) {
-  rerank_block<MODE, DIM, GT, NSI>(p, (int)blockIdx.x, p.rows);
+  // gq_quantize_z_gauss_f32 launches ONE block more than the rows need: block 0 then runs GQ2's statistics (gq_gauss.h) beside the
+  // re-rank's blocks -- its input, the per-row KL bits, was left by the call's first launch -- so that call has no fourth launch
+  int vblock = (int)blockIdx.x;
+  if constexpr (MODE == kModeGQ) {
+    const int extra = (int)gridDim.x - (p.rows + 15) / 16;          // 0 or 1
+    if (extra > 0) {
+      if (vblock == 0) {
+        if (p.hdr->gs.rows > 0) gauss_stats_block(p.hdr->gs);
+        return;
+      }
+      vblock -= extra;
+    }
+  }
+  rerank_block<MODE, DIM, GT, NSI>(p, vblock, p.rows);
 }
 
 // Exhaustive exact arg-max of rows list[first], list[first + stride], ... (list == NULL: the rows themselves): one

@@ -274,8 +274,8 @@ int launch_filter(const Plan &pl, const FilterParams &fp, int dim, hipStream_t s
 
 // re-rank: 16 lanes per row, 16 rows per block; NSI = record passes per lane (1 covers up to 16 record sets: every BASELINE shape)
 template <int MODE>
-int launch_rerank(const RerankParams &rp, int64_t rows, int dim, hipStream_t st) {
-  const dim3 grid((unsigned)((rows + 15) / 16));
+int launch_rerank(const RerankParams &rp, int64_t rows, int dim, hipStream_t st, bool stats_block = false) {
+  const dim3 grid((unsigned)((rows + 15) / 16 + (stats_block ? 1 : 0)));
 #define GQ_RR(D, G)                                                                                  \
   do {                                                                                               \
     if (rp.nsplit <= 16) hipLaunchKernelGGL((gq_rerank_kernel<MODE, D, G, 1>), grid, dim3(256), 0, st, rp); \
@@ -381,6 +381,8 @@ struct PrepInput {
   int ste_kind = 0;                             // straight-through mix where zhat is stored (gq_common.h:WsHeader)
   const float *ste = nullptr;
   float *pure = nullptr;
+  GaussStatsParams gs{};                        // want_kl2: the statistics block's parameters (kl2row is filled in by run_argmax)
+  bool *stats_done = nullptr;                   // out: the statistics block ran inside the re-rank launch (no launch of its own needed)
 };
 
 template <int MODE, bool FROM_Z>
@@ -484,6 +486,12 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   pp.z = in.z; pp.noise = in.noise; pp.zhat_noquant = in.zhat_noquant; pp.lv_min = in.lv_min; pp.lv_max = in.lv_max;
   pp.sd_layout = in.sd_layout; pp.kl2row = in.want_kl2 ? reinterpret_cast<float *>(ws + w.kl2) : nullptr;
   pp.ste_kind = in.ste_kind; pp.ste = in.ste; pp.pure = in.pure;
+  const bool stats_in_rerank = MODE == kModeGQ && in.want_kl2 && !grid_applies(n, dim, cb_cache, cb_cache_bytes);
+  if (stats_in_rerank) {
+    pp.gs = in.gs;
+    pp.gs.kl2row = pp.kl2row;
+  }
+  if (in.stats_done) *in.stats_done = stats_in_rerank;
   pp.mu = const_cast<float *>(r_mu); pp.sd = const_cast<float *>(r_sd);
   pp.lsd = const_cast<float *>(from_z ? ws_lsd : lsd);
   pp.lsd_out = (!from_z && MODE == kModeGQ && !lsd) ? ws_lsd : nullptr;
@@ -582,7 +590,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   }
 
   // ---- launch 3: exact re-rank of the candidates; rows they cannot decide are finished by their own block --------------
-  return launch_rerank<MODE>(rp, rows, (int)dim, st);
+  return launch_rerank<MODE>(rp, rows, (int)dim, st, stats_in_rerank);
 }
 
 }  // namespace
@@ -771,15 +779,17 @@ int gq_quantize_z_gauss_f32(const float *z, const float *noise, const float *cb,
   om.mode = layout == GQHIP_LAYOUT_BCHW ? 1 : 2;
   om.K = (int)K; om.L = (int)L; om.c = (int)c; om.grouping = grouping;
   if (use_ste) { in.ste_kind = 1; in.ste = zhat_noquant; in.pure = zhat_quant_or_null; }
-  int rc = run_argmax<kModeGQ>(in, nullptr, nullptr, nullptr, cb, idx, zhat, dim, rows, n, beta, workspace, workspace_bytes,
-                               cb_cache_or_null, cb_cache_bytes, om, st);
-  if (rc != GQHIP_OK) return rc;
   GaussStatsParams gp{};
-  gp.kl2row = reinterpret_cast<const float *>(static_cast<char *>(workspace) + ws_layout(rows, n, dim).kl2);
   gp.rows = (long)rows; gp.lam_state = lam_state; gp.scalars = scalars_out;
   gp.thr_hi = (float)(log2n + tolerance); gp.thr_lo = (float)(log2n - tolerance); gp.log2n = (float)log2n;
   gp.lam_factor = lam_factor; gp.lam_lo = lam_lo; gp.lam_hi = lam_hi; gp.lam_max_decreases = lam_max_decreases;
-  hipLaunchKernelGGL(gauss_stats_finalize_kernel, dim3(1), dim3(1024), 0, st, gp);
+  bool stats_done = false;
+  in.gs = gp; in.stats_done = &stats_done;
+  int rc = run_argmax<kModeGQ>(in, nullptr, nullptr, nullptr, cb, idx, zhat, dim, rows, n, beta, workspace, workspace_bytes,
+                               cb_cache_or_null, cb_cache_bytes, om, st);
+  if (rc != GQHIP_OK || stats_done) return rc;       // dims 8 / 16 / 32: the statistics block ran as one extra block of the re-rank launch
+  gp.kl2row = reinterpret_cast<const float *>(static_cast<char *>(workspace) + ws_layout(rows, n, dim).kl2);
+  hipLaunchKernelGGL(gauss_stats_finalize_kernel, dim3(1), dim3(256), 0, st, gp);
   return check_launch();
 }
 
