@@ -56,6 +56,22 @@ int main() {
                            1.0, nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;
   bad += gq_dequant_f32(nullptr, nullptr, nullptr, 1, 16, 1, 16, 1024, 0, 0, nullptr) == GQHIP_OK;
   bad += vq_argmin_f32(nullptr, nullptr, nullptr, nullptr, 16, 4, 1024, nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;
+  bad += vq_quantize_z_f32(nullptr, nullptr, nullptr, nullptr, nullptr, 1, 16, 16, 16, 1024, 0, 0.25, 1, nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;
+  {
+    char buf[64];                 // non-NULL host addresses: validation must stop at the first NULL device pointer / bad size
+    bad += vq_quantize_z_f32((const float *)buf, (const float *)buf, (int64_t *)buf, (float *)buf, nullptr, 1, 16, 16, 5, 1024, 0, 0.25, 1, nullptr, 0,
+                             nullptr, 0, nullptr) == GQHIP_OK;                                      // c % dim != 0
+    bad += vq_quantize_z_f32((const float *)buf, (const float *)buf, (int64_t *)buf, (float *)buf, nullptr, 0, 16, 16, 16, 1024, 0, 0.25, 1, nullptr,
+                             0, nullptr, 0, nullptr) != GQHIP_OK;                                  // empty batch: OK, nothing launched
+    bad += gq_quantize_z_gauss_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 16, 16, 16, 1024, 0, 1,
+                                   -30.0, 20.0, 1.0, 1, 10.0, 0.5, 1.01, 1e-7, 1e7, 0, nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;
+    bad += gq_quantize_z_gauss_f32((const float *)buf, (const float *)buf, (const float *)buf, (int64_t *)buf, (float *)buf, nullptr, (float *)buf,
+                                   nullptr, buf + 4, (double *)buf, 1, 16, 16, 16, 1024, 0, 1, -30.0, 20.0, 1.0, 1, 10.0, 0.5, 1.01, 1e-7, 1e7, 0,
+                                   nullptr, 0, nullptr, 0, nullptr) == GQHIP_OK;                  // scalars_out not 8-byte aligned
+    bad += gq_quantize_z_gauss_f32((const float *)buf, (const float *)buf, (const float *)buf, (int64_t *)buf, (float *)buf, nullptr, (float *)buf,
+                                   nullptr, buf, (double *)buf, 1, 16, 16, 16, 1024, 0, 1, -30.0, 20.0, 1.0, 1, 10.0, 0.5, 1.01, 1e-7, 1e7, 0,
+                                   nullptr, 0, nullptr, 0, nullptr) != GQHIP_ERR_WORKSPACE;       // valid arguments, no workspace
+  }
   bad += lfq_pack_f32(nullptr, nullptr, nullptr, 4, 16, nullptr) == GQHIP_OK;
   bad += lfq_pack_f32(nullptr, nullptr, nullptr, 4, 63, nullptr) == GQHIP_OK;
   bad += lfq_unpack_f32(nullptr, nullptr, 4, 0, nullptr) == GQHIP_OK;
