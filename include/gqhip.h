@@ -185,7 +185,8 @@ int gq_quantize_z_f32(const float *z, const float *noise_or_null, const float *c
                       void *cb_cache_or_null, int64_t cb_cache_bytes, void *stream);
 
 /* ---- GaussianQuantRegularizer2.forward in eval (pit/quantization/gaussian.py:211-271 quant_gaussian, :273-331 quant_vq,
- * :333-345 forward) as ONE call: gq_quantize_z_f32's launches + one one-block launch.  On top of gq_quantize_z_f32:
+ * :333-345 forward) as ONE call: gq_quantize_z_f32's launches, the re-rank launch carrying one extra block for the statistics (behind the
+ * dim-4 search and at dims without a filter: one extra one-block launch).  On top of gq_quantize_z_f32:
  *   zhat_noquant = mu + noise * sd (required here: it is the Gaussian branch's sample), sd_out_or_null = sd in the layout of zhat
  *   (info["std"]); use_ste != 0: zhat = (zhat_noquant - zhat_noquant) + code, the value of `zhat_g - zhat_g.detach() + zhat_v`
  *   (gaussian.py:337-338) in the reference's fp32 op order (a non-finite zhat_noquant makes it NaN there too), and
