@@ -107,3 +107,17 @@ def test_more_rccl_ranks_than_devices_exits_2_before_any_rendezvous_or_device_co
     assert p.returncode == 2, (p.returncode, p.stderr[-400:])
     assert "needs 8 devices" in p.stderr and "--dist-backend gloo" in p.stderr
     assert p.stdout.strip() == ""
+
+
+def test_bench_reads_the_committed_pmc_passes_per_shape():
+    """roofline.traffic comes from the committed rocprofv3 PMC passes of the config's own shape (profiles/rNN/pmc_*_<config>[_<size>].csv;
+    gq2_0.25 shares gq_0.25's: the same rows x codes x dim and filter instantiation); a shape without a committed pass reports None."""
+    import bench as b
+
+    for kernel, cfg in (("gq_filter_bf16_kernel", "gq_0.25"), ("gq_filter_bf16_kernel", "gq_0.50"), ("gq_filter_bf16_kernel", "gq2_0.25"),
+                        ("gq_grid_kernel", "gq_1.00"), ("gq_filter_bf16_kernel", "vq_16_512")):
+        traffic, prov = b.pmc_traffic(kernel, cfg)
+        assert traffic and traffic > 1e6, (kernel, cfg)
+        assert all(os.path.exists(os.path.join(b.ROOT, f)) for f in prov["files_sha256_16"]) and prov["launches_averaged"] >= 5
+    assert b.pmc_traffic("gq_filter_bf16_kernel", "gq_0.25_512") == (None, None)
+    assert b.pmc_traffic("gq_filter_bf16_kernel", None) == (None, None)
