@@ -262,3 +262,67 @@ def test_gq2_fused_forward_on_every_launch_path_vs_the_oracle(dim, n, c):
             assert same.mean() > 0.999, same.mean()
             el = np.repeat(same, dim, axis=1)
             assert np.array_equal(zh.cpu().numpy()[el], ozq[el])
+
+
+# ------------------------------------------------------------------------------------------ randomized sweep of both fused forwards
+def _fused_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([4, 8, 16, 32, 6]))
+    K = int(rng.choice([1, 2, 3])) if dim <= 8 else 1
+    n = int(rng.choice([64, 1000, 4096, 16384, 65536] if dim != 6 else [64, 500]))
+    B, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 20)), int(rng.integers(1, 20))
+    layout = str(rng.choice(["nchw", "channels_last", "last"]))
+    kind = int(rng.integers(0, 3))
+    return dim, K, n, B, h, w, layout, kind
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("GQ_FUSED_SEEDS", "16")))))
+def test_randomized_fused_forwards_vs_the_oracle(seed):
+    """Random shapes (ragged h x w, K sub-codebooks, every filter dim + a dim without one), layouts (NCHW, channels_last, channel axis
+    last) and three kinds of z, both fused forwards.  GQ2: indices identical to gq_quantize_z_f32's on the same z AND to the oracle on
+    the operands those kernels derived (strict), statistics and lambdas against the oracle's restatement; VQ: indices, straight-through
+    value and loss against the oracle's fp64 arbiter."""
+    from pit_hip import _lib
+    from pit_hip.quantization.gaussian import GaussianQuantRegularizer2
+    from pit_hip.quantization.vq import VQQuantizer
+
+    dim, K, n, B, h, w, layout, kind = _fused_case(seed)
+    c = dim * K
+    g = torch.Generator().manual_seed(seed)
+    mu = torch.randn(B, c, h, w, generator=g) * (0.9, 3.0, 0.3)[kind]
+    lv = (-1.5 + 0.3 * torch.randn(B, c, h, w, generator=g), 12.0 * torch.rand(B, c, h, w, generator=g) - 9.0,
+          0.1 * torch.randn(B, c, h, w, generator=g))[kind]
+    z = torch.cat([mu, lv], 1)
+    dim_idx = 1
+    zd = z.to(DEV)
+    if layout == "channels_last":
+        zd = zd.contiguous(memory_format=torch.channels_last)
+    elif layout == "last":
+        zd, dim_idx = zd.permute(0, 2, 3, 1).contiguous(), -1
+    m = GaussianQuantRegularizer2(dim, n, dim_idx=dim_idx).eval().to(DEV)
+    with torch.no_grad():
+        zh, info = m(zd)
+    # the same kernels through the plain module-level entry, with the operands they derived
+    zrows = z.permute(0, 2, 3, 1).reshape(1, -1, 2 * c).to(DEV)
+    idx2, _, mu_r, sd_r = _lib.gq_quantize_z(zrows, m.prior_samples, dim, "blc", _lib.GQHIP_GROUP_CONTIGUOUS, return_operands=True)
+    ind_rows = torch.movedim(info["indices"], dim_idx, -1).reshape(-1)
+    assert torch.equal(ind_rows, idx2.reshape(-1))
+    sd_np = sd_r.cpu().numpy()
+    oi, _ = O.argmax_rows(mu_r.cpu().numpy(), sd_np, m.prior_samples.cpu().numpy(), 1.0,
+                          logstd=np.log(sd_np.astype(np.float64)).astype(np.float32))
+    assert np.array_equal(ind_rows.cpu().numpy(), oi), (seed, dim, K, n, layout, kind)
+    assert torch.equal(zh, m.dequant(info["indices"])) and torch.equal(zh, info["zhat_quant"])
+    want, state = O.gq2_quant_gaussian_stats(z.numpy(), dim, n, (1.0, 1.0, 1.0))
+    for k in ("kl_loss", "bits-mean", "bits-min", "bits-max"):
+        assert _close(info[k], want[k], 3e-6), (seed, k, float(info[k]), float(want[k]))
+    assert (float(info["lam"]), float(info["lam-min"]), float(info["lam-max"])) == state
+
+    vq = VQQuantizer("bchw", n, dim, codebook_num=K).eval().to(DEV)
+    zv = mu if layout != "channels_last" else mu
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.randn(n, dim, generator=g))
+        zvd = zv.to(DEV).contiguous(memory_format=torch.channels_last) if layout == "channels_last" else zv.to(DEV)
+        zq, vinfo = vq(zvd)
+    ozq, oind, oloss, gap = O.vq_forward_eval(zv.numpy(), vq.embedding.weight.detach().cpu().numpy(), K, "bchw", vq.beta, True)
+    assert np.array_equal(vinfo["indices"].cpu().numpy(), oind), (seed, float(gap.min()))
+    assert np.array_equal(zq.cpu().numpy(), ozq) and _close(vinfo["codebook_loss"], oloss, 3e-6)
