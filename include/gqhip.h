@@ -127,6 +127,13 @@ int64_t gqhip_cb_cache_bytes(int64_t n, int64_t dim);
 /* 1 when a call with this codebook shape and a cache runs the pruned search (today: dim 4, 2^14 <= n <= 2^20, filter selection
  * AUTO), 0 when it runs filter + re-rank (dims 8 / 16 / 32 then keep the filter's fp16 codebook image in the cache). */
 int gqhip_grid_search_applies(int64_t n, int64_t dim);
+/* Synchronous (a 4-KiB device-to-host copy; never needed for correctness): what the index builder found when it sorted this codebook.
+ * 1: a DEGENERATE book for the search -- some sub-leaf holds more than 255 codes (most of the book in one cell: clustered or collapsed
+ * codebooks), so every row that lists it is handed to gq_grid_finish_kernel, a block per row: a multi-millisecond call where the dense
+ * filter + re-rank takes ~100 us; a host that sees 1 should stop passing the cache for this codebook (NULL / 0: the dense path).
+ * 0: fine.  -1: no current index in `cb_cache` (never built, stale, another shape) or a shape without a search.  pit_hip's Workspace
+ * asks once, at the call after the one that built the index.  (No reference counterpart.) */
+int gqhip_cb_cache_degenerate(const void *cb_cache, int64_t n, int64_t dim);
 
 /* ---- compat op: the reference's native boundary ---------------------------
  * out[r, j] = sum_i -((cb[j,i]-mu[r,i])/sd[r,i])^2 + cb[j,i]^2 * beta

@@ -152,6 +152,38 @@ def test_grid_non_finite_codebook_means_every_row_is_scanned():
     assert (idx == 777).all()                     # NaN score counts as the maximum (torch.argmax)
 
 
+def test_degenerate_codebook_is_routed_back_to_the_dense_path():
+    """a clustered codebook puts most codes into a couple of sub-leaves (> 255 codes each), the search hands every row
+    that lists them to the block-per-row finish kernel -- milliseconds per call.  The index builder records the fullest sub-leaf, the
+    Workspace asks ONCE (at the call after the build: gqhip_cb_cache_degenerate, a 4-KiB synchronous copy) and stops passing the cache
+    for such a book: filter + re-rank from then on.  Same indices on every call; an ordinary codebook keeps the search."""
+    import time
+
+    from pit_hip import _lib
+
+    dim, n, rows = 4, 65536, 4096
+    mu, sd = _rows(rows, dim, 31)
+    for which, degenerate in (("clustered", True), ("sobol", False)):
+        cb = _books(n, dim, which)
+        cbt = torch.from_numpy(cb).to(DEV)
+        ws = _lib.Workspace()
+        ref = None
+        ms = []
+        for call in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            idx, zhat, lsd, _ = _gq(mu, sd, cbt, ws=ws)
+            ms.append((time.perf_counter() - t0) * 1e3)
+            if ref is None:
+                ref = O.argmax_rows(mu.numpy(), sd.numpy(), cb, 1.0, logstd=lsd)
+            assert np.array_equal(idx, ref[0]) and np.array_equal(zhat, ref[1]), (which, call)
+            if call == 0:
+                assert _lib.lib().gqhip_cb_cache_degenerate(ws.cache_buf.data_ptr(), n, dim) == (1 if degenerate else 0)
+        assert ws.no_search is degenerate
+        print(f"{which}: wall ms per call {[round(m, 2) for m in ms]} (call 0 builds the index; from call 1 on: {'dense path' if degenerate else 'the search'})")
+    assert _lib.lib().gqhip_cb_cache_degenerate(None, n, dim) == -1 and _lib.lib().gqhip_cb_cache_degenerate(ws.cache_buf.data_ptr(), n, 16) == -1
+
+
 def test_cache_body_clobbered_behind_an_intact_header_stays_in_bounds():
     """the validation covers the header's stamps, not the body.  A body overwritten with garbage while the 4-KiB
     header is intact (an aliased allocation, a stray write -- a breach of the caller's half of the contract, gqhip.h) may cost wrong

@@ -54,7 +54,9 @@ struct GridHdr {                                   // first 4 KiB of the codeboo
   unsigned magic;
   int n, dim;
   int stale;                                       // set by the first launch when the codebook's hash differs; cleared by the builder
-  int pad0[12];
+  int max_sub;                                     // the builder's census: codes in the fullest sub-leaf (> 255: the search hands every row that lists
+                                                   // it to gq_grid_finish_kernel -- a degenerate book; hosts read it through gqhip_cb_cache_degenerate)
+  int pad0[11];
   float thr[8][8];                                 // per axis: the (cells - 1) ascending thresholds of its coordinate, rest +inf
   unsigned long long blk_sum[kAbsmaxParts];        // hash of the codebook slice of prep's code block k when the index was built
   int pad1[432];
@@ -193,6 +195,18 @@ __global__ __launch_bounds__(kGridBuildThreads) void gq_grid_build_kernel(const 
   };
   for (int j = tid; j < p.n; j += NT) atomicAdd(&s_cnt[sub_of_code(j)], 1);
   __syncthreads();
+  {   // census: the fullest sub-leaf (one wave-reduced atomicMax per wave into LDS)
+    __shared__ int s_maxsub;
+    if (tid == 0) s_maxsub = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int c = tid; c < kGridSubs; c += NT) mx = max(mx, s_cnt[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 0) atomicMax(&s_maxsub, mx);
+    __syncthreads();
+    if (tid == 0) gh->max_sub = s_maxsub;
+  }
 
   // ---- 3. exclusive scan of the sub-leaf counters (one leaf = four of them per thread) -> sstart[], start[], cursors in s_cnt
   {

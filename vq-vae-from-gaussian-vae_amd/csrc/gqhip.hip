@@ -635,6 +635,14 @@ int gqhip_debug_plan(int64_t rows, int64_t n, int64_t dim, int64_t *out8) {
 
 int gqhip_grid_search_applies(int64_t n, int64_t dim) { return grid_cache_bytes(n, dim) > 0 && g_filter_kind.load(std::memory_order_relaxed) == 0; }
 
+int gqhip_cb_cache_degenerate(const void *cb_cache, int64_t n, int64_t dim) {
+  if (!cb_cache || grid_cache_bytes(n, dim) <= 0) return -1;
+  GridHdr g;
+  if (hipMemcpy(&g, cb_cache, sizeof(g), hipMemcpyDeviceToHost) != hipSuccess) { (void)check_launch(); return -1; }
+  if (g.magic != kGridMagic || g.n != (int)n || g.dim != (int)dim || g.stale != 0) return -1;
+  return g.max_sub > 255 ? 1 : 0;
+}
+
 int64_t gqhip_cb_cache_bytes(int64_t n, int64_t dim) {
   if (n < 1 || dim < 1 || dim > kMaxDim) return -1;
   const int64_t g = grid_cache_bytes(n, dim);

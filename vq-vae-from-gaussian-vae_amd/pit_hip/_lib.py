@@ -37,6 +37,7 @@ _SIGNATURES = {
     "gqhip_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gqhip_cb_cache_bytes": (_i64, [_i64, _i64]),
     "gqhip_grid_search_applies": (ctypes.c_int, [_i64, _i64]),
+    "gqhip_cb_cache_degenerate": (ctypes.c_int, [_vp, _i64, _i64]),
     "gqhip_debug_grid": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_i64)]),
     "gqhip_set_filter": (ctypes.c_int, [ctypes.c_int]),
     "gqhip_get_filter": (ctypes.c_int, []),
@@ -184,12 +185,14 @@ class Workspace:
         self.buf: Optional[torch.Tensor] = None
         self.cache_buf: Optional[torch.Tensor] = None
         self._cache_key = None
+        self._cache_calls = 0     # calls that were handed the current cache buffer
+        self.no_search = False    # the dim-4 index of this codebook was found degenerate (gqhip_cb_cache_degenerate): dense path from then on
         self._pinned = False      # True once a graph capture has used this buffer: it must never be replaced
 
     def cache(self, n: int, dim: int, device) -> Tuple[Optional[int], int]:
         """(pointer, bytes) of the codebook cache for (n, dim), or (None, 0) for shapes that keep none."""
         need = lib().gqhip_cb_cache_bytes(n, dim)
-        if need <= 0:
+        if need <= 0 or self.no_search:
             return None, 0
         key = (n, dim, device)
         if self.cache_buf is None or self._cache_key != key or self.cache_buf.numel() < need:
@@ -198,6 +201,16 @@ class Workspace:
                                  "this Workspace: run a warm-up call of the same codebook shape before capturing")
             self.cache_buf = torch.zeros(need, dtype=torch.uint8, device=device)    # zeros: no stamp -> built by the first call
             self._cache_key = key
+            self._cache_calls = 0
+        # ONE look at what the index builder found, at the call after the one that built it (a 4-KiB synchronous copy, once per
+        # cache buffer): a clustered / collapsed codebook puts most codes into one sub-leaf, and the search then hands every row to
+        # the block-per-row finish kernel -- milliseconds per call where filter + re-rank takes ~100 us.  Such a book goes
+        # back to the dense path for good (always exact; a codebook that changes every step should not pass a cache at all: vq.py).
+        self._cache_calls += 1
+        if self._cache_calls == 2 and lib().gqhip_grid_search_applies(n, dim) and not torch.cuda.is_current_stream_capturing():
+            if lib().gqhip_cb_cache_degenerate(self.cache_buf.data_ptr(), n, dim) == 1:
+                self.no_search = True
+                return None, 0
         return self.cache_buf.data_ptr(), self.cache_buf.numel()
 
     def reserve(self, rows: int, n: int, dim: int, device) -> None:
