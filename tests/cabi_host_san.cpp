@@ -72,6 +72,7 @@ int main() {
                                    nullptr, buf, (double *)buf, 1, 16, 16, 16, 1024, 0, 1, -30.0, 20.0, 1.0, 1, 10.0, 0.5, 1.01, 1e-7, 1e7, 0,
                                    nullptr, 0, nullptr, 0, nullptr) != GQHIP_ERR_WORKSPACE;       // valid arguments, no workspace
   }
+  bad += gqhip_cb_cache_degenerate(nullptr, 65536, 4) != -1;
   bad += lfq_pack_f32(nullptr, nullptr, nullptr, 4, 16, nullptr) == GQHIP_OK;
   bad += lfq_pack_f32(nullptr, nullptr, nullptr, 4, 63, nullptr) == GQHIP_OK;
   bad += lfq_unpack_f32(nullptr, nullptr, 4, 0, nullptr) == GQHIP_OK;

@@ -58,7 +58,7 @@ def _x512():
 
 
 # ------------------------------------------------------------------------------------------ checkpoint-shaped weights
-from ckpt_like import checkpoint_like_ as _checkpoint_like_  # noqa: E402  (shared with tests/golden/make_golden_r4.py)
+_checkpoint_like_ = checkpoint_like_      # (shared with tests/golden/make_golden_r4.py)
 
 
 def _trained_like_engine(d):
