@@ -41,7 +41,7 @@ __device__ __forceinline__ void gauss_stats_block(const GaussStatsParams &p) {
   };
   // rows in slabs of 1024 (one per virtual lane), four slabs' loads in flight at once: the block is one latency chain otherwise
   // (virtual lane v still adds its rows in ascending order: the result does not depend on the unrolling)
-  constexpr int UN = 4;
+  constexpr int UN = 2;
   long base = 0;
   for (; base + (long)UN * NT * VL <= p.rows; base += (long)UN * NT * VL) {
     float k[UN][VL];

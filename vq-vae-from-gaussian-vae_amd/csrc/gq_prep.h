@@ -435,8 +435,10 @@ __global__ __launch_bounds__(256) void gq_prep_kernel(const PrepParams p) {
   if (e_out < p.rows * DIM) {
     if constexpr (FROM_Z) {
       p.mu[e_out] = s_mu[tid];
-      p.sd[e_out] = s_sd[tid];
-      p.lsd[e_out] = s_lsd[tid];
+      if constexpr (MODE == kModeGQ) {               // (VQ has no sd / log sd rows: 8 bytes per element less to write)
+        p.sd[e_out] = s_sd[tid];
+        p.lsd[e_out] = s_lsd[tid];
+      }
     } else if (MODE == kModeGQ && p.lsd_out) {
       p.lsd_out[e_out] = s_lsd[tid];
     }

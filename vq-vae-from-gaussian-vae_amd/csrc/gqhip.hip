@@ -438,7 +438,7 @@ int run_argmax(const PrepInput &in, const float *mu, const float *sd, const floa
   const float *r_lsd = from_z ? ws_lsd : (MODE == kModeGQ ? (lsd ? lsd : (pl.mfma ? ws_lsd : nullptr)) : nullptr);
 
   RerankParams rp{};
-  rp.mu = r_mu; rp.sd = r_sd; rp.lsd = r_lsd; rp.cb = cb;
+  rp.mu = r_mu; rp.sd = MODE == kModeGQ ? r_sd : nullptr; rp.lsd = r_lsd; rp.cb = cb;
   rp.rowsum = reinterpret_cast<const double *>(ws + w.rowsum);
   rp.coef = reinterpret_cast<const float *>(ws + w.coef);
   rp.rec = reinterpret_cast<const Rec *>(ws + w.rec);
