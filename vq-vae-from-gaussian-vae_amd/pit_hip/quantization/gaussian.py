@@ -7,7 +7,12 @@ pit/quantization/gaussian.py): same constructor keywords, same ``forward(z) ->
 (gaussian.py:120-160 and :273-331) runs as ONE call into libgqhip.so
 (``gq_quantize_z_f32``): chunk / clamp / exp, the group permutes, the
 rows x 65 536 score matrix, the arg-max and the codeword gather are all inside
-the HIP kernels and the score matrix never exists in HBM.
+the HIP kernels and the score matrix never exists in HBM.  For
+``GaussianQuantRegularizer2`` the whole eval forward (gaussian.py:333-345: the
+Gaussian branch's sample, KL statistics, re-weighted loss and lambda state
+machine, quant_vq, the straight-through mix) is ONE call as well
+(``gq_quantize_z_gauss_f32``) whenever autograd is not recording; the lambda
+state then advances on the device and is read back only when somebody looks.
 
 backend:
   "hip"   fused path (default here).
