@@ -120,7 +120,8 @@ int64_t gqhip_workspace_bytes(int64_t rows, int64_t n, int64_t dim);
  * codebook, a fresh buffer or one overwritten as a whole all cost one rebuild and never a wrong index.  What the validation does NOT
  * cover is a write into the BODY of a cache whose 4-KiB header (the stamps) is left intact -- the "never writes it" above is the
  * caller's half of the contract; the dim-4 search still bounds every offset and index it reads from the body by the codebook size,
- * so such a write can cost a wrong index but never an out-of-range access (csrc/gq_grid.h).  One cache serves one stream at a time.
+ * so such a write can cost a wrong index but never an out-of-range access (csrc/gq_grid.h); the fp16 image of dims 8 / 16 / 32 is only
+ * ever multiplied -- no address is derived from it.  One cache serves one stream at a time.
  * Without a cache (NULL) every shape runs the filter + re-rank path.  (No reference counterpart: the reference recomputes
  * everything per call, pit/quantization/gaussian.py:136-150.) */
 int64_t gqhip_cb_cache_bytes(int64_t n, int64_t dim);
