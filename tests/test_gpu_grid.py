@@ -152,6 +152,40 @@ def test_grid_non_finite_codebook_means_every_row_is_scanned():
     assert (idx == 777).all()                     # NaN score counts as the maximum (torch.argmax)
 
 
+@pytest.mark.parametrize("dim", [8, 16])
+def test_image_cache_body_clobbered_behind_intact_stamps_stays_in_range(dim):
+    """The same breach of the cache contract at dims 8 / 16 (gqhip.h): the cached fp16 image overwritten while its 256 stamps stay
+    intact.  The image is only ever multiplied -- no address is derived from it --, so the call completes with every index in
+    [0, n) (garbage that is not finite even lands on the exhaustive finish and stays right); a zeroed stamp area repairs it."""
+    from pit_hip import _lib
+
+    n, rows = 65536, 512
+    if _lib.lib().gqhip_cb_cache_bytes(n, dim) <= 0:
+        pytest.skip("no cached image for this dim with the current filter selection")
+    cb0 = O.codebook(n, dim, 42)
+    cbt = torch.from_numpy(cb0.copy()).to(DEV)
+    mu, sd = _rows(rows, dim, 29)
+    ws = _lib.Workspace()
+    idx0, zhat0, lsd, _ = _gq(mu, sd, cbt, ws=ws)
+    ref_idx, ref_zhat = O.argmax_rows(mu.numpy(), sd.numpy(), cb0, 1.0, logstd=lsd)
+    assert np.array_equal(idx0, ref_idx)
+    g = torch.Generator().manual_seed(6)
+    for kind in ("random bytes", "zeros", "fp16 ones"):
+        body = ws.cache_buf[4096:]
+        if kind == "random bytes":
+            body.copy_(torch.randint(0, 256, body.shape, dtype=torch.uint8, generator=g).to(DEV))
+        elif kind == "zeros":
+            body.zero_()
+        else:
+            body.view(torch.float16).fill_(1.0)
+        idx, zhat, _, _ = _gq(mu, sd, cbt, ws=ws)              # stamps intact: the garbage image is used
+        assert idx.min() >= 0 and idx.max() < n, kind
+        assert np.array_equal(zhat, cb0[idx]), kind            # zhat is gathered from the caller's codebook: consistent with the index
+        ws.cache_buf[:4096].zero_()
+        idx, zhat, _, _ = _gq(mu, sd, cbt, ws=ws)
+        assert np.array_equal(idx, ref_idx) and np.array_equal(zhat, ref_zhat), kind
+
+
 def test_degenerate_codebook_is_routed_back_to_the_dense_path():
     """a clustered codebook puts most codes into a couple of sub-leaves (> 255 codes each), the search hands every row
     that lists them to the block-per-row finish kernel -- milliseconds per call.  The index builder records the fullest sub-leaf, the
